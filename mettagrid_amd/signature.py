@@ -1,0 +1,79 @@
+"""Generalised deterministic episode signature.
+
+The reference's parity script (/root/reference/scripts/deterministic_episode_signature.py:19-47,97-110) hashes a
+JSON payload of objects + stats + rewards for ONE fixed scenario.  This module restates the payload function so it
+can be applied to any engine state: the reference (through its ``grid_objects()`` / ``get_episode_stats()``), the CPU
+oracle and the HIP engine (through their raw object/stat dumps).  Same schema, same rounding (8 decimals), same
+``json.dumps(sort_keys=True, separators=(",", ":"))`` + SHA-256.
+"""
+from __future__ import annotations
+
+import hashlib
+import json
+
+import numpy as np
+
+_MAXR = 13
+
+
+def _round(v) -> float:
+    return round(float(v), 8)
+
+
+def stats_dicts(prog, gv, gt, av, at) -> dict:
+    """Raw stat arrays + touched flags -> {"game": {name: value}, "agent": [{...}]} (keys exist once touched:
+    cpp/include/mettagrid/systems/stats_tracker.hpp:57-67,109-115)."""
+    game = {prog.game_stat_names[i]: float(gv[i]) for i in range(len(gv)) if gt[i]}
+    agents = [{prog.agent_stat_names[i]: float(av[a, i]) for i in range(av.shape[1]) if at[a, i]}
+              for a in range(av.shape[0])]
+    return {"game": game, "agent": agents}
+
+
+def objects_from_raw(prog, raw: np.ndarray, current_stat_reward=None) -> dict:
+    """Raw object records (see mgx.h mgx_get_objects) -> reference ``grid_objects()``-shaped dict
+    (cpp/bindings/mettagrid_py.cpp:28-139; only the fields the signature and tests use)."""
+    from .fmt import K
+    words = prog.words
+    coff = int(words[K.H_SECTION_BASE + 2 * K.SEC_CLASSES])
+    out = {}
+    for rec in raw:
+        oid, cls, r, c, vibe, alive, agent_id, norder = (int(x) for x in rec[:8])
+        if not alive:
+            continue
+        C = words[coff + cls * K.C_WORDS: coff + (cls + 1) * K.C_WORDS]
+        tags = [t for t in range(256) if (int(C[K.C_TAGS + (t >> 5)]) >> (t & 31)) & 1]
+        amounts = rec[8 + _MAXR: 8 + 2 * _MAXR]
+        d = {"id": oid, "type_name": prog.type_names[int(C[K.C_TYPE_ID])], "r": r, "c": c, "location": (c, r),
+             "tag_ids": tags, "vibe": vibe,
+             "inventory": {i: int(amounts[i]) for i in range(_MAXR) if amounts[i] > 0},
+             "inventory_order": [int(x) for x in rec[8:8 + norder]]}
+        if agent_id >= 0:
+            d["agent_id"] = agent_id
+            d["group_id"] = int(C[K.C_GROUP])
+            d["current_stat_reward"] = float(current_stat_reward[agent_id]) if current_stat_reward is not None else 0.0
+        out[oid] = d
+    return out
+
+
+def payload(objects: dict, stats: dict, action_success, episode_rewards, steps: int, seed: int) -> dict:
+    objs = []
+    for obj_id, obj in sorted(objects.items()):
+        entry = {"id": int(obj_id), "type_name": obj["type_name"], "location": [int(obj["r"]), int(obj["c"])],
+                 "tag_ids": [int(t) for t in obj.get("tag_ids", [])],
+                 "inventory_items": [(int(k), int(v)) for k, v in sorted(obj.get("inventory", {}).items())]}
+        if "agent_id" in obj:
+            entry["agent_id"] = int(obj["agent_id"])
+            entry["group_id"] = int(obj["group_id"])
+            entry["vibe"] = int(obj["vibe"])
+            entry["current_stat_reward"] = _round(obj["current_stat_reward"])
+        objs.append(entry)
+    return {
+        "seed": int(seed), "steps": int(steps), "action_success": [bool(x) for x in action_success],
+        "episode_reward": [_round(v) for v in episode_rewards], "objects": objs,
+        "stats": {"game": [(n, _round(v)) for n, v in sorted(stats["game"].items())],
+                  "agent": [[(n, _round(v)) for n, v in sorted(a.items())] for a in stats["agent"]]},
+    }
+
+
+def signature(p: dict) -> str:
+    return hashlib.sha256(json.dumps(p, sort_keys=True, separators=(",", ":")).encode("utf-8")).hexdigest()

@@ -1,0 +1,115 @@
+"""TEST INFRASTRUCTURE ONLY — ctypes wrapper of the CPU restatement (oracle/libmgx_oracle.so).
+
+Used by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg as the CHECKER.  Never imported by the
+product package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "libmgx_oracle.so")
+_lib = None
+_MAXR = 13
+_RW = 8 + 2 * _MAXR
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_HERE, "mgx_oracle.cpp")
+    hdr = os.path.join(os.path.dirname(_HERE), "include", "mgx_program.h")
+    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-I", os.path.dirname(hdr), "-o", _LIB, src])
+    return _LIB
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB)
+        L.mgxo_create.restype = C.c_void_p
+        L.mgxo_create.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+        for name in ("mgxo_obs", "mgxo_rewards", "mgxo_episode_rewards", "mgxo_terminals", "mgxo_truncations",
+                     "mgxo_action_success"):
+            getattr(L, name).restype = C.c_void_p
+            getattr(L, name).argtypes = [C.c_void_p]
+        L.mgxo_destroy.argtypes = [C.c_void_p]
+        L.mgxo_reinit_buffers.argtypes = [C.c_void_p]
+        L.mgxo_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.mgxo_error.argtypes = [C.c_void_p]
+        L.mgxo_current_step.argtypes = [C.c_void_p]
+        L.mgxo_current_step.restype = C.c_uint32
+        L.mgxo_num_objects.argtypes = [C.c_void_p]
+        L.mgxo_objects.argtypes = [C.c_void_p, C.c_void_p]
+        L.mgxo_stats.argtypes = [C.c_void_p] + [C.c_void_p] * 4
+        L.mgxo_reward_state.argtypes = [C.c_void_p, C.c_void_p]
+        L.mgxo_selftest_shuffle.argtypes = [C.c_uint32, C.c_int, C.c_int]
+        _lib = L
+    return _lib
+
+
+def _view(ptr, shape, dtype):
+    n = int(np.prod(shape))
+    buf = (C.c_uint8 * (n * np.dtype(dtype).itemsize)).from_address(ptr)
+    return np.frombuffer(buf, dtype=dtype).reshape(shape)
+
+
+class OracleSim:
+    def __init__(self, prog, class_map: np.ndarray, seed: int) -> None:
+        self.prog = prog
+        self.L = lib()
+        self.words = np.ascontiguousarray(prog.words, dtype=np.int32)
+        cm = np.ascontiguousarray(class_map, dtype=np.uint16)
+        self.h = self.L.mgxo_create(self.words.ctypes.data, cm.ctypes.data, int(seed) & 0xFFFFFFFF)
+        if not self.h:
+            raise RuntimeError("mgxo_create failed (bad program)")
+        self.A, self.T = prog.num_agents, prog.num_tokens
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.mgxo_destroy(self.h)
+            self.h = None
+
+    def step(self, actions, vibe_actions=None) -> None:
+        a = np.ascontiguousarray(actions, dtype=np.int32)
+        v = np.zeros(self.A, np.int32) if vibe_actions is None else np.ascontiguousarray(vibe_actions, dtype=np.int32)
+        self.L.mgxo_step(self.h, a.ctypes.data, v.ctypes.data)
+
+    def snapshot(self) -> dict:
+        A, T, L, h = self.A, self.T, self.L, self.h
+        return dict(obs=_view(L.mgxo_obs(h), (A, T, 3), np.uint8).copy(),
+                    rewards=_view(L.mgxo_rewards(h), (A,), np.float32).copy(),
+                    terminals=_view(L.mgxo_terminals(h), (A,), np.uint8).astype(bool),
+                    truncations=_view(L.mgxo_truncations(h), (A,), np.uint8).astype(bool),
+                    action_success=_view(L.mgxo_action_success(h), (A,), np.uint8).astype(bool),
+                    episode_rewards=_view(L.mgxo_episode_rewards(h), (A,), np.float32).copy())
+
+    @property
+    def error(self) -> int:
+        return self.L.mgxo_error(self.h)
+
+    @property
+    def current_step(self) -> int:
+        return self.L.mgxo_current_step(self.h)
+
+    def raw_objects(self) -> np.ndarray:
+        n = self.L.mgxo_num_objects(self.h)
+        out = np.zeros((n, _RW), np.int32)
+        self.L.mgxo_objects(self.h, out.ctypes.data)
+        return out
+
+    def raw_stats(self):
+        ng, na = len(self.prog.game_stat_names), len(self.prog.agent_stat_names)
+        gv, gt = np.zeros(ng, np.float32), np.zeros(ng, np.uint8)
+        av, at = np.zeros((self.A, na), np.float32), np.zeros((self.A, na), np.uint8)
+        self.L.mgxo_stats(self.h, gv.ctypes.data, gt.ctypes.data, av.ctypes.data, at.ctypes.data)
+        return gv, gt, av, at
+
+    def current_stat_reward(self) -> np.ndarray:
+        out = np.zeros(self.A, np.float32)
+        self.L.mgxo_reward_state(self.h, out.ctypes.data)
+        return out
