@@ -1,0 +1,110 @@
+/*
+ * mgx.h — C ABI of libmgx, the MI355X-native MettaGrid step engine (batched: E independent envs per engine).
+ *
+ * Drop-in boundary.  Each entry point replaces one member of the reference's pybind11 class `MettaGrid`
+ * (module mettagrid.mettagrid_c, /root/reference/cpp/bindings/mettagrid_py.cpp:242-397); the cited lines are the
+ * reference interface it stands in for.  Plain pointers and sizes only; every call returns an int status
+ * (0 = ok, <0 = error, text via mgx_last_error) — no exceptions cross the ABI.  The Python mirror of the pybind
+ * class lives in mettagrid_amd/engine.py; INTEGRATION.md shows the binding a reference maintainer would add.
+ *
+ * Buffers follow the reference dtypes (cpp/include/mettagrid/core/types.hpp:46-64), batched over envs:
+ *   observations u8 [E*A][T][3], terminals/truncations u8(bool) [E*A], rewards f32 [E*A],
+ *   actions / vibe_actions i32 [E*A].   Agent (env e, index i) is row e*A + i.
+ */
+#ifndef MGX_H_
+#define MGX_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mgx_engine mgx_engine;
+
+enum { MGX_OK = 0, MGX_ERR_BAD_ARG = -1, MGX_ERR_HIP = -2, MGX_ERR_PROGRAM = -3, MGX_ERR_ENV = -4 };
+enum { MGX_MEM_HOST = 0, MGX_MEM_DEVICE = 1 };
+
+/* Per-env error bits (mgx_poll_errors): what the reference reports by throwing. */
+enum {
+  MGX_ENV_TOKEN_OVERFLOW = 1,   /* std::runtime_error "Observation token budget exceeded" mettagrid_c.cpp:364-375 */
+  MGX_ENV_INVALID_KEY_RANGE = 2,/* action.invalid_index.<k> outside the tracked window (include/mgx_program.h) */
+  MGX_ENV_DEPTH = 4,            /* handler / inventory-limit recursion deeper than the engine supports */
+  MGX_ENV_TOO_MANY_OBJECTS = 8  /* map holds more objects than MGX_H_MAX_OBJECTS slots */
+};
+
+/* MettaGrid(GameConfig, map, seed) — cpp/bindings/mettagrid_c.cpp:42-191, _init_grid :200-269.
+ * program:    int32 blob of include/mgx_program.h (the compiled GameConfig).
+ * class_maps: uint16 [num_envs][H][W], class index + 1 (0 = empty) — the map after per-agent renaming.
+ * seeds:      uint32 [num_envs] (std::mt19937 seed of each env, mettagrid_c.cpp:52).
+ * device:     HIP device ordinal.  The engine owns its device state and a HIP stream. */
+int mgx_create(const int32_t* program, size_t program_words, const uint16_t* class_maps, const uint32_t* seeds,
+               int32_t num_envs, int32_t device, mgx_engine** out);
+void mgx_destroy(mgx_engine* e);
+
+/* MettaGrid::set_buffers — mettagrid_c.cpp:1165-1184 (stores the caller's buffers by reference, validates shapes,
+ * clears them and computes the initial observations).  MGX_MEM_DEVICE: pointers are device memory and the engine
+ * writes into them directly (zero-copy, like the reference's shared numpy arrays).  MGX_MEM_HOST: the engine keeps
+ * device mirrors and copies actions in / results out on every step (PCIe-inclusive path).
+ * n_rows must equal E*A and n_tokens the program's token budget, else MGX_ERR_BAD_ARG (validate_buffers :1104-1150).
+ * Passing all-NULL pointers re-binds the engine's own internal buffers. */
+int mgx_set_buffers(mgx_engine* e, uint8_t* observations, uint8_t* terminals, uint8_t* truncations, float* rewards,
+                    int32_t* actions, int32_t* vibe_actions, int64_t n_rows, int64_t n_tokens, int32_t mem_kind);
+
+/* MettaGrid::step — mettagrid_c.cpp:1186-1205 / _step :921-1102.  Enqueues one tick for all envs on the engine's
+ * stream and returns without waiting (device buffers) or after the results are back in host memory (host buffers). */
+int mgx_step(mgx_engine* e);
+/* Wait for all enqueued work. */
+int mgx_sync(mgx_engine* e);
+/* The engine's hipStream_t (as void*) so callers can order their own work / record events on it. */
+void* mgx_stream(mgx_engine* e);
+
+/* Pointers to the currently bound buffers (observations(), rewards(), ... accessors, mettagrid_py.cpp:291-299);
+ * device or host according to mem_kind. */
+int mgx_get_buffers(mgx_engine* e, uint8_t** observations, uint8_t** terminals, uint8_t** truncations,
+                    float** rewards, int32_t** actions, int32_t** vibe_actions, int32_t* mem_kind);
+
+/* get_episode_rewards() — mettagrid_py.cpp:151-153.  Copies f32 [E*A] to host memory. */
+int mgx_get_episode_rewards(mgx_engine* e, float* out);
+/* action_success() — mettagrid_py.cpp:196-198.  Copies u8 [E*A]. */
+int mgx_get_action_success(mgx_engine* e, uint8_t* out);
+/* current_step — mettagrid_py.cpp:306.  Copies u32 [E]. */
+int mgx_get_current_steps(mgx_engine* e, uint32_t* out);
+
+/* get_episode_stats() — mettagrid_py.cpp:161-179.  For env `env`: values + "touched" flags (a key is present in
+ * the reference's dict once touched).  game_* hold NUM_GAME_STATS entries, agent_* hold A * NUM_AGENT_STATS. */
+int mgx_get_stats(mgx_engine* e, int32_t env, float* game_values, uint8_t* game_touched, float* agent_values,
+                  uint8_t* agent_touched);
+
+/* grid_objects() — mettagrid_py.cpp:28-139.  One record of MGX_OBJ_RECORD_WORDS int32 per object slot of env `env`:
+ * [0] id (slot+1)  [1] class  [2] r  [3] c  [4] vibe  [5] alive  [6] agent_id or -1  [7] n inventory items,
+ * [8..20] inventory items in the reference's iteration order (-1 padded), [21..33] amount by resource id.
+ * Returns the number of records written via *n_objects; `out` must hold MAX_OBJECTS records. */
+#define MGX_OBJ_RECORD_WORDS 34
+int mgx_get_objects(mgx_engine* e, int32_t env, int32_t* out, int32_t* n_objects);
+/* current_stat_reward per agent of env `env` (RewardHelper::current_reward, systems/reward.hpp:36-42). f32 [A]. */
+int mgx_get_reward_state(mgx_engine* e, int32_t env, float* out);
+
+/* OR of the per-env error bits over all envs; if first_env != NULL receives the first env with a bit set (or -1).
+ * Replaces the exceptions thrown from inside step() in the reference. */
+int mgx_poll_errors(mgx_engine* e, uint32_t* bits, int32_t* first_env);
+
+/* Device time of the most recent mgx_step in milliseconds, per kernel: [0] world-update kernel, [1] observation
+ * kernel (hipEvents on the engine stream; replaces MettaGrid.step_timing, cpp/bindings/profiling_py.cpp:8-30).
+ * Only recorded after mgx_set_profiling(e, 1). */
+int mgx_set_profiling(mgx_engine* e, int32_t enabled);
+int mgx_get_step_timing(mgx_engine* e, float* ms_out /* [2] */);
+
+/* Shape queries. */
+int32_t mgx_num_envs(const mgx_engine* e);
+int32_t mgx_num_agents(const mgx_engine* e);   /* per env */
+int32_t mgx_num_tokens(const mgx_engine* e);
+int64_t mgx_state_bytes(const mgx_engine* e);  /* device bytes held by the engine */
+
+const char* mgx_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MGX_H_ */

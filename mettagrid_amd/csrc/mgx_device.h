@@ -1,0 +1,117 @@
+// mgx_device.h — device-side state layout and small helpers of the MI355X MettaGrid step engine.
+//
+// State lives in HBM for the whole episode.  Two layouts are used on purpose (see DESIGN.md "Data layout"):
+//   * ENV-MAJOR blocks  [env][...]  for spatial/object/agent state: the observation kernel maps one workgroup to
+//     one env and streams that env's grid block with coalesced 16-byte loads into LDS; the world-update kernel
+//     (one env per wavefront lane) touches only a few dozen scattered cells/records per env and step.
+//   * ENV-MINOR arrays  [word][env]  for the per-env Mersenne-Twister state: all 64 lanes of a wavefront read the
+//     same word index of 64 consecutive envs -> one coalesced 256-byte access per draw.
+#ifndef MGX_DEVICE_H_
+#define MGX_DEVICE_H_
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mgx_program.h"
+
+#define MGX_WAVE 64
+#define MGX_NO_AGENT 0xFF
+#define MGX_DEAD_CLASS 0xFFFF
+
+struct MgxDev {
+  const int32_t* P;       // program blob (device copy)
+  int sec[MGX_SEC_COUNT]; // section offsets (words) — hoisted from the header
+  int E, H, W, A, S, R, T;
+  int NS, NG, NSW, NGW;   // agent/game stat counts and their touched-bit word counts
+  int NRW;                // reward "prev value" slots per agent (max over classes)
+  int SEENW;              // words of the per-agent visited-cell bitmap
+  int NOFF;               // observation offsets
+  int base;               // token_value_base
+  int max_steps, truncates, max_priority, nact, flags, hp_res, n_obs_values, n_move_handlers;
+  int feat[16];
+  int wk[32];             // well-known stat ids (MGX_S_*)
+
+  // ---- env-major object state ----
+  uint16_t* grid;         // [E][H*W]   0 = empty, else slot + 1
+  uint16_t* obj_cls;      // [E][S]     class id, MGX_DEAD_CLASS = unused slot
+  uint16_t* obj_rc;       // [E][S]     (r << 8) | c
+  uint8_t* obj_vibe;      // [E][S]
+  uint8_t* obj_agent;     // [E][S]     agent index or MGX_NO_AGENT
+  uint32_t* obj_visited;  // [E][S]     GridObject::visited (core/grid_object.hpp:113)
+  uint16_t* obj_inv;      // [E][S][R]  amount by resource id
+  unsigned long long* obj_order;  // [E][S] inventory iteration order: 4-bit ids, begin() in the low nibble, 0xF ends
+  uint32_t* num_objs;     // [E]
+  // ---- env-major agent state ----
+  uint16_t* ag_obj;       // [E][A] slot of agent i
+  uint16_t* ag_prev;      // [E][A] Agent::prev_location
+  uint16_t* ag_spawn;     // [E][A]
+  uint16_t* ag_stepprev;  // [E][A] MettaGrid::_prev_agent_locations
+  uint32_t* ag_swm;       // [E][A] steps_without_motion
+  uint32_t* ag_maxdist;   // [E][A]
+  uint32_t* ag_unique;    // [E][A]
+  uint32_t* ag_seen;      // [E][A][SEENW]
+  float* ag_rprev;        // [E][A][NRW]
+  float* ag_stats;        // [E][A][NS]
+  uint32_t* ag_touched;   // [E][A][NSW]
+  float* game_stats;      // [E][NG]
+  uint32_t* game_touched; // [E][NGW]
+  uint32_t* step;         // [E]
+  uint32_t* err;          // [E]
+  int32_t* executed;      // [E][A] action executed this step (0 = noop / failed)
+  uint8_t* success;       // [E][A]
+  float* episode_rewards; // [E*A]
+  // ---- env-minor RNG ----
+  uint32_t* mt;           // [624][E]
+  uint32_t* mt_idx;       // [E]
+  // ---- caller-visible buffers (device pointers) ----
+  uint8_t* obs;           // [E*A][T][3]
+  float* rewards;         // [E*A]
+  uint8_t* terminals;     // [E*A]
+  uint8_t* truncations;   // [E*A]
+  const int32_t* actions;       // [E*A]
+  const int32_t* vibe_actions;  // [E*A]
+};
+
+__device__ __forceinline__ const int32_t* mgx_cls(const MgxDev& d, int cls) {
+  return d.P + d.sec[MGX_SEC_CLASSES] + cls * MGX_C_WORDS;
+}
+__device__ __forceinline__ int mgx_wk(const MgxDev& d, int s) { return d.wk[s]; }
+
+// glibc 2.35 logf restated (sysdeps/ieee754/flt-32/e_logf.c; table e_logf_data.c).  The reference calls
+// std::log(float) in SumValue(log=True) (cpp/src/mettagrid/core/game_value.cpp:77-79) and the parity signature
+// exposes every bit of it.  tests/golden/logf_check.c proves this restatement equal to the host libm for all
+// 2 139 095 039 positive finite floats.  Double arithmetic with contraction disabled.
+__device__ __noinline__ float mgx_logf(float x) {
+#pragma clang fp contract(off)
+  const double INVC[16] = {0x1.661ec79f8f3bep+0, 0x1.571ed4aaf883dp+0, 0x1.49539f0f010bp+0,  0x1.3c995b0b80385p+0,
+                           0x1.30d190c8864a5p+0, 0x1.25e227b0b8eap+0,  0x1.1bb4a4a1a343fp+0, 0x1.12358f08ae5bap+0,
+                           0x1.0953f419900a7p+0, 0x1p+0,               0x1.e608cfd9a47acp-1, 0x1.ca4b31f026aap-1,
+                           0x1.b2036576afce6p-1, 0x1.9c2d163a1aa2dp-1, 0x1.886e6037841edp-1, 0x1.767dcf5534862p-1};
+  const double LOGC[16] = {-0x1.57bf7808caadep-2, -0x1.2bef0a7c06ddbp-2, -0x1.01eae7f513a67p-2, -0x1.b31d8a68224e9p-3,
+                           -0x1.6574f0ac07758p-3, -0x1.1aa2bc79c81p-3,   -0x1.a4e76ce8c0e5ep-4, -0x1.1973c5a611cccp-4,
+                           -0x1.252f438e10c1ep-5, 0x0p+0,                0x1.aa5aa5df25984p-5,  0x1.c5e53aa362eb4p-4,
+                           0x1.526e57720db08p-3,  0x1.bc2860d22477p-3,   0x1.1058bc8a07ee1p-2,  0x1.4043057b6ee09p-2};
+  uint32_t ix = __float_as_uint(x);
+  if (ix == 0x3f800000u) return 0.0f;
+  if (ix - 0x00800000u >= 0x7f800000u - 0x00800000u) {
+    if (ix * 2u == 0u) return -__builtin_inff();
+    if (ix == 0x7f800000u) return x;
+    if ((ix & 0x80000000u) || ix * 2u >= 0xff000000u) return __builtin_nanf("");
+    ix = __float_as_uint(x * 0x1p23f);
+    ix -= 23u << 23;
+  }
+  uint32_t tmp = ix - 0x3f330000u;
+  int i = (int)((tmp >> 19) & 15u);
+  int k = (int32_t)tmp >> 23;
+  uint32_t iz = ix - (tmp & 0xff800000u);
+  double z = (double)__uint_as_float(iz);
+  double r = z * INVC[i] - 1.0;
+  double y0 = LOGC[i] + (double)k * 0x1.62e42fefa39efp-1;
+  double r2 = r * r;
+  double y = 0x1.5575b0be00b6ap-2 * r + -0x1.ffffef20a4123p-2;
+  y = -0x1.00ea348b88334p-2 * r2 + y;
+  y = y * r2 + (y0 + r);
+  return (float)y;
+}
+
+#endif  // MGX_DEVICE_H_

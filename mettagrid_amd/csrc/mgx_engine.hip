@@ -1,0 +1,434 @@
+// mgx_engine.hip — host side of libmgx: device state allocation, kernel launches and the C ABI of include/mgx.h.
+// gfx950 only.  There is NO CPU fallback in this library: every entry point that computes runs HIP kernels.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "mgx.h"
+#include "mgx_device.h"
+#include "mgx_obs.h"
+#include "mgx_world.h"
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+#define HIP_TRY(expr)                                                                              \
+  do {                                                                                             \
+    hipError_t _e = (expr);                                                                        \
+    if (_e != hipSuccess)                                                                          \
+      return fail(MGX_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));                 \
+  } while (0)
+
+struct mgx_engine {
+  MgxDev d{};
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::vector<void*> allocs;
+  int64_t state_bytes = 0;
+  std::vector<int32_t> prog;
+  // internally owned caller-visible buffers (always allocated; bound by default)
+  uint8_t *own_obs = nullptr, *own_term = nullptr, *own_trunc = nullptr;
+  float* own_rew = nullptr;
+  int32_t *own_act = nullptr, *own_vact = nullptr;
+  // host-bound buffers (MGX_MEM_HOST)
+  int mem_kind = MGX_MEM_DEVICE;
+  uint8_t *h_obs = nullptr, *h_term = nullptr, *h_trunc = nullptr;
+  float* h_rew = nullptr;
+  int32_t *h_act = nullptr, *h_vact = nullptr;
+  bool external = false;
+  size_t lds_world = 0, lds_obs = 0;
+  bool profiling = false;
+  hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+  float last_ms[2] = {0.f, 0.f};
+
+  template <class T>
+  int alloc(T** p, size_t count, int fill = 0) {
+    void* q = nullptr;
+    size_t bytes = count * sizeof(T);
+    if (bytes == 0) bytes = sizeof(T);
+    hipError_t e = hipMalloc(&q, bytes);
+    if (e != hipSuccess) return fail(MGX_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(e));
+    e = hipMemsetAsync(q, fill, bytes, stream);
+    if (e != hipSuccess) return fail(MGX_ERR_HIP, std::string("hipMemset: ") + hipGetErrorString(e));
+    allocs.push_back(q);
+    state_bytes += (int64_t)bytes;
+    *p = (T*)q;
+    return MGX_OK;
+  }
+};
+
+static int launch_obs(mgx_engine* e, bool with_rewards) {
+  dim3 grid(e->d.E), block(MGX_OBS_THREADS);
+  if (with_rewards) hipLaunchKernelGGL(mgx_obs_kernel<true>, grid, block, e->lds_obs, e->stream, e->d);
+  else hipLaunchKernelGGL(mgx_obs_kernel<false>, grid, block, e->lds_obs, e->stream, e->d);
+  HIP_TRY(hipGetLastError());
+  return MGX_OK;
+}
+
+// MettaGrid::_init_buffers (mettagrid_c.cpp:294-319): clear the bound buffers, initial observations (action 0).
+static int init_buffers(mgx_engine* e) {
+  const MgxDev& d = e->d;
+  size_t rows = (size_t)d.E * d.A;
+  HIP_TRY(hipMemsetAsync(d.terminals, 0, rows, e->stream));
+  HIP_TRY(hipMemsetAsync(d.truncations, 0, rows, e->stream));
+  HIP_TRY(hipMemsetAsync(d.rewards, 0, rows * 4, e->stream));
+  HIP_TRY(hipMemsetAsync(d.episode_rewards, 0, rows * 4, e->stream));
+  HIP_TRY(hipMemsetAsync(d.executed, 0, rows * 4, e->stream));
+  int rc = launch_obs(e, false);
+  if (rc) return rc;
+  if (e->mem_kind == MGX_MEM_HOST) {
+    HIP_TRY(hipMemcpyAsync(e->h_obs, d.obs, rows * d.T * 3, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipMemcpyAsync(e->h_term, d.terminals, rows, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipMemcpyAsync(e->h_trunc, d.truncations, rows, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipMemcpyAsync(e->h_rew, d.rewards, rows * 4, hipMemcpyDeviceToHost, e->stream));
+  }
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return MGX_OK;
+}
+
+extern "C" {
+
+const char* mgx_last_error(void) { return g_err.c_str(); }
+
+int mgx_create(const int32_t* program, size_t program_words, const uint16_t* class_maps, const uint32_t* seeds,
+               int32_t num_envs, int32_t device, mgx_engine** out) {
+  if (!program || !class_maps || !seeds || !out || num_envs <= 0) return fail(MGX_ERR_BAD_ARG, "mgx_create: null/empty argument");
+  if (program_words < MGX_H_WORDS || program[MGX_H_MAGIC] != MGX_MAGIC || program[MGX_H_VERSION] != MGX_VERSION ||
+      (size_t)program[MGX_H_TOTAL_WORDS] != program_words)
+    return fail(MGX_ERR_PROGRAM, "mgx_create: not a version-" + std::to_string(MGX_VERSION) + " mgx program");
+  const int32_t* P = program;
+  if (P[MGX_H_NUM_RESOURCES] > MGX_MAX_RESOURCES || P[MGX_H_NUM_AGENTS] >= 255 || P[MGX_H_HEIGHT] > 255 ||
+      P[MGX_H_WIDTH] > 255 || P[MGX_H_NUM_AGENTS] < 1)
+    return fail(MGX_ERR_PROGRAM, "mgx_create: program exceeds engine limits (resources<=13, agents<255, map<=255x255)");
+  HIP_TRY(hipSetDevice(device));
+  mgx_engine* e = new mgx_engine();
+  e->device = device;
+  e->prog.assign(program, program + program_words);
+  hipError_t se = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+  if (se != hipSuccess) { delete e; return fail(MGX_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(se)); }
+
+  MgxDev& d = e->d;
+  d.E = num_envs; d.H = P[MGX_H_HEIGHT]; d.W = P[MGX_H_WIDTH]; d.A = P[MGX_H_NUM_AGENTS]; d.S = P[MGX_H_MAX_OBJECTS];
+  d.R = P[MGX_H_NUM_RESOURCES] > 0 ? P[MGX_H_NUM_RESOURCES] : 1;
+  d.T = P[MGX_H_NUM_TOKENS];
+  d.NS = P[MGX_H_NUM_AGENT_STATS]; d.NG = P[MGX_H_NUM_GAME_STATS];
+  d.NSW = (d.NS + 31) / 32; d.NGW = (d.NG + 31) / 32;
+  d.SEENW = (d.H * d.W + 31) / 32;
+  d.NOFF = P[MGX_H_NUM_OBS_OFFSETS];
+  d.base = P[MGX_H_TOKEN_BASE];
+  d.max_steps = P[MGX_H_MAX_STEPS]; d.truncates = P[MGX_H_EPISODE_TRUNCATES]; d.max_priority = P[MGX_H_MAX_PRIORITY];
+  d.nact = P[MGX_H_NUM_ACTIONS]; d.flags = P[MGX_H_GLOBAL_FLAGS]; d.hp_res = P[MGX_H_HP_RESOURCE];
+  d.n_obs_values = P[MGX_H_NUM_OBS_VALUES]; d.n_move_handlers = P[MGX_H_NUM_MOVE_HANDLERS];
+  for (int i = 0; i < 14; i++) d.feat[i] = P[MGX_H_FEAT_BASE + i];
+  d.feat[14] = P[MGX_H_OBS_HEIGHT] >> 1;
+  d.feat[15] = P[MGX_H_OBS_WIDTH] >> 1;
+  for (int i = 0; i < 32; i++) d.wk[i] = P[MGX_H_STAT_BASE + i];
+  for (int s = 0; s < MGX_SEC_COUNT; s++) d.sec[s] = mgx_sec_off(P, s);
+  int nrw = 1;
+  for (int c = 0; c < P[MGX_H_NUM_CLASSES]; c++)
+    nrw = std::max(nrw, (int)P[d.sec[MGX_SEC_CLASSES] + c * MGX_C_WORDS + MGX_C_REWARD_COUNT]);
+  d.NRW = nrw;
+
+  const size_t E = d.E, HW = (size_t)d.H * d.W, S = d.S, A = d.A, rows = E * A;
+  int rc = MGX_OK;
+  int32_t* dprog = nullptr;
+  uint16_t* dmaps = nullptr;
+  uint32_t* dseeds = nullptr;
+#define A_(call) if (rc == MGX_OK) rc = (call)
+  A_(e->alloc(&dprog, program_words));
+  A_(e->alloc(&d.grid, E * HW));
+  A_(e->alloc(&d.obj_cls, E * S, 0xFF));
+  A_(e->alloc(&d.obj_rc, E * S));
+  A_(e->alloc(&d.obj_vibe, E * S));
+  A_(e->alloc(&d.obj_agent, E * S, 0xFF));
+  A_(e->alloc(&d.obj_visited, E * S));
+  A_(e->alloc(&d.obj_inv, E * S * d.R));
+  A_(e->alloc(&d.obj_order, E * S, 0xFF));
+  A_(e->alloc(&d.num_objs, E));
+  A_(e->alloc(&d.ag_obj, rows));
+  A_(e->alloc(&d.ag_prev, rows));
+  A_(e->alloc(&d.ag_spawn, rows));
+  A_(e->alloc(&d.ag_stepprev, rows));
+  A_(e->alloc(&d.ag_swm, rows));
+  A_(e->alloc(&d.ag_maxdist, rows));
+  A_(e->alloc(&d.ag_unique, rows));
+  A_(e->alloc(&d.ag_seen, rows * d.SEENW));
+  A_(e->alloc(&d.ag_rprev, rows * d.NRW));
+  A_(e->alloc(&d.ag_stats, rows * d.NS));
+  A_(e->alloc(&d.ag_touched, rows * d.NSW));
+  A_(e->alloc(&d.game_stats, E * d.NG));
+  A_(e->alloc(&d.game_touched, E * d.NGW));
+  A_(e->alloc(&d.step, E));
+  A_(e->alloc(&d.err, E));
+  A_(e->alloc(&d.executed, rows));
+  A_(e->alloc(&d.success, rows));
+  A_(e->alloc(&d.episode_rewards, rows));
+  A_(e->alloc(&d.mt, 624 * E));
+  A_(e->alloc(&d.mt_idx, E));
+  A_(e->alloc(&e->own_obs, rows * d.T * 3, 0xFF));
+  A_(e->alloc(&e->own_term, rows));
+  A_(e->alloc(&e->own_trunc, rows));
+  A_(e->alloc(&e->own_rew, rows));
+  A_(e->alloc(&e->own_act, rows));
+  A_(e->alloc(&e->own_vact, rows));
+  A_(e->alloc(&dmaps, E * HW));
+  A_(e->alloc(&dseeds, E));
+#undef A_
+  if (rc != MGX_OK) { mgx_destroy(e); return rc; }
+  d.P = dprog;
+  d.obs = e->own_obs; d.terminals = e->own_term; d.truncations = e->own_trunc; d.rewards = e->own_rew;
+  d.actions = e->own_act; d.vibe_actions = e->own_vact;
+
+  e->lds_world = (size_t)d.A * MGX_WAVE;
+  e->lds_obs = ((HW * 2 + 15) / 16) * 16 + S * 4 + ((A * 4 + 15) / 16) * 16 + (size_t)MGX_OBS_WAVES * (((3 * d.T + 15) / 16) * 16);
+  if (e->lds_obs > 160 * 1024 || e->lds_world > 64 * 1024) {
+    mgx_destroy(e);
+    return fail(MGX_ERR_PROGRAM, "mgx_create: map/object count too large for the LDS staging of the observation kernel");
+  }
+  hipError_t he = hipFuncSetAttribute((const void*)mgx_obs_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_obs);
+  if (he == hipSuccess) he = hipFuncSetAttribute((const void*)mgx_obs_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_obs);
+  if (he == hipSuccess) he = hipMemcpyAsync(dprog, program, program_words * 4, hipMemcpyHostToDevice, e->stream);
+  if (he == hipSuccess) he = hipMemcpyAsync(dmaps, class_maps, E * HW * 2, hipMemcpyHostToDevice, e->stream);
+  if (he == hipSuccess) he = hipMemcpyAsync(dseeds, seeds, E * 4, hipMemcpyHostToDevice, e->stream);
+  if (he != hipSuccess) { mgx_destroy(e); return fail(MGX_ERR_HIP, std::string("mgx_create upload: ") + hipGetErrorString(he)); }
+  hipLaunchKernelGGL(mgx_init_kernel, dim3((d.E + MGX_WAVE - 1) / MGX_WAVE), dim3(MGX_WAVE), 0, e->stream, e->d, dmaps, dseeds);
+  he = hipGetLastError();
+  if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
+  if (he != hipSuccess) { mgx_destroy(e); return fail(MGX_ERR_HIP, std::string("mgx_init_kernel: ") + hipGetErrorString(he)); }
+  for (int i = 0; i < 3; i++) (void)hipEventCreate(&e->ev[i]);
+  rc = init_buffers(e);  // ctor -> _make_buffers -> set_buffers -> _init_buffers (mettagrid_c.cpp:190, 271-292)
+  if (rc != MGX_OK) { mgx_destroy(e); return rc; }
+  *out = e;
+  return MGX_OK;
+}
+
+void mgx_destroy(mgx_engine* e) {
+  if (!e) return;
+  (void)hipSetDevice(e->device);
+  if (e->stream) (void)hipStreamSynchronize(e->stream);
+  for (void* p : e->allocs) (void)hipFree(p);
+  for (int i = 0; i < 3; i++) if (e->ev[i]) (void)hipEventDestroy(e->ev[i]);
+  if (e->stream) (void)hipStreamDestroy(e->stream);
+  delete e;
+}
+
+int mgx_set_buffers(mgx_engine* e, uint8_t* observations, uint8_t* terminals, uint8_t* truncations, float* rewards,
+                    int32_t* actions, int32_t* vibe_actions, int64_t n_rows, int64_t n_tokens, int32_t mem_kind) {
+  if (!e) return fail(MGX_ERR_BAD_ARG, "mgx_set_buffers: null engine");
+  HIP_TRY(hipSetDevice(e->device));
+  MgxDev& d = e->d;
+  bool all_null = !observations && !terminals && !truncations && !rewards && !actions && !vibe_actions;
+  if (!all_null) {
+    if (!observations || !terminals || !truncations || !rewards || !actions || !vibe_actions)
+      return fail(MGX_ERR_BAD_ARG, "mgx_set_buffers: all six buffers are required");
+    if (n_rows != (int64_t)d.E * d.A)  // validate_buffers (mettagrid_c.cpp:1104-1150)
+      return fail(MGX_ERR_BAD_ARG, "observations has shape [" + std::to_string(n_rows) + ", " + std::to_string(n_tokens) +
+                                       ", 3] but expected [" + std::to_string((int64_t)d.E * d.A) + ", [something], 3]");
+    if (n_tokens != d.T) return fail(MGX_ERR_BAD_ARG, "observations token dimension does not match num_observation_tokens");
+  }
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  if (all_null || mem_kind == MGX_MEM_HOST) {
+    d.obs = e->own_obs; d.terminals = e->own_term; d.truncations = e->own_trunc; d.rewards = e->own_rew;
+    d.actions = e->own_act; d.vibe_actions = e->own_vact;
+  }
+  if (all_null) {
+    e->mem_kind = MGX_MEM_DEVICE;
+    e->external = false;
+  } else if (mem_kind == MGX_MEM_HOST) {
+    e->mem_kind = MGX_MEM_HOST;
+    e->external = true;
+    e->h_obs = observations; e->h_term = terminals; e->h_trunc = truncations; e->h_rew = rewards;
+    e->h_act = actions; e->h_vact = vibe_actions;
+  } else if (mem_kind == MGX_MEM_DEVICE) {
+    e->mem_kind = MGX_MEM_DEVICE;
+    e->external = true;
+    d.obs = observations; d.terminals = terminals; d.truncations = truncations; d.rewards = rewards;
+    d.actions = actions; d.vibe_actions = vibe_actions;
+  } else {
+    return fail(MGX_ERR_BAD_ARG, "mgx_set_buffers: unknown mem_kind");
+  }
+  return init_buffers(e);
+}
+
+int mgx_step(mgx_engine* e) {
+  if (!e) return fail(MGX_ERR_BAD_ARG, "mgx_step: null engine");
+  HIP_TRY(hipSetDevice(e->device));
+  const MgxDev& d = e->d;
+  const size_t rows = (size_t)d.E * d.A;
+  if (e->mem_kind == MGX_MEM_HOST) {
+    HIP_TRY(hipMemcpyAsync(e->own_act, e->h_act, rows * 4, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemcpyAsync(e->own_vact, e->h_vact, rows * 4, hipMemcpyHostToDevice, e->stream));
+  }
+  if (e->profiling) HIP_TRY(hipEventRecord(e->ev[0], e->stream));
+  hipLaunchKernelGGL(mgx_world_kernel, dim3((d.E + MGX_WAVE - 1) / MGX_WAVE), dim3(MGX_WAVE), e->lds_world, e->stream, e->d);
+  HIP_TRY(hipGetLastError());
+  if (e->profiling) HIP_TRY(hipEventRecord(e->ev[1], e->stream));
+  int rc = launch_obs(e, true);
+  if (rc) return rc;
+  if (e->profiling) HIP_TRY(hipEventRecord(e->ev[2], e->stream));
+  if (e->mem_kind == MGX_MEM_HOST) {
+    HIP_TRY(hipMemcpyAsync(e->h_obs, d.obs, rows * d.T * 3, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipMemcpyAsync(e->h_term, d.terminals, rows, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipMemcpyAsync(e->h_trunc, d.truncations, rows, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipMemcpyAsync(e->h_rew, d.rewards, rows * 4, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+  }
+  return MGX_OK;
+}
+
+int mgx_sync(mgx_engine* e) {
+  if (!e) return fail(MGX_ERR_BAD_ARG, "mgx_sync: null engine");
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return MGX_OK;
+}
+
+void* mgx_stream(mgx_engine* e) { return e ? (void*)e->stream : nullptr; }
+
+int mgx_get_buffers(mgx_engine* e, uint8_t** observations, uint8_t** terminals, uint8_t** truncations,
+                    float** rewards, int32_t** actions, int32_t** vibe_actions, int32_t* mem_kind) {
+  if (!e) return fail(MGX_ERR_BAD_ARG, "mgx_get_buffers: null engine");
+  bool host = e->mem_kind == MGX_MEM_HOST;
+  if (observations) *observations = host ? e->h_obs : e->d.obs;
+  if (terminals) *terminals = host ? e->h_term : e->d.terminals;
+  if (truncations) *truncations = host ? e->h_trunc : e->d.truncations;
+  if (rewards) *rewards = host ? e->h_rew : e->d.rewards;
+  if (actions) *actions = host ? e->h_act : (int32_t*)e->d.actions;
+  if (vibe_actions) *vibe_actions = host ? e->h_vact : (int32_t*)e->d.vibe_actions;
+  if (mem_kind) *mem_kind = e->mem_kind;
+  return MGX_OK;
+}
+
+static int d2h(mgx_engine* e, void* dst, const void* src, size_t bytes) {
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return MGX_OK;
+}
+
+int mgx_get_episode_rewards(mgx_engine* e, float* out) {
+  if (!e || !out) return fail(MGX_ERR_BAD_ARG, "mgx_get_episode_rewards: null argument");
+  return d2h(e, out, e->d.episode_rewards, (size_t)e->d.E * e->d.A * 4);
+}
+int mgx_get_action_success(mgx_engine* e, uint8_t* out) {
+  if (!e || !out) return fail(MGX_ERR_BAD_ARG, "mgx_get_action_success: null argument");
+  return d2h(e, out, e->d.success, (size_t)e->d.E * e->d.A);
+}
+int mgx_get_current_steps(mgx_engine* e, uint32_t* out) {
+  if (!e || !out) return fail(MGX_ERR_BAD_ARG, "mgx_get_current_steps: null argument");
+  return d2h(e, out, e->d.step, (size_t)e->d.E * 4);
+}
+
+int mgx_get_stats(mgx_engine* e, int32_t env, float* game_values, uint8_t* game_touched, float* agent_values,
+                  uint8_t* agent_touched) {
+  if (!e || env < 0 || env >= e->d.E) return fail(MGX_ERR_BAD_ARG, "mgx_get_stats: bad env");
+  const MgxDev& d = e->d;
+  std::vector<uint32_t> gt(d.NGW), at((size_t)d.A * d.NSW);
+  int rc = d2h(e, game_values, d.game_stats + (size_t)env * d.NG, (size_t)d.NG * 4);
+  if (rc) return rc;
+  rc = d2h(e, gt.data(), d.game_touched + (size_t)env * d.NGW, (size_t)d.NGW * 4);
+  if (rc) return rc;
+  rc = d2h(e, agent_values, d.ag_stats + (size_t)env * d.A * d.NS, (size_t)d.A * d.NS * 4);
+  if (rc) return rc;
+  rc = d2h(e, at.data(), d.ag_touched + (size_t)env * d.A * d.NSW, (size_t)d.A * d.NSW * 4);
+  if (rc) return rc;
+  for (int i = 0; i < d.NG; i++) game_touched[i] = (gt[i >> 5] >> (i & 31)) & 1u;
+  for (int a = 0; a < d.A; a++)
+    for (int i = 0; i < d.NS; i++) agent_touched[(size_t)a * d.NS + i] = (at[(size_t)a * d.NSW + (i >> 5)] >> (i & 31)) & 1u;
+  return MGX_OK;
+}
+
+int mgx_get_objects(mgx_engine* e, int32_t env, int32_t* out, int32_t* n_objects) {
+  if (!e || !out || !n_objects || env < 0 || env >= e->d.E) return fail(MGX_ERR_BAD_ARG, "mgx_get_objects: bad argument");
+  const MgxDev& d = e->d;
+  const size_t S = d.S;
+  std::vector<uint16_t> cls(S), rc(S), inv(S * d.R);
+  std::vector<uint8_t> vibe(S), agent(S);
+  std::vector<unsigned long long> ord(S);
+  uint32_t n = 0;
+  int r = d2h(e, &n, d.num_objs + env, 4);
+  if (!r) r = d2h(e, cls.data(), d.obj_cls + env * S, S * 2);
+  if (!r) r = d2h(e, rc.data(), d.obj_rc + env * S, S * 2);
+  if (!r) r = d2h(e, vibe.data(), d.obj_vibe + env * S, S);
+  if (!r) r = d2h(e, agent.data(), d.obj_agent + env * S, S);
+  if (!r) r = d2h(e, inv.data(), d.obj_inv + env * S * d.R, S * d.R * 2);
+  if (!r) r = d2h(e, ord.data(), d.obj_order + env * S, S * 8);
+  if (r) return r;
+  for (uint32_t s = 0; s < n; s++) {
+    int32_t* w = out + (size_t)s * MGX_OBJ_RECORD_WORDS;
+    w[0] = (int)s + 1; w[1] = cls[s]; w[2] = rc[s] >> 8; w[3] = rc[s] & 0xFF; w[4] = vibe[s];
+    w[5] = cls[s] != MGX_DEAD_CLASS; w[6] = agent[s] == MGX_NO_AGENT ? -1 : agent[s];
+    int cnt = 0;
+    for (int k = 0; k < MGX_MAX_RESOURCES; k++) {
+      int item = (int)((ord[s] >> (4 * k)) & 0xF);
+      if (item == 0xF) { for (int q = k; q < MGX_MAX_RESOURCES; q++) w[8 + q] = -1; break; }
+      w[8 + k] = item;
+      cnt++;
+    }
+    w[7] = cnt;
+    for (int k = 0; k < MGX_MAX_RESOURCES; k++) w[8 + MGX_MAX_RESOURCES + k] = k < d.R ? inv[s * d.R + k] : 0;
+  }
+  *n_objects = (int32_t)n;
+  return MGX_OK;
+}
+
+int mgx_get_reward_state(mgx_engine* e, int32_t env, float* out) {
+  if (!e || !out || env < 0 || env >= e->d.E) return fail(MGX_ERR_BAD_ARG, "mgx_get_reward_state: bad argument");
+  const MgxDev& d = e->d;
+  std::vector<float> prev((size_t)d.A * d.NRW);
+  std::vector<uint16_t> ag_obj(d.A), cls(d.S);
+  int r = d2h(e, prev.data(), d.ag_rprev + (size_t)env * d.A * d.NRW, prev.size() * 4);
+  if (!r) r = d2h(e, ag_obj.data(), d.ag_obj + (size_t)env * d.A, (size_t)d.A * 2);
+  if (!r) r = d2h(e, cls.data(), d.obj_cls + (size_t)env * d.S, (size_t)d.S * 2);
+  if (r) return r;
+  for (int a = 0; a < d.A; a++) {
+    int n = e->prog[d.sec[MGX_SEC_CLASSES] + cls[ag_obj[a]] * MGX_C_WORDS + MGX_C_REWARD_COUNT];
+    float t = 0.f;
+    for (int k = 0; k < n; k++) t += prev[(size_t)a * d.NRW + k];
+    out[a] = t;
+  }
+  return MGX_OK;
+}
+
+int mgx_poll_errors(mgx_engine* e, uint32_t* bits, int32_t* first_env) {
+  if (!e || !bits) return fail(MGX_ERR_BAD_ARG, "mgx_poll_errors: null argument");
+  std::vector<uint32_t> err(e->d.E);
+  int r = d2h(e, err.data(), e->d.err, (size_t)e->d.E * 4);
+  if (r) return r;
+  uint32_t all = 0;
+  int first = -1;
+  for (int i = 0; i < e->d.E; i++) {
+    if (err[i] && first < 0) first = i;
+    all |= err[i];
+  }
+  *bits = all;
+  if (first_env) *first_env = first;
+  return MGX_OK;
+}
+
+int mgx_set_profiling(mgx_engine* e, int32_t enabled) {
+  if (!e) return fail(MGX_ERR_BAD_ARG, "mgx_set_profiling: null engine");
+  e->profiling = enabled != 0;
+  return MGX_OK;
+}
+int mgx_get_step_timing(mgx_engine* e, float* ms_out) {
+  if (!e || !ms_out) return fail(MGX_ERR_BAD_ARG, "mgx_get_step_timing: null argument");
+  if (!e->profiling) return fail(MGX_ERR_BAD_ARG, "mgx_get_step_timing: profiling is off");
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipEventSynchronize(e->ev[2]));
+  HIP_TRY(hipEventElapsedTime(&ms_out[0], e->ev[0], e->ev[1]));
+  HIP_TRY(hipEventElapsedTime(&ms_out[1], e->ev[1], e->ev[2]));
+  return MGX_OK;
+}
+
+int32_t mgx_num_envs(const mgx_engine* e) { return e ? e->d.E : 0; }
+int32_t mgx_num_agents(const mgx_engine* e) { return e ? e->d.A : 0; }
+int32_t mgx_num_tokens(const mgx_engine* e) { return e ? e->d.T : 0; }
+int64_t mgx_state_bytes(const mgx_engine* e) { return e ? e->state_bytes : 0; }
+
+}  // extern "C"

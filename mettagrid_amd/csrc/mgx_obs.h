@@ -1,0 +1,299 @@
+// mgx_obs.h — observation / reward kernel: one workgroup (4 wavefronts) per env.
+//
+// Covers phases 12-14 of MettaGrid::_step (/root/reference/cpp/bindings/mettagrid_c.cpp:1062-1096):
+// the tokenised local-window observation of every agent (_compute_observation_optimized :665-824), the per-agent
+// reward entries (systems/reward.hpp:56-77) and truncation/termination.  ~91 % of the reference's CPU step time is
+// spent here, so this is the dominant kernel and the one the HBM roofline is quoted for.
+//
+// Mapping: the env's H*W u16 occupancy grid is streamed once into LDS with coalesced 16-byte loads; each wavefront
+// then encodes agents w, w+4, ... : lanes map to window cells in the reference's Manhattan-shell order, per-cell
+// token counts are turned into output slots with a wavefront exclusive scan (ordered compaction), tokens are
+// assembled in an LDS staging row that starts out as 0xFF (the reference's separate memset of the whole buffer is
+// fused away) and the finished 3*T-byte row is written to HBM with coalesced dword stores.
+// The reference's "first observer of an object this step gets the cell.visited staleness" rule (:789-796, serial
+// agent order) becomes an LDS atomicMin over observer indices followed by an in-order wavefront reduction.
+#ifndef MGX_OBS_H_
+#define MGX_OBS_H_
+
+#include "mgx_world.h"
+
+#define MGX_OBS_THREADS 256
+#define MGX_OBS_WAVES (MGX_OBS_THREADS / MGX_WAVE)
+
+__device__ __forceinline__ int mgx_wave_excl_scan(int v, int lane, int* total) {
+  int x = v;
+#pragma unroll
+  for (int off = 1; off < MGX_WAVE; off <<= 1) {
+    int y = __shfl_up(x, off);
+    if (lane >= off) x += y;
+  }
+  *total = __shfl(x, MGX_WAVE - 1);
+  return x - v;
+}
+
+__device__ __forceinline__ int mgx_digits(uint32_t v, uint32_t base) {  // encoding_utils.hpp:39-62
+  int n = 1;
+  v /= base;
+  while (v > 0) { n++; v /= base; }
+  return n;
+}
+
+struct MgxTokWriter {
+  uint8_t* stage;  // LDS row of this wavefront
+  int T;
+  __device__ __forceinline__ void put(int pos, uint8_t loc, uint8_t f, uint8_t v) const {
+    if (pos < T) {
+      stage[pos * 3] = loc;
+      stage[pos * 3 + 1] = f;
+      stage[pos * 3 + 2] = v;
+    }
+  }
+};
+
+// Number of tokens GridObject::write_obs_features / Agent::write_obs_features emit for the object in `slot`
+// (core/grid_object.cpp:178-203, objects/agent.cpp:142-154).
+__device__ int mgx_object_token_count(const MgxDev& d, const MgxEnv& e, int slot, const int32_t* C) {
+  int n = 0;
+#pragma unroll
+  for (int w = 0; w < MGX_TAG_WORDS; w++) n += __popc((uint32_t)C[MGX_C_TAGS + w]);
+  if (C[MGX_C_STATIC]) return n;
+  if (d.obj_vibe[e.so(slot)] != 0) n++;
+  unsigned long long ord = d.obj_order[e.so(slot)];
+  for (int k = 0; k < 16; k++) {
+    int item = (int)((ord >> (4 * k)) & 0xF);
+    if (item == 0xF) break;
+    n += mgx_digits(e.inv(slot, item), (uint32_t)d.base);
+  }
+  if (C[MGX_C_KIND] == MGX_KIND_AGENT) n += 2;
+  return n;
+}
+
+__device__ void mgx_object_tokens_emit(const MgxDev& d, const MgxEnv& e, int slot, const int32_t* C, uint8_t loc,
+                                       int pos, const MgxTokWriter& w) {
+  const uint8_t ftag = (uint8_t)d.feat[MGX_F_TAG];
+  for (int wi = 0; wi < MGX_TAG_WORDS; wi++) {
+    uint32_t m = (uint32_t)C[MGX_C_TAGS + wi];
+    while (m) {
+      int b = __ffs(m) - 1;
+      m &= m - 1;
+      w.put(pos++, loc, ftag, (uint8_t)(wi * 32 + b));
+    }
+  }
+  if (C[MGX_C_STATIC]) return;
+  uint8_t vibe = d.obj_vibe[e.so(slot)];
+  if (vibe != 0) w.put(pos++, loc, (uint8_t)d.feat[MGX_F_VIBE], vibe);
+  unsigned long long ord = d.obj_order[e.so(slot)];
+  for (int k = 0; k < 16; k++) {  // observation_encoder.hpp:198-225: base digit, then :pK digits while remaining > 0
+    int item = (int)((ord >> (4 * k)) & 0xF);
+    if (item == 0xF) break;
+    const int32_t* F = d.P + d.sec[MGX_SEC_INV_FEATURES] + item * MGX_IF_WORDS;
+    uint32_t rem = e.inv(slot, item);
+    w.put(pos++, loc, (uint8_t)F[0], (uint8_t)(rem % (uint32_t)d.base));
+    rem /= (uint32_t)d.base;
+    int p = 1;
+    while (rem > 0) {
+      w.put(pos++, loc, (uint8_t)F[p], (uint8_t)(rem % (uint32_t)d.base));
+      rem /= (uint32_t)d.base;
+      p++;
+    }
+  }
+  if (C[MGX_C_KIND] == MGX_KIND_AGENT) {
+    w.put(pos++, loc, (uint8_t)d.feat[MGX_F_GROUP], (uint8_t)C[MGX_C_GROUP]);
+    w.put(pos++, loc, (uint8_t)d.feat[MGX_F_AGENT_ID], d.obj_agent[e.so(slot)]);
+  }
+}
+
+// LDS layout (dynamic): grid u16[HW pad 8] | minobs u32[S] | written i32[A] | stage u8[WAVES][row]
+template <bool WITH_REWARDS>
+__global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d) {
+  extern __shared__ __align__(16) uint8_t smem[];
+  const int env = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & (MGX_WAVE - 1), wave = tid / MGX_WAVE;
+  const int HW = d.H * d.W, A = d.A, S = d.S, T = d.T;
+  const int grid_bytes = ((HW * 2 + 15) / 16) * 16;
+  const int row_bytes = ((3 * T + 15) / 16) * 16;
+  uint16_t* s_grid = (uint16_t*)smem;
+  uint32_t* s_minobs = (uint32_t*)(smem + grid_bytes);
+  int* s_written = (int*)(smem + grid_bytes + S * 4);
+  uint8_t* s_stage = smem + grid_bytes + S * 4 + ((A * 4 + 15) / 16) * 16 + wave * row_bytes;
+
+  MgxEnv e(d, env);
+  e.step = d.step[env];
+  const uint32_t step = e.step;
+
+  // ---- stage the env's occupancy grid: coalesced 16 B per lane (env-major block) ----
+  {
+    const uint4* src = (const uint4*)(d.grid + (size_t)env * HW);
+    uint4* dst = (uint4*)s_grid;
+    const int n16 = (HW * 2) / 16;
+    for (int i = tid; i < n16; i += MGX_OBS_THREADS) dst[i] = src[i];
+    for (int i = n16 * 8 + tid; i < HW; i += MGX_OBS_THREADS) s_grid[i] = d.grid[(size_t)env * HW + i];
+    for (int i = tid; i < S; i += MGX_OBS_THREADS) s_minobs[i] = 0xFFFFFFFFu;
+  }
+  __syncthreads();
+
+  const int32_t* offs = d.P + d.sec[MGX_SEC_OBS_OFFSETS];
+  const int hr = d.feat[14], wr = d.feat[15];  // obs_height >> 1, obs_width >> 1 (stored by the host)
+
+  // ---- phase 1: first observer (lowest agent index) of every visible object ----
+  if (step > 0) {
+    for (int a = wave; a < A; a += MGX_OBS_WAVES) {
+      uint16_t rc = d.obj_rc[e.so(d.ag_obj[e.ao(a)])];
+      int r0 = rc >> 8, c0 = rc & 0xFF;
+      for (int j = lane; j < d.NOFF; j += MGX_WAVE) {
+        int r = r0 + offs[j * 2], c = c0 + offs[j * 2 + 1];
+        if (r < 0 || c < 0 || r >= d.H || c >= d.W) continue;
+        int slot = (int)s_grid[r * d.W + c] - 1;
+        if (slot >= 0) atomicMin(&s_minobs[slot], (uint32_t)a);
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- phase 2: encode ----
+  MgxTokWriter w{s_stage, T};
+  for (int a = wave; a < A; a += MGX_OBS_WAVES) {
+    const int my_slot = d.ag_obj[e.ao(a)];
+    const uint16_t rc = d.obj_rc[e.so(my_slot)];
+    const int r0 = rc >> 8, c0 = rc & 0xFF;
+    for (int i = lane; i < row_bytes / 4; i += MGX_WAVE) ((uint32_t*)s_stage)[i] = 0xFFFFFFFFu;
+
+    // global tokens (location 0xFE), mettagrid_c.cpp:700-753 — a handful, written by lane 0
+    int n_global = 0;
+    if (lane == 0) {
+      int pos = 0;
+      if (d.flags & MGX_G_COMPLETION) {
+        uint8_t pct = 0;
+        if (d.max_steps > 0) pct = step >= (uint32_t)d.max_steps ? 255 : (uint8_t)(256u * step / (uint32_t)d.max_steps);
+        w.put(pos++, 0xFE, (uint8_t)d.feat[MGX_F_COMPLETION], pct);
+      }
+      if (d.flags & MGX_G_LAST_ACTION) w.put(pos++, 0xFE, (uint8_t)d.feat[MGX_F_LAST_ACTION], (uint8_t)d.executed[e.ao(a)]);
+      if ((d.flags & MGX_G_LAST_ACTION_MOVE) && d.feat[MGX_F_LAST_ACTION_MOVE] != 0)
+        w.put(pos++, 0xFE, (uint8_t)d.feat[MGX_F_LAST_ACTION_MOVE], rc != d.ag_stepprev[e.ao(a)] ? 1 : 0);
+      // last_reward: the reference reads the reward buffer it zeroed at the top of the step (:937-938,722-726),
+      // so the token is always round(0 * 100) = 0.
+      if (d.flags & MGX_G_LAST_REWARD) w.put(pos++, 0xFE, (uint8_t)d.feat[MGX_F_LAST_REWARD], 0);
+      if (d.flags & MGX_G_LOCAL_POSITION) {
+        uint16_t sp = d.ag_spawn[e.ao(a)];
+        int dc = c0 - (int)(sp & 0xFF), dr = (int)(sp >> 8) - r0;
+        if (dc > 0) w.put(pos++, 0xFE, (uint8_t)d.feat[MGX_F_LP_EAST], (uint8_t)min(dc, 255));
+        else if (dc < 0) w.put(pos++, 0xFE, (uint8_t)d.feat[MGX_F_LP_WEST], (uint8_t)min(-dc, 255));
+        if (dr > 0) w.put(pos++, 0xFE, (uint8_t)d.feat[MGX_F_LP_NORTH], (uint8_t)min(dr, 255));
+        else if (dr < 0) w.put(pos++, 0xFE, (uint8_t)d.feat[MGX_F_LP_SOUTH], (uint8_t)min(-dr, 255));
+      }
+      for (int i = 0; i < d.n_obs_values; i++) {  // _emit_obs_value_tokens :1207-1238
+        const int32_t* V = d.P + d.sec[MGX_SEC_OBS_VALUES] + i * MGX_OV_WORDS;
+        float raw = e.eval_code(V[MGX_OV_GV_START], V[MGX_OV_GV_COUNT], my_slot);
+        uint32_t rem = (uint32_t)raw;
+        int f = V[MGX_OV_FEATURE];
+        w.put(pos++, 0xFE, (uint8_t)f, (uint8_t)(rem % (uint32_t)d.base));
+        rem /= (uint32_t)d.base;
+        f++;
+        while (rem > 0) { w.put(pos++, 0xFE, (uint8_t)f, (uint8_t)(rem % (uint32_t)d.base)); rem /= (uint32_t)d.base; f++; }
+      }
+      n_global = pos;
+    }
+    int base_pos = __shfl(n_global, 0);
+
+    // window cells in reference order; 64 cells per pass
+    float visited_acc = 0.f;
+    bool visited_any = false;
+    const int sid_visited = mgx_wk(d, MGX_S_CELL_VISITED);
+    if (step > 0) visited_acc = e.astat_get(a, sid_visited);
+    for (int j0 = 0; j0 < d.NOFF; j0 += MGX_WAVE) {
+      const int j = j0 + lane;
+      int slot = -1, n = 0;
+      uint8_t loc = 0;
+      const int32_t* C = nullptr;
+      float stale = 0.f;
+      bool first = false;
+      if (j < d.NOFF) {
+        int dr = offs[j * 2], dc = offs[j * 2 + 1];
+        int r = r0 + dr, c = c0 + dc;
+        if (r >= 0 && c >= 0 && r < d.H && c < d.W) {
+          slot = (int)s_grid[r * d.W + c] - 1;
+          if (slot >= 0) {
+            loc = (uint8_t)(((dr + hr) << 4) | (dc + wr));
+            C = mgx_cls(d, d.obj_cls[e.so(slot)]);
+            n = mgx_object_token_count(d, e, slot, C);
+            if (step > 0 && s_minobs[slot] == (uint32_t)a) {
+              uint32_t pv = d.obj_visited[e.so(slot)];
+              if (pv < step) { first = true; stale = (float)(step - pv); }
+            }
+          }
+        }
+      }
+      int total;
+      int pos = base_pos + mgx_wave_excl_scan(n, lane, &total);
+      if (n > 0) mgx_object_tokens_emit(d, e, slot, C, loc, pos, w);
+      base_pos += total;
+      // cell.visited staleness, added in cell order exactly like the serial reference loop
+      unsigned long long m = __ballot(first);
+      while (m) {
+        int l = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        visited_acc = __fadd_rn(visited_acc, __shfl(stale, l));
+        visited_any = true;
+      }
+    }
+    if (lane == 0) {
+      if (visited_any) e.astat_set(a, sid_visited, visited_acc);
+      s_written[a] = base_pos;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // LDS staging row complete before it is read back
+    // ---- store the row: coalesced dwords ----
+    uint8_t* out = d.obs + ((size_t)env * A + a) * (size_t)T * 3;
+    if (((3 * T) & 3) == 0) {
+      uint32_t* o32 = (uint32_t*)out;
+      const uint32_t* s32 = (const uint32_t*)s_stage;
+      for (int i = lane; i < (3 * T) / 4; i += MGX_WAVE) o32[i] = s32[i];
+    } else {
+      for (int i = lane; i < 3 * T; i += MGX_WAVE) out[i] = s_stage[i];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  }
+  __syncthreads();
+
+  // ---- visited stamps, token statistics, rewards, termination ----
+  if (step > 0)
+    for (int s = tid; s < S; s += MGX_OBS_THREADS)
+      if (s_minobs[s] != 0xFFFFFFFFu && d.obj_visited[e.so(s)] < step) d.obj_visited[e.so(s)] = step;
+  if (tid == 0) {  // sequential f32 adds in agent order, as the reference does (:659-661, 821-823)
+    float* gs = d.game_stats + (size_t)env * d.NG;
+    float tw = gs[mgx_wk(d, MGX_S_GAME_TOKENS_WRITTEN)], tf = gs[mgx_wk(d, MGX_S_GAME_TOKENS_FREE)];
+    bool overflow = false;
+    for (int a = 0; a < A && !overflow; a++) {
+      int n = s_written[a];
+      if (n > T) { overflow = true; break; }  // reference: std::runtime_error (:813-819)
+      tw = __fadd_rn(tw, (float)n);
+      tf = __fadd_rn(tf, (float)(T - n));
+    }
+    gs[mgx_wk(d, MGX_S_GAME_TOKENS_WRITTEN)] = tw;
+    gs[mgx_wk(d, MGX_S_GAME_TOKENS_FREE)] = tf;
+    if (overflow) d.err[env] |= 1u;
+  }
+  if (WITH_REWARDS) {
+    for (int a = tid; a < A; a += MGX_OBS_THREADS) {  // RewardHelper::compute_entries, systems/reward.hpp:56-77
+      const int slot = d.ag_obj[e.ao(a)];
+      const int32_t* C = e.cls_of(slot);
+      const int32_t* rw = d.P + d.sec[MGX_SEC_REWARDS] + C[MGX_C_REWARD_START] * MGX_RW_WORDS;
+      float total = 0.f;
+      for (int k = 0; k < C[MGX_C_REWARD_COUNT]; k++, rw += MGX_RW_WORDS) {
+        float val = e.eval_code(rw[MGX_RW_GV_START], rw[MGX_RW_GV_COUNT], slot);
+        float* prev = &d.ag_rprev[e.ao(a) * d.NRW + k];
+        if (rw[MGX_RW_ACCUMULATE]) total = __fadd_rn(total, val);
+        else total = __fadd_rn(total, __fsub_rn(val, *prev));
+        *prev = val;
+      }
+      float reward = total != 0.f ? total : 0.f;  // rewards were zeroed at the top of the step; += total
+      d.rewards[e.ao(a)] = reward;
+      d.episode_rewards[e.ao(a)] = __fadd_rn(d.episode_rewards[e.ao(a)], reward);
+      if (d.max_steps > 0 && step >= (uint32_t)d.max_steps) {  // mettagrid_c.cpp:1086-1096
+        if (d.truncates) d.truncations[e.ao(a)] = 1;
+        else d.terminals[e.ao(a)] = 1;
+      }
+    }
+  }
+}
+
+#endif  // MGX_OBS_H_

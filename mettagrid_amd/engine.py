@@ -1,0 +1,341 @@
+"""Python host side of the MI355X MettaGrid step engine: ctypes binding of libmgx (include/mgx.h) plus mirrors of
+the reference's Python-visible interface.
+
+* ``BatchedMettaGrid`` — E envs per engine, buffers ``[E*A, T, 3]`` etc. resident in HBM (torch tensors are used
+  only as device-memory handles).
+* ``MettaGrid`` — same constructor, methods and error behaviour as the reference's pybind class
+  ``mettagrid.mettagrid_c.MettaGrid`` (/root/reference/cpp/bindings/mettagrid_py.cpp:242-397, type stub
+  python/src/mettagrid/mettagrid_c.pyi:752-806) for ONE env, so callers written against the reference
+  (``c.actions()[:] = a; c.step(); c.observations()``) run unchanged.
+
+There is no CPU fallback: if libmgx.so (the HIP build) is missing this module raises at first use.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from .compiler import Program, compile_spec
+from .fmt import K
+from .signature import objects_from_raw, stats_dicts
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmgx.so")
+_lib = None
+OBJ_RECORD_WORDS = 34
+
+ENV_TOKEN_OVERFLOW, ENV_INVALID_KEY_RANGE, ENV_DEPTH, ENV_TOO_MANY_OBJECTS = 1, 2, 4, 8
+
+
+class MgxError(RuntimeError):
+    pass
+
+
+def load_lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MgxError(
+            f"{LIB_PATH} not found: the HIP engine is not built. Run `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
+    L.mgx_last_error.restype = C.c_char_p
+    L.mgx_create.argtypes = [vp, C.c_size_t, vp, vp, i32, i32, C.POINTER(vp)]
+    L.mgx_destroy.argtypes = [vp]
+    L.mgx_destroy.restype = None
+    L.mgx_set_buffers.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, i64, i32]
+    L.mgx_step.argtypes = [vp]
+    L.mgx_sync.argtypes = [vp]
+    L.mgx_stream.argtypes = [vp]
+    L.mgx_stream.restype = vp
+    L.mgx_get_buffers.argtypes = [vp] + [C.POINTER(vp)] * 6 + [C.POINTER(i32)]
+    L.mgx_get_episode_rewards.argtypes = [vp, vp]
+    L.mgx_get_action_success.argtypes = [vp, vp]
+    L.mgx_get_current_steps.argtypes = [vp, vp]
+    L.mgx_get_stats.argtypes = [vp, i32, vp, vp, vp, vp]
+    L.mgx_get_objects.argtypes = [vp, i32, vp, C.POINTER(i32)]
+    L.mgx_get_reward_state.argtypes = [vp, i32, vp]
+    L.mgx_poll_errors.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(i32)]
+    L.mgx_set_profiling.argtypes = [vp, i32]
+    L.mgx_get_step_timing.argtypes = [vp, vp]
+    for name in ("mgx_num_envs", "mgx_num_agents", "mgx_num_tokens"):
+        getattr(L, name).argtypes = [vp]
+        getattr(L, name).restype = i32
+    L.mgx_state_bytes.argtypes = [vp]
+    L.mgx_state_bytes.restype = i64
+    _lib = L
+    return L
+
+
+def exported_symbols() -> list:
+    """Entry points declared in include/mgx.h (used by the CPU-side ABI test)."""
+    import re
+    hdr = open(os.path.join(os.path.dirname(_HERE), "include", "mgx.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", " ", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(mgx_[a-z_]+)\s*\(", hdr)))
+
+
+def _check(rc: int) -> None:
+    if rc != 0:
+        msg = load_lib().mgx_last_error().decode()
+        if rc == -1:
+            raise ValueError(msg) if "shape" not in msg and "token" not in msg else RuntimeError(msg)
+        raise MgxError(f"libmgx error {rc}: {msg}")
+
+
+class BatchedMettaGrid:
+    """E independent envs stepped together on one MI355X.
+
+    ``buffers="device"``: observation/reward/terminal/truncation/action buffers are torch CUDA tensors owned by this
+    object (or passed in through ``set_buffers``) and the kernels write into them directly.
+    ``buffers="host"``: numpy arrays; actions are uploaded and results downloaded on every step (PCIe-inclusive).
+    """
+
+    def __init__(self, prog: Program, class_maps: np.ndarray, seeds, device: int = 0, buffers: str = "device") -> None:
+        self.L = load_lib()
+        self.prog = prog
+        cm = np.ascontiguousarray(class_maps, dtype=np.uint16)
+        H, W = int(prog.words[K.H_HEIGHT]), int(prog.words[K.H_WIDTH])
+        if cm.ndim == 2:
+            cm = cm[None]
+        if cm.shape[1:] != (H, W):
+            raise ValueError(f"class_maps has shape {cm.shape} but the program was compiled for {H}x{W} maps")
+        self.E = cm.shape[0]
+        self.A, self.T = prog.num_agents, prog.num_tokens
+        seeds = np.ascontiguousarray(np.broadcast_to(np.asarray(seeds, dtype=np.uint32), (self.E,)))
+        words = np.ascontiguousarray(prog.words, dtype=np.int32)
+        self.device = device
+        self.h = C.c_void_p()
+        _check(self.L.mgx_create(words.ctypes.data, words.size, cm.ctypes.data, seeds.ctypes.data, self.E, device,
+                                 C.byref(self.h)))
+        self.kind = buffers
+        rows = self.E * self.A
+        if buffers == "device":
+            import torch
+            dev = torch.device("cuda", device)
+            self.obs = torch.empty((rows, self.T, 3), dtype=torch.uint8, device=dev)
+            self.terminals = torch.empty(rows, dtype=torch.bool, device=dev)
+            self.truncations = torch.empty(rows, dtype=torch.bool, device=dev)
+            self.rewards = torch.empty(rows, dtype=torch.float32, device=dev)
+            self.actions = torch.zeros(rows, dtype=torch.int32, device=dev)
+            self.vibe_actions = torch.zeros(rows, dtype=torch.int32, device=dev)
+            torch.cuda.synchronize(dev)
+            self._bind(*(t.data_ptr() for t in (self.obs, self.terminals, self.truncations, self.rewards,
+                                                self.actions, self.vibe_actions)), mem_kind=1)
+        elif buffers == "host":
+            self.obs = np.empty((rows, self.T, 3), np.uint8)
+            self.terminals = np.zeros(rows, np.bool_)
+            self.truncations = np.zeros(rows, np.bool_)
+            self.rewards = np.zeros(rows, np.float32)
+            self.actions = np.zeros(rows, np.int32)
+            self.vibe_actions = np.zeros(rows, np.int32)
+            self._bind(*(a.ctypes.data for a in (self.obs, self.terminals, self.truncations, self.rewards,
+                                                 self.actions, self.vibe_actions)), mem_kind=0)
+        else:
+            raise ValueError("buffers must be 'device' or 'host'")
+
+    def _bind(self, obs, term, trunc, rew, act, vact, mem_kind: int, rows=None, tokens=None) -> None:
+        _check(self.L.mgx_set_buffers(self.h, obs, term, trunc, rew, act, vact,
+                                      self.E * self.A if rows is None else rows,
+                                      self.T if tokens is None else tokens, mem_kind))
+
+    def close(self) -> None:
+        if getattr(self, "h", None) and self.h:
+            self.L.mgx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- stepping ----
+    def step(self, check_errors: bool = False) -> None:
+        _check(self.L.mgx_step(self.h))
+        if check_errors:
+            self.raise_env_errors()
+
+    def sync(self) -> None:
+        _check(self.L.mgx_sync(self.h))
+
+    @property
+    def stream(self) -> int:
+        return int(self.L.mgx_stream(self.h) or 0)
+
+    def poll_errors(self):
+        bits, first = C.c_uint32(0), C.c_int32(-1)
+        _check(self.L.mgx_poll_errors(self.h, C.byref(bits), C.byref(first)))
+        return bits.value, first.value
+
+    def raise_env_errors(self) -> None:
+        bits, first = self.poll_errors()
+        if bits & ENV_TOKEN_OVERFLOW:  # reference: std::runtime_error -> RuntimeError (mettagrid_c.cpp:364-375)
+            raise RuntimeError(f"Observation token budget exceeded (first env {first}, budget={self.T})")
+        if bits & ENV_TOO_MANY_OBJECTS:
+            raise MgxError(f"env {first}: map holds more objects than max_objects={self.prog.max_objects}")
+        if bits & ENV_DEPTH:
+            raise MgxError(f"env {first}: handler / inventory-limit recursion exceeds the engine's depth")
+        if bits & ENV_INVALID_KEY_RANGE:
+            raise MgxError(f"env {first}: action index outside the tracked action.invalid_index window")
+
+    # ---- readbacks ----
+    def episode_rewards(self) -> np.ndarray:
+        out = np.empty(self.E * self.A, np.float32)
+        _check(self.L.mgx_get_episode_rewards(self.h, out.ctypes.data))
+        return out
+
+    def action_success(self) -> np.ndarray:
+        out = np.empty(self.E * self.A, np.uint8)
+        _check(self.L.mgx_get_action_success(self.h, out.ctypes.data))
+        return out.astype(bool)
+
+    def current_steps(self) -> np.ndarray:
+        out = np.empty(self.E, np.uint32)
+        _check(self.L.mgx_get_current_steps(self.h, out.ctypes.data))
+        return out
+
+    def raw_stats(self, env: int = 0):
+        ng, na = len(self.prog.game_stat_names), len(self.prog.agent_stat_names)
+        gv, gt = np.zeros(ng, np.float32), np.zeros(ng, np.uint8)
+        av, at = np.zeros((self.A, na), np.float32), np.zeros((self.A, na), np.uint8)
+        _check(self.L.mgx_get_stats(self.h, env, gv.ctypes.data, gt.ctypes.data, av.ctypes.data, at.ctypes.data))
+        return gv, gt, av, at
+
+    def get_episode_stats(self, env: int = 0) -> dict:
+        return stats_dicts(self.prog, *self.raw_stats(env))
+
+    def raw_objects(self, env: int = 0) -> np.ndarray:
+        out = np.zeros((self.prog.max_objects, OBJ_RECORD_WORDS), np.int32)
+        n = C.c_int32(0)
+        _check(self.L.mgx_get_objects(self.h, env, out.ctypes.data, C.byref(n)))
+        return out[: n.value]
+
+    def current_stat_reward(self, env: int = 0) -> np.ndarray:
+        out = np.zeros(self.A, np.float32)
+        _check(self.L.mgx_get_reward_state(self.h, env, out.ctypes.data))
+        return out
+
+    def grid_objects(self, env: int = 0) -> dict:
+        return objects_from_raw(self.prog, self.raw_objects(env), self.current_stat_reward(env))
+
+    def snapshot(self, env: int | None = None) -> dict:
+        """Host copies of the caller-visible buffers (all envs, or the rows of one env)."""
+        self.sync()
+        if self.kind == "device":
+            import torch
+            torch.cuda.synchronize(self.device)
+            obs, rew = self.obs.cpu().numpy(), self.rewards.cpu().numpy()
+            term, trunc = self.terminals.cpu().numpy(), self.truncations.cpu().numpy()
+        else:
+            obs, rew, term, trunc = self.obs.copy(), self.rewards.copy(), self.terminals.copy(), self.truncations.copy()
+        out = dict(obs=obs, rewards=rew, terminals=term.astype(bool), truncations=trunc.astype(bool),
+                   action_success=self.action_success(), episode_rewards=self.episode_rewards())
+        if env is not None:
+            sl = slice(env * self.A, (env + 1) * self.A)
+            out = {k: v[sl] for k, v in out.items()}
+        return out
+
+    def set_profiling(self, on: bool) -> None:
+        _check(self.L.mgx_set_profiling(self.h, 1 if on else 0))
+
+    def step_timing_ms(self):
+        out = np.zeros(2, np.float32)
+        _check(self.L.mgx_get_step_timing(self.h, out.ctypes.data))
+        return float(out[0]), float(out[1])
+
+    @property
+    def state_bytes(self) -> int:
+        return int(self.L.mgx_state_bytes(self.h))
+
+
+class MettaGrid:
+    """One env with the reference's pybind surface (``MettaGrid(env_cfg, map, seed)``; here ``env_cfg`` is a compiled
+    ``Program`` or a ``GameSpec``).  Buffers are caller-visible numpy arrays, stored by reference like the
+    reference does (cpp/bindings/mettagrid_c.cpp:1165-1184): ``step()`` writes into them."""
+
+    def __init__(self, env_cfg, map, seed: int, device: int = 0) -> None:  # noqa: A002 - reference argument name
+        H, W = len(map), len(map[0])
+        prog = env_cfg if isinstance(env_cfg, Program) else compile_spec(env_cfg, H, W)
+        self.prog = prog
+        self._b = BatchedMettaGrid(prog, prog.class_map(map), [int(seed) & 0xFFFFFFFF], device=device, buffers="host")
+        w = prog.words
+        self.obs_width, self.obs_height = int(w[K.H_OBS_WIDTH]), int(w[K.H_OBS_HEIGHT])
+        self.max_steps = int(w[K.H_MAX_STEPS])
+        self.map_width, self.map_height = W, H
+        self.object_type_names = list(prog.type_names)
+        self.resource_names = list(prog.resource_names)
+        self._num_agents = prog.num_agents
+
+    # -- buffers --
+    def set_buffers(self, observations, terminals, truncations, rewards, actions, vibe_actions=None) -> None:
+        n = self._num_agents
+        if vibe_actions is None:
+            vibe_actions = np.zeros(n, np.int32)
+        want = ((observations, np.uint8), (terminals, np.bool_), (truncations, np.bool_), (rewards, np.float32),
+                (actions, np.int32), (vibe_actions, np.int32))
+        for arr, dt in want:  # pybind .noconvert(): dtype and C-contiguity are part of the signature
+            if not isinstance(arr, np.ndarray) or arr.dtype != dt or not arr.flags.c_contiguous:
+                raise TypeError("set_buffers(): incompatible function arguments (dtype / contiguity)")
+        if observations.ndim != 3:
+            raise RuntimeError(f"observations has {observations.ndim} dimensions but expected 3")
+        if observations.shape[0] != n or observations.shape[2] != 3:
+            raise RuntimeError(f"observations has shape {list(observations.shape)} but expected [{n}, [something], 3]")
+        for name, arr in (("terminals", terminals), ("truncations", truncations), ("vibe_actions", vibe_actions),
+                          ("rewards", rewards)):
+            if arr.ndim != 1 or arr.shape[0] != n:
+                raise RuntimeError(f"{name} has the wrong shape")
+        b = self._b
+        b.obs, b.terminals, b.truncations, b.rewards, b.actions, b.vibe_actions = (
+            observations, terminals, truncations, rewards, actions, vibe_actions)
+        b._bind(*(a.ctypes.data for a in (observations, terminals, truncations, rewards, actions, vibe_actions)),
+                mem_kind=0, rows=observations.shape[0], tokens=observations.shape[1])
+
+    def step(self) -> None:
+        b = self._b
+        if b.actions.ndim != 1:
+            raise RuntimeError("actions must be 1D array")
+        if b.actions.shape[0] != self._num_agents:
+            raise RuntimeError("actions has the wrong shape")
+        b.step(check_errors=True)
+
+    def observations(self): return self._b.obs
+    def terminals(self): return self._b.terminals
+    def truncations(self): return self._b.truncations
+    def rewards(self): return self._b.rewards
+    def actions(self): return self._b.actions
+    def vibe_actions(self): return self._b.vibe_actions
+
+    def masks(self):
+        return np.ones((self._num_agents, len(self.prog.action_names)), np.bool_)
+
+    def get_episode_rewards(self): return self._b.episode_rewards()
+    def get_episode_stats(self): return self._b.get_episode_stats(0)
+    def action_success(self): return [bool(x) for x in self._b.action_success()]
+
+    def get_game_stat(self, key: str):
+        return self.get_episode_stats()["game"].get(key)
+
+    def get_agent_stat(self, agent_id: int, key: str):
+        st = self.get_episode_stats()["agent"]
+        return st[agent_id].get(key) if 0 <= agent_id < len(st) else None
+
+    @property
+    def current_step(self) -> int:
+        return int(self._b.current_steps()[0])
+
+    def grid_objects(self, min_row=-1, max_row=-1, min_col=-1, max_col=-1, ignore_types=()):
+        objs = self._b.grid_objects(0)
+        use_bounds = min_row >= 0 and max_row >= 0 and min_col >= 0 and max_col >= 0
+        out = {}
+        for oid, o in objs.items():
+            if o["type_name"] in ignore_types:
+                continue
+            if use_bounds and not (min_row <= o["r"] < max_row and min_col <= o["c"] < max_col):
+                continue
+            out[oid] = o
+        return out

@@ -1,0 +1,136 @@
+"""Shared helpers for the parity tests: scenario table, stepping an engine pair with identical actions, and the
+comparison of every caller-visible buffer plus the generalised signature payload."""
+from __future__ import annotations
+
+import numpy as np
+
+from mettagrid_amd import presets, signature as sg
+from mettagrid_amd import spec as S
+from mettagrid_amd.compiler import compile_spec
+from mettagrid_amd.mapgen import random_map
+
+
+def torture_spec(max_steps: int = 40, truncates: bool = True) -> S.GameSpec:
+    """Exercises the parts of the handler VM the benchmark rungs do not: limit groups with modifiers and drop
+    enforcement, ClearInventory, Or / TagPrefix / GameValue filters, AllOf, on_after_use, obs values, local
+    position, last_action_move, multi-digit inventory tokens (base 16), truncation."""
+    A, T = S.ACTOR, S.TARGET
+    shrine_use = S.AllOf([
+        S.Handler([S.OrFilter([S.VibeFilter(A, "b"), S.ResourceFilter(A, "gear", 2)])],
+                  [S.ResourceDelta(A, "gear", -1), S.ResourceDelta(A, "energy", 300)], "burn_gear"),
+        S.Handler([S.TagPrefixFilter(A, "team:blue")], [S.ClearInventory(A, ["carbon", "oxygen"])], "clear_some"),
+        S.Handler([S.GameValueFilter(A, S.InventoryValue("energy"), S.ConstValue(600.0))],
+                  [S.ClearInventory(A), S.SetStat("shrine.wipes", S.StatValue("shrine.wipes", "game"), scope="game")],
+                  "wipe"),
+    ])
+    forge_use = S.FirstMatch([
+        S.Handler([S.ResourceFilter(A, "ore", 3)],
+                  [S.ResourceDelta(A, "ore", -3), S.ResourceDelta(A, "gear", 1),
+                   S.SetStat("forged", S.SumValue([S.InventoryValue("gear"), S.StatValue("forged", "agent")]),
+                             scope="agent", entity=A)], "forge"),
+        S.Handler([], [S.ResourceTransfer(T, A, "carbon", 2), S.ResourceTransfer(T, A, "oxygen", 7)], "scraps"),
+    ])
+    mine_use = S.Handler([], [S.ResourceTransfer(T, A, "ore", 4), S.ChangeVibe(A, "c")], "mine")
+    agent_use = S.FirstMatch([
+        S.Handler([S.NegFilter([S.SharedTagPrefixFilter("team:")])],
+                  [S.ResourceTransfer(T, A, "gear", 1), S.Attack("laser", "armor", "hp", 150)], "rob"),
+        S.Handler([S.SharedTagPrefixFilter("team:")], [S.Swap()], "swap"),
+    ])
+    after_use = S.Handler([], [S.ResourceDelta(A, "energy", -1)], "tired")
+
+    def agent(team: int, i: int) -> S.AgentSpec:
+        return S.AgentSpec(
+            team_id=team, tags=["team:red" if team == 0 else "team:blue"], vibe=i % 3,
+            inventory=S.Inventory(
+                initial={"laser": 3, "hp": 40 + i, "gear": i % 3, "energy": 20, "armor": 1, "oxygen": 0},
+                default_limit=1000,
+                limits=[S.Limit(["ore", "carbon", "oxygen"], base=6, max=40, modifiers={"gear": 8}),
+                        S.Limit(["energy"], base=1000)]),
+            rewards=[S.RewardSpec(S.InventoryValue("gear")),
+                     S.RewardSpec(S.SumValue([S.InventoryValue("hp"), S.InventoryValue("energy")], [0.5, 0.25], log=True),
+                                  per_tick=True),
+                     S.RewardSpec(S.StatValue("forged", "agent")),
+                     S.RewardSpec(S.RatioValue(S.InventoryValue("ore"), S.MaxValue([S.InventoryValue("gear"), S.ConstValue(1.0)])))],
+            on_use=agent_use, on_after_use=after_use,
+            on_tick=S.Handler([S.PeriodicFilter(3, 2)], [S.ResourceDelta(T, "energy", -2), S.ResourceDelta(T, "hp", -1)], "decay"))
+
+    return S.GameSpec(
+        resource_names=["ore", "hp", "laser", "armor", "gear", "energy", "carbon", "oxygen"],
+        agents=[agent(0, i) for i in range(3)] + [agent(1, i) for i in range(3)],
+        objects={
+            "wall": S.ObjectSpec(name="wall", kind="wall"),
+            "block": S.ObjectSpec(name="block", kind="wall", tags=["solid"]),
+            "mine": S.ObjectSpec(name="mine", tags=["res:ore"], inventory=S.Inventory(initial={"ore": 500}), on_use=mine_use),
+            "forge": S.ObjectSpec(name="forge", vibe=2, inventory=S.Inventory(initial={"oxygen": 300, "carbon": 9}, default_limit=400),
+                                  on_use=forge_use),
+            "shrine": S.ObjectSpec(name="shrine", on_use=shrine_use),
+        },
+        tags=["team:red", "team:blue"],
+        vibe_names=["default", "a", "b", "c"], change_vibe_enabled=True,
+        move_directions=["north", "south", "west", "east", "northeast", "southwest"],
+        obs=S.ObsSpec(width=7, height=9, num_tokens=120, token_value_base=16, last_action_move=True, local_position=True,
+                      values={"my_energy": S.InventoryValue("energy"), "forged": S.StatValue("forged", "agent")}),
+        max_steps=max_steps, episode_truncates=truncates)
+
+
+def torture_map(seed: int) -> np.ndarray:
+    return random_map(12, 14, {"wall": 8, "block": 5, "mine": 4, "forge": 3, "shrine": 3}, {"red": 3, "blue": 3}, seed)
+
+
+SCENARIOS = {
+    # name: (spec factory, map factory(seed), steps, allow invalid action indices)
+    "rung1": (presets.rung1_spec, lambda s: presets.rung1_map(), 120, False),
+    "rung1_invalid": (presets.rung1_spec, lambda s: presets.rung1_map(), 60, True),
+    "rung2": (presets.rung2_spec, presets.rung2_map, 128, False),
+    "rung3": (presets.rung3_spec, presets.rung3_map, 160, False),
+    "rung3_flat_damage": (lambda: presets.rung3_spec(use_attack_mutation=False), presets.rung3_map, 100, True),
+    "torture": (torture_spec, torture_map, 45, False),
+    "torture_terminal": (lambda: torture_spec(25, False), torture_map, 30, True),
+}
+
+
+def make_actions(prog, seed: int, steps: int, invalid: bool) -> tuple:
+    rng = np.random.RandomState(1000 + seed)
+    n = len(prog.action_names)
+    lo, hi = (-2, n + 2) if invalid else (0, n)
+    return (rng.randint(lo, hi, (steps, prog.num_agents)).astype(np.int32),
+            rng.randint(lo, hi, (steps, prog.num_agents)).astype(np.int32))
+
+
+def compare_snapshots(a: dict, b: dict, where: str) -> None:
+    for k in ("obs", "rewards", "terminals", "truncations", "action_success", "episode_rewards"):
+        if not np.array_equal(np.asarray(a[k]), np.asarray(b[k])):
+            detail = ""
+            if k == "obs":
+                idx = np.argwhere((a[k] != b[k]).any(axis=2))
+                ag, tok = idx[0]
+                detail = f" agent {ag} token {tok}: {a[k][ag, max(0, tok - 2):tok + 3].tolist()} vs {b[k][ag, max(0, tok - 2):tok + 3].tolist()}"
+            else:
+                detail = f" {np.asarray(a[k]).tolist()} vs {np.asarray(b[k]).tolist()}"
+            raise AssertionError(f"{where}: '{k}' differs.{detail}")
+
+
+def payload_from_raw(prog, raw_objects, current_stat_reward, raw_stats, snap, steps, seed) -> dict:
+    return sg.payload(sg.objects_from_raw(prog, raw_objects, current_stat_reward), sg.stats_dicts(prog, *raw_stats),
+                      snap["action_success"], snap["episode_rewards"], steps, seed)
+
+
+def diff_payload(pa: dict, pb: dict) -> str:
+    out = []
+    for k in pa:
+        if pa[k] != pb[k]:
+            if k == "stats":
+                ga, gb = pa[k]["game"], pb[k]["game"]
+                out.append(f"game stats: only-a {[x for x in ga if x not in gb]} only-b {[x for x in gb if x not in ga]}")
+                for i, (x, y) in enumerate(zip(pa[k]["agent"], pb[k]["agent"])):
+                    if x != y:
+                        out.append(f"agent {i} stats: only-a {[e for e in x if e not in y]} only-b {[e for e in y if e not in x]}")
+                        break
+            elif k == "objects":
+                for x, y in zip(pa[k], pb[k]):
+                    if x != y:
+                        out.append(f"object: {x} vs {y}")
+                        break
+            else:
+                out.append(f"{k}: {pa[k]} vs {pb[k]}")
+    return "; ".join(out)
