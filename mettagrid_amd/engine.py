@@ -41,6 +41,10 @@ def load_lib():
         raise MgxError(
             f"{LIB_PATH} not found: the HIP engine is not built. Run `python -c 'import __graft_entry__ as g; "
             "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    try:  # one HIP runtime per process: torch bundles libamdhip64.so.7; load it first so libmgx binds to the same one
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
     L.mgx_last_error.restype = C.c_char_p

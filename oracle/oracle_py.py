@@ -74,6 +74,10 @@ class OracleSim:
             self.L.mgxo_destroy(self.h)
             self.h = None
 
+    def reinit_buffers(self) -> None:
+        """What a second MettaGrid::set_buffers call does (mettagrid_c.cpp:1165-1184): clear + initial obs again."""
+        self.L.mgxo_reinit_buffers(self.h)
+
     def step(self, actions, vibe_actions=None) -> None:
         a = np.ascontiguousarray(actions, dtype=np.int32)
         v = np.zeros(self.A, np.int32) if vibe_actions is None else np.ascontiguousarray(vibe_actions, dtype=np.int32)

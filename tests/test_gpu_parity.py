@@ -28,6 +28,8 @@ def test_step_parity(name, buffers):
     seeds = np.arange(E, dtype=np.uint32) * 7 + 3
     eng = BatchedMettaGrid(prog, cms, seeds, buffers=buffers)
     oracles = [op.OracleSim(prog, cms[i], int(seeds[i])) for i in range(E)]
+    for o in oracles:  # the engine binds caller buffers after construction = a second set_buffers in the reference
+        o.reinit_buffers()
     acts = [hp.make_actions(prog, i, steps, invalid) for i in range(E)]
     A = prog.num_agents
 
