@@ -48,3 +48,56 @@ def random_map(height: int, width: int, objects: dict, agents: dict | int, seed:
 
 def ascii_map(lines: list, char_to_name: dict) -> np.ndarray:
     return np.array([[char_to_name[ch] for ch in line] for line in lines], dtype="<U50")
+
+
+def random_class_maps(prog, height: int, width: int, objects: dict, agents: dict | int, seeds, border_width: int = 1,
+                      border_object: str = "wall") -> np.ndarray:
+    """Batched, integer-coded equivalent of ``prog.class_map(random_map(...))`` for many seeds -> uint16 [E][H][W].
+
+    ``Generator.shuffle`` draws the same swap sequence for any dtype, so shuffling small integer codes reproduces the
+    string-array shuffle of the reference's RandomMapBuilder bit for bit (tests/test_host_logic.py).  Per-agent
+    renaming (the k-th cell of a team is that team's k-th agent, row-major) is applied with a cumulative count.
+    """
+    ih, iw = max(0, height - 2 * border_width), max(0, width - 2 * border_width)
+    area = ih * iw
+    if isinstance(agents, int):
+        agent_cells = [("agent.agent", agents)]
+    else:
+        agent_cells = [("agent." + n, c) for n, c in agents.items()]
+    objects = dict(objects)
+    n_agents = sum(c for _, c in agent_cells)
+    if sum(objects.values()) + n_agents > area:
+        raise ValueError("random_class_maps: objects do not fit (the halving rule of random_map is not vectorised)")
+    # symbol codes: 0 empty, 1.. objects (class id + 1), then one code per agent cell name
+    codes, lut = [], {}
+    for name, count in objects.items():
+        codes += [prog.cell_to_class[name] + 1] * count
+    next_code = 60000
+    for name, count in agent_cells:
+        lut[next_code] = name
+        codes += [next_code] * count
+        next_code += 1
+    base = np.array(codes + [0] * (area - len(codes)), dtype=np.uint16)
+    seeds = np.asarray(seeds)
+    out = np.zeros((len(seeds), height, width), dtype=np.uint16)
+    if border_width > 0:
+        b = prog.cell_to_class[border_object] + 1
+        out[:, :border_width, :] = b
+        out[:, -border_width:, :] = b
+        out[:, :, :border_width] = b
+        out[:, :, -border_width:] = b
+    inner = np.empty((len(seeds), area), dtype=np.uint16)
+    for i, s in enumerate(seeds):
+        row = base.copy()
+        np.random.default_rng(int(s)).shuffle(row)
+        inner[i] = row
+    for code, name in lut.items():
+        mask = inner == code
+        if name in prog.agent_rename:
+            group = np.asarray(prog.agent_rename[name], dtype=np.uint16) + 1
+            k = np.cumsum(mask, axis=1) - 1
+            inner = np.where(mask, group[np.clip(k, 0, len(group) - 1)], inner)
+        else:
+            inner = np.where(mask, np.uint16(prog.cell_to_class[name] + 1), inner)
+    out[:, border_width:border_width + ih, border_width:border_width + iw] = inner.reshape(len(seeds), ih, iw)
+    return out
