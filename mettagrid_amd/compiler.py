@@ -485,6 +485,8 @@ class _Compiler:
         if obs.width > 15 or obs.height > 15:  # mettagrid_c.cpp:63-68 (PackedCoordinate 4-bit coords)
             raise RuntimeError(f"Observation window size ({obs.width}x{obs.height}) exceeds maximum packable size")
         base = obs.token_value_base
+        if base <= 1 or base > 256:
+            raise RuntimeError("Base must be greater than 1")  # systems/observation_encoder.hpp:90-92
         digits = num_tokens_needed(65535, base)
         if digits > K.IF_WORDS:
             raise UnsupportedFeature("token_value_base too small")
@@ -609,8 +611,8 @@ class _Compiler:
                 elif al not in cell_to_class:
                     # single-agent team: the map keeps the alias spelling, and the game stat key is
                     # "objects.<cell as spelled in the map>" (mettagrid_c.cpp:244) -> one class copy per alias.
-                    base = per_agent[0] * K.C_WORDS
-                    rec = list(self.sections[K.SEC_CLASSES][base:base + K.C_WORDS])
+                    woff = per_agent[0] * K.C_WORDS
+                    rec = list(self.sections[K.SEC_CLASSES][woff:woff + K.C_WORDS])
                     rec[K.C_OBJECTS_STAT] = self.stat("game", f"objects.{al}")
                     cell_to_class[al] = self.emit(K.SEC_CLASSES, rec)
                     class_cells.append(al)

@@ -42,6 +42,7 @@ struct mgx_engine {
   int32_t *h_act = nullptr, *h_vact = nullptr;
   bool external = false;
   size_t lds_world = 0, lds_obs = 0;
+  int pool_tokens = 0;
   bool profiling = false;
   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
   float last_ms[2] = {0.f, 0.f};
@@ -64,8 +65,8 @@ struct mgx_engine {
 
 static int launch_obs(mgx_engine* e, bool with_rewards) {
   dim3 grid(e->d.E), block(MGX_OBS_THREADS);
-  if (with_rewards) hipLaunchKernelGGL(mgx_obs_kernel<true>, grid, block, e->lds_obs, e->stream, e->d);
-  else hipLaunchKernelGGL(mgx_obs_kernel<false>, grid, block, e->lds_obs, e->stream, e->d);
+  if (with_rewards) hipLaunchKernelGGL(mgx_obs_kernel<true>, grid, block, e->lds_obs, e->stream, e->d, e->pool_tokens);
+  else hipLaunchKernelGGL(mgx_obs_kernel<false>, grid, block, e->lds_obs, e->stream, e->d, e->pool_tokens);
   HIP_TRY(hipGetLastError());
   return MGX_OK;
 }
@@ -103,7 +104,8 @@ int mgx_create(const int32_t* program, size_t program_words, const uint16_t* cla
     return fail(MGX_ERR_PROGRAM, "mgx_create: not a version-" + std::to_string(MGX_VERSION) + " mgx program");
   const int32_t* P = program;
   if (P[MGX_H_NUM_RESOURCES] > MGX_MAX_RESOURCES || P[MGX_H_NUM_AGENTS] >= 255 || P[MGX_H_HEIGHT] > 255 ||
-      P[MGX_H_WIDTH] > 255 || P[MGX_H_NUM_AGENTS] < 1)
+      P[MGX_H_WIDTH] > 255 || P[MGX_H_NUM_AGENTS] < 1 || P[MGX_H_TOKEN_BASE] < 2 || P[MGX_H_TOKEN_BASE] > 256 ||
+      P[MGX_H_NUM_TOKENS] < 1 || P[MGX_H_OBS_HEIGHT] > 15 || P[MGX_H_OBS_WIDTH] > 15)
     return fail(MGX_ERR_PROGRAM, "mgx_create: program exceeds engine limits (resources<=13, agents<255, map<=255x255)");
   HIP_TRY(hipSetDevice(device));
   mgx_engine* e = new mgx_engine();
@@ -185,7 +187,23 @@ int mgx_create(const int32_t* program, size_t program_words, const uint16_t* cla
   d.actions = e->own_act; d.vibe_actions = e->own_vact;
 
   e->lds_world = (size_t)d.A * MGX_WAVE;
-  e->lds_obs = ((HW * 2 + 15) / 16) * 16 + S * 4 + ((A * 4 + 15) / 16) * 16 + (size_t)MGX_OBS_WAVES * (((3 * d.T + 15) / 16) * 16);
+  {  // LDS token pool: every object of an env caches its (feature, value) list once per step.  Upper bound per
+     // object from the program: tags + vibe + R * digits + 2; capped so that several workgroups fit one CU.
+    int digits = 1;
+    for (unsigned v = 65535u / (unsigned)d.base; v > 0; v /= (unsigned)d.base) digits++;
+    int max_per_obj = 1;
+    for (int c = 0; c < P[MGX_H_NUM_CLASSES]; c++) {
+      const int32_t* C = P + d.sec[MGX_SEC_CLASSES] + c * MGX_C_WORDS;
+      int n = 0;
+      for (int w = 0; w < MGX_TAG_WORDS; w++) n += __builtin_popcount((unsigned)C[MGX_C_TAGS + w]);
+      if (!C[MGX_C_STATIC]) n += 1 + P[MGX_H_NUM_RESOURCES] * digits + (C[MGX_C_KIND] == MGX_KIND_AGENT ? 2 : 0);
+      max_per_obj = std::max(max_per_obj, n);
+    }
+    long long bound = (long long)S * max_per_obj;
+    e->pool_tokens = (int)std::min<long long>(bound, 16384);
+    e->pool_tokens = (e->pool_tokens + 7) & ~7;
+  }
+  e->lds_obs = (size_t)mgx_obs_lds_layout((int)HW, d.NOFF, (int)S, (int)A, d.T, e->pool_tokens).total;
   if (e->lds_obs > 160 * 1024 || e->lds_world > 64 * 1024) {
     mgx_destroy(e);
     return fail(MGX_ERR_PROGRAM, "mgx_create: map/object count too large for the LDS staging of the observation kernel");

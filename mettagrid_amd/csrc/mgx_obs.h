@@ -50,8 +50,18 @@ struct MgxTokWriter {
   }
 };
 
-// Number of tokens GridObject::write_obs_features / Agent::write_obs_features emit for the object in `slot`
-// (core/grid_object.cpp:178-203, objects/agent.cpp:142-154).
+// ---------------------------------------------------------------------------------------------------------------
+// Per-object token cache.  GridObject::write_obs_features / Agent::write_obs_features (core/grid_object.cpp:178-203,
+// objects/agent.cpp:142-154) produce the same (feature, value) list for every observer of an object — only the
+// location byte differs.  One thread per object slot builds that list ONCE per env and step into an LDS pool
+// (u16 = feature | value << 8); the per-agent loop then only copies from LDS.
+// ---------------------------------------------------------------------------------------------------------------
+struct MgxObjTok {
+  uint16_t* pool;
+  int pos;
+  __device__ __forceinline__ void put(uint8_t f, uint8_t v) { pool[pos++] = (uint16_t)(f | (v << 8)); }
+};
+
 __device__ int mgx_object_token_count(const MgxDev& d, const MgxEnv& e, int slot, const int32_t* C) {
   int n = 0;
 #pragma unroll
@@ -68,80 +78,133 @@ __device__ int mgx_object_token_count(const MgxDev& d, const MgxEnv& e, int slot
   return n;
 }
 
-__device__ void mgx_object_tokens_emit(const MgxDev& d, const MgxEnv& e, int slot, const int32_t* C, uint8_t loc,
-                                       int pos, const MgxTokWriter& w) {
+__device__ void mgx_object_tokens_build(const MgxDev& d, const MgxEnv& e, int slot, const int32_t* C, MgxObjTok w) {
   const uint8_t ftag = (uint8_t)d.feat[MGX_F_TAG];
   for (int wi = 0; wi < MGX_TAG_WORDS; wi++) {
     uint32_t m = (uint32_t)C[MGX_C_TAGS + wi];
     while (m) {
       int b = __ffs(m) - 1;
       m &= m - 1;
-      w.put(pos++, loc, ftag, (uint8_t)(wi * 32 + b));
+      w.put(ftag, (uint8_t)(wi * 32 + b));
     }
   }
   if (C[MGX_C_STATIC]) return;
   uint8_t vibe = d.obj_vibe[e.so(slot)];
-  if (vibe != 0) w.put(pos++, loc, (uint8_t)d.feat[MGX_F_VIBE], vibe);
+  if (vibe != 0) w.put((uint8_t)d.feat[MGX_F_VIBE], vibe);
   unsigned long long ord = d.obj_order[e.so(slot)];
   for (int k = 0; k < 16; k++) {  // observation_encoder.hpp:198-225: base digit, then :pK digits while remaining > 0
     int item = (int)((ord >> (4 * k)) & 0xF);
     if (item == 0xF) break;
     const int32_t* F = d.P + d.sec[MGX_SEC_INV_FEATURES] + item * MGX_IF_WORDS;
     uint32_t rem = e.inv(slot, item);
-    w.put(pos++, loc, (uint8_t)F[0], (uint8_t)(rem % (uint32_t)d.base));
+    w.put((uint8_t)F[0], (uint8_t)(rem % (uint32_t)d.base));
     rem /= (uint32_t)d.base;
     int p = 1;
     while (rem > 0) {
-      w.put(pos++, loc, (uint8_t)F[p], (uint8_t)(rem % (uint32_t)d.base));
+      w.put((uint8_t)F[p], (uint8_t)(rem % (uint32_t)d.base));
       rem /= (uint32_t)d.base;
       p++;
     }
   }
   if (C[MGX_C_KIND] == MGX_KIND_AGENT) {
-    w.put(pos++, loc, (uint8_t)d.feat[MGX_F_GROUP], (uint8_t)C[MGX_C_GROUP]);
-    w.put(pos++, loc, (uint8_t)d.feat[MGX_F_AGENT_ID], d.obj_agent[e.so(slot)]);
+    w.put((uint8_t)d.feat[MGX_F_GROUP], (uint8_t)C[MGX_C_GROUP]);
+    w.put((uint8_t)d.feat[MGX_F_AGENT_ID], d.obj_agent[e.so(slot)]);
   }
 }
 
-// LDS layout (dynamic): grid u16[HW pad 8] | minobs u32[S] | written i32[A] | stage u8[WAVES][row]
+// Dynamic LDS layout, all regions 16-byte aligned (sizes mirrored by mgx_obs_lds_bytes on the host):
+//   grid u16[HW] | offsets i8x2[NOFF] | minobs u32[S] | visited u32[S] | tokinfo u32[S] (start | count << 16) |
+//   agents u32[A] (slot | rc << 16) | written i32[A] | misc u32[4] | pool u16[POOL] | stage u8[WAVES][row]
+__host__ __device__ inline int mgx_align16(int x) { return (x + 15) & ~15; }
+struct MgxObsLds {
+  int grid, offs, minobs, visited, tokinfo, agents, written, misc, pool, stage, row_bytes, total;
+};
+__host__ __device__ inline MgxObsLds mgx_obs_lds_layout(int HW, int NOFF, int S, int A, int T, int pool_tokens) {
+  MgxObsLds l;
+  int o = 0;
+  l.grid = o; o += mgx_align16(HW * 2);
+  l.offs = o; o += mgx_align16(NOFF * 2);
+  l.minobs = o; o += mgx_align16(S * 4);
+  l.visited = o; o += mgx_align16(S * 4);
+  l.tokinfo = o; o += mgx_align16(S * 4);
+  l.agents = o; o += mgx_align16(A * 4);
+  l.written = o; o += mgx_align16(A * 4);
+  l.misc = o; o += 16;
+  l.pool = o; o += mgx_align16(pool_tokens * 2);
+  l.row_bytes = mgx_align16(3 * T);
+  l.stage = o; o += MGX_OBS_WAVES * l.row_bytes;
+  l.total = o;
+  return l;
+}
+
 template <bool WITH_REWARDS>
-__global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d) {
+__global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int pool_tokens) {
   extern __shared__ __align__(16) uint8_t smem[];
   const int env = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & (MGX_WAVE - 1), wave = tid / MGX_WAVE;
-  const int HW = d.H * d.W, A = d.A, S = d.S, T = d.T;
-  const int grid_bytes = ((HW * 2 + 15) / 16) * 16;
-  const int row_bytes = ((3 * T + 15) / 16) * 16;
-  uint16_t* s_grid = (uint16_t*)smem;
-  uint32_t* s_minobs = (uint32_t*)(smem + grid_bytes);
-  int* s_written = (int*)(smem + grid_bytes + S * 4);
-  uint8_t* s_stage = smem + grid_bytes + S * 4 + ((A * 4 + 15) / 16) * 16 + wave * row_bytes;
+  const int HW = d.H * d.W, A = d.A, S = d.S, T = d.T, NOFF = d.NOFF;
+  const MgxObsLds L = mgx_obs_lds_layout(HW, NOFF, S, A, T, pool_tokens);
+  uint16_t* s_grid = (uint16_t*)(smem + L.grid);
+  char2* s_offs = (char2*)(smem + L.offs);
+  uint32_t* s_minobs = (uint32_t*)(smem + L.minobs);
+  uint32_t* s_visited = (uint32_t*)(smem + L.visited);
+  uint32_t* s_tokinfo = (uint32_t*)(smem + L.tokinfo);
+  uint32_t* s_agents = (uint32_t*)(smem + L.agents);
+  int* s_written = (int*)(smem + L.written);
+  uint32_t* s_misc = (uint32_t*)(smem + L.misc);
+  uint16_t* s_pool = (uint16_t*)(smem + L.pool);
+  uint8_t* s_stage = smem + L.stage + wave * L.row_bytes;
 
   MgxEnv e(d, env);
   e.step = d.step[env];
   const uint32_t step = e.step;
 
-  // ---- stage the env's occupancy grid: coalesced 16 B per lane (env-major block) ----
+  // ---- phase 0: stage the env (coalesced) and build the per-object token cache ----
   {
     const uint4* src = (const uint4*)(d.grid + (size_t)env * HW);
     uint4* dst = (uint4*)s_grid;
     const int n16 = (HW * 2) / 16;
     for (int i = tid; i < n16; i += MGX_OBS_THREADS) dst[i] = src[i];
     for (int i = n16 * 8 + tid; i < HW; i += MGX_OBS_THREADS) s_grid[i] = d.grid[(size_t)env * HW + i];
-    for (int i = tid; i < S; i += MGX_OBS_THREADS) s_minobs[i] = 0xFFFFFFFFu;
+    const int32_t* offs = d.P + d.sec[MGX_SEC_OBS_OFFSETS];
+    for (int i = tid; i < NOFF; i += MGX_OBS_THREADS) s_offs[i] = make_char2((char)offs[i * 2], (char)offs[i * 2 + 1]);
+    for (int i = tid; i < A; i += MGX_OBS_THREADS) {
+      uint32_t slot = d.ag_obj[e.ao(i)];
+      s_agents[i] = slot | ((uint32_t)d.obj_rc[e.so(slot)] << 16);
+    }
+    if (tid == 0) s_misc[0] = 0;  // pool top
+  }
+  __syncthreads();
+  for (int s = tid; s < S; s += MGX_OBS_THREADS) {
+    s_minobs[s] = 0xFFFFFFFFu;
+    uint32_t info = 0;
+    uint16_t cls = d.obj_cls[e.so(s)];
+    if (cls != MGX_DEAD_CLASS) {
+      const int32_t* C = mgx_cls(d, cls);
+      int n = mgx_object_token_count(d, e, s, C);
+      uint32_t start = atomicAdd(&s_misc[0], (uint32_t)n);
+      if ((int)(start + n) <= pool_tokens) {
+        mgx_object_tokens_build(d, e, s, C, MgxObjTok{s_pool, (int)start});
+        info = start | ((uint32_t)n << 16);
+      } else {
+        d.err[env] |= 16u;  // token pool exhausted (sized from the program's per-object maximum; see host)
+      }
+      s_visited[s] = d.obj_visited[e.so(s)];
+    }
+    s_tokinfo[s] = info;
   }
   __syncthreads();
 
-  const int32_t* offs = d.P + d.sec[MGX_SEC_OBS_OFFSETS];
   const int hr = d.feat[14], wr = d.feat[15];  // obs_height >> 1, obs_width >> 1 (stored by the host)
 
   // ---- phase 1: first observer (lowest agent index) of every visible object ----
   if (step > 0) {
     for (int a = wave; a < A; a += MGX_OBS_WAVES) {
-      uint16_t rc = d.obj_rc[e.so(d.ag_obj[e.ao(a)])];
-      int r0 = rc >> 8, c0 = rc & 0xFF;
-      for (int j = lane; j < d.NOFF; j += MGX_WAVE) {
-        int r = r0 + offs[j * 2], c = c0 + offs[j * 2 + 1];
+      uint32_t ag = s_agents[a];
+      int r0 = (ag >> 24) & 0xFF, c0 = (ag >> 16) & 0xFF;
+      for (int j = lane; j < NOFF; j += MGX_WAVE) {
+        char2 o = s_offs[j];
+        int r = r0 + o.x, c = c0 + o.y;
         if (r < 0 || c < 0 || r >= d.H || c >= d.W) continue;
         int slot = (int)s_grid[r * d.W + c] - 1;
         if (slot >= 0) atomicMin(&s_minobs[slot], (uint32_t)a);
@@ -153,10 +216,11 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d) {
   // ---- phase 2: encode ----
   MgxTokWriter w{s_stage, T};
   for (int a = wave; a < A; a += MGX_OBS_WAVES) {
-    const int my_slot = d.ag_obj[e.ao(a)];
-    const uint16_t rc = d.obj_rc[e.so(my_slot)];
+    const uint32_t ag = s_agents[a];
+    const int my_slot = ag & 0xFFFF;
+    const uint16_t rc = (uint16_t)(ag >> 16);
     const int r0 = rc >> 8, c0 = rc & 0xFF;
-    for (int i = lane; i < row_bytes / 4; i += MGX_WAVE) ((uint32_t*)s_stage)[i] = 0xFFFFFFFFu;
+    for (int i = lane; i < L.row_bytes / 16; i += MGX_WAVE) ((uint4*)s_stage)[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
 
     // global tokens (location 0xFE), mettagrid_c.cpp:700-753 — a handful, written by lane 0
     int n_global = 0;
@@ -195,29 +259,29 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d) {
     }
     int base_pos = __shfl(n_global, 0);
 
-    // window cells in reference order; 64 cells per pass
+    // window cells in reference order; 64 cells per pass; everything below reads LDS only
     float visited_acc = 0.f;
     bool visited_any = false;
     const int sid_visited = mgx_wk(d, MGX_S_CELL_VISITED);
     if (step > 0) visited_acc = e.astat_get(a, sid_visited);
-    for (int j0 = 0; j0 < d.NOFF; j0 += MGX_WAVE) {
+    for (int j0 = 0; j0 < NOFF; j0 += MGX_WAVE) {
       const int j = j0 + lane;
-      int slot = -1, n = 0;
+      int n = 0, start = 0;
       uint8_t loc = 0;
-      const int32_t* C = nullptr;
       float stale = 0.f;
       bool first = false;
-      if (j < d.NOFF) {
-        int dr = offs[j * 2], dc = offs[j * 2 + 1];
-        int r = r0 + dr, c = c0 + dc;
+      if (j < NOFF) {
+        char2 o = s_offs[j];
+        int r = r0 + o.x, c = c0 + o.y;
         if (r >= 0 && c >= 0 && r < d.H && c < d.W) {
-          slot = (int)s_grid[r * d.W + c] - 1;
+          int slot = (int)s_grid[r * d.W + c] - 1;
           if (slot >= 0) {
-            loc = (uint8_t)(((dr + hr) << 4) | (dc + wr));
-            C = mgx_cls(d, d.obj_cls[e.so(slot)]);
-            n = mgx_object_token_count(d, e, slot, C);
+            loc = (uint8_t)(((o.x + hr) << 4) | (o.y + wr));
+            uint32_t info = s_tokinfo[slot];
+            start = info & 0xFFFF;
+            n = info >> 16;
             if (step > 0 && s_minobs[slot] == (uint32_t)a) {
-              uint32_t pv = d.obj_visited[e.so(slot)];
+              uint32_t pv = s_visited[slot];
               if (pv < step) { first = true; stale = (float)(step - pv); }
             }
           }
@@ -225,9 +289,12 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d) {
       }
       int total;
       int pos = base_pos + mgx_wave_excl_scan(n, lane, &total);
-      if (n > 0) mgx_object_tokens_emit(d, e, slot, C, loc, pos, w);
+      for (int k = 0; k < n; k++) {
+        uint16_t t = s_pool[start + k];
+        w.put(pos + k, loc, (uint8_t)(t & 0xFF), (uint8_t)(t >> 8));
+      }
       base_pos += total;
-      // cell.visited staleness, added in cell order exactly like the serial reference loop
+      // cell.visited staleness, added in cell order exactly like the serial reference loop (:789-796)
       unsigned long long m = __ballot(first);
       while (m) {
         int l = __ffsll((long long)m) - 1;
@@ -241,14 +308,17 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d) {
       s_written[a] = base_pos;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // LDS staging row complete before it is read back
-    // ---- store the row: coalesced dwords ----
+    // ---- store the row with the widest access the row pitch allows ----
     uint8_t* out = d.obs + ((size_t)env * A + a) * (size_t)T * 3;
-    if (((3 * T) & 3) == 0) {
-      uint32_t* o32 = (uint32_t*)out;
-      const uint32_t* s32 = (const uint32_t*)s_stage;
-      for (int i = lane; i < (3 * T) / 4; i += MGX_WAVE) o32[i] = s32[i];
+    const int nbytes = 3 * T;
+    if ((nbytes & 15) == 0) {
+      for (int i = lane; i < nbytes / 16; i += MGX_WAVE) ((uint4*)out)[i] = ((const uint4*)s_stage)[i];
+    } else if ((nbytes & 7) == 0) {
+      for (int i = lane; i < nbytes / 8; i += MGX_WAVE) ((uint2*)out)[i] = ((const uint2*)s_stage)[i];
+    } else if ((nbytes & 3) == 0) {
+      for (int i = lane; i < nbytes / 4; i += MGX_WAVE) ((uint32_t*)out)[i] = ((const uint32_t*)s_stage)[i];
     } else {
-      for (int i = lane; i < 3 * T; i += MGX_WAVE) out[i] = s_stage[i];
+      for (int i = lane; i < nbytes; i += MGX_WAVE) out[i] = s_stage[i];
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
   }
@@ -257,7 +327,7 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d) {
   // ---- visited stamps, token statistics, rewards, termination ----
   if (step > 0)
     for (int s = tid; s < S; s += MGX_OBS_THREADS)
-      if (s_minobs[s] != 0xFFFFFFFFu && d.obj_visited[e.so(s)] < step) d.obj_visited[e.so(s)] = step;
+      if (s_minobs[s] != 0xFFFFFFFFu && s_visited[s] < step) d.obj_visited[e.so(s)] = step;
   if (tid == 0) {  // sequential f32 adds in agent order, as the reference does (:659-661, 821-823)
     float* gs = d.game_stats + (size_t)env * d.NG;
     float tw = gs[mgx_wk(d, MGX_S_GAME_TOKENS_WRITTEN)], tf = gs[mgx_wk(d, MGX_S_GAME_TOKENS_FREE)];
@@ -274,7 +344,7 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d) {
   }
   if (WITH_REWARDS) {
     for (int a = tid; a < A; a += MGX_OBS_THREADS) {  // RewardHelper::compute_entries, systems/reward.hpp:56-77
-      const int slot = d.ag_obj[e.ao(a)];
+      const int slot = s_agents[a] & 0xFFFF;
       const int32_t* C = e.cls_of(slot);
       const int32_t* rw = d.P + d.sec[MGX_SEC_REWARDS] + C[MGX_C_REWARD_START] * MGX_RW_WORDS;
       float total = 0.f;

@@ -1,0 +1,59 @@
+"""Generates the golden parity fixtures from the REAL reference engine (oracle/_ref, built from /root/reference/cpp).
+
+Run in the build container only:  python tests/golden/make_golden.py
+Output: tests/golden/<scenario>_s<seed>.npz — inputs (class map, seed, action traces) and the reference's outputs
+after every step (observations, rewards, terminals, truncations, action_success, episode rewards) plus the generalised
+signature payload (JSON) and its SHA-256.  Fixtures are data only; no reference source is copied.
+"""
+import json
+import os
+import platform
+import subprocess
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+
+import helpers as hp  # noqa: E402
+import ref_driver as rd  # noqa: E402
+from mettagrid_amd import signature as sg  # noqa: E402
+from mettagrid_amd.compiler import compile_spec  # noqa: E402
+
+SEEDS = {"rung1": [42], "rung1_invalid": [43], "rung2": [0, 1], "rung3": [0, 1], "rung3_flat_damage": [10],
+         "torture": [0, 1], "torture_terminal": [2]}
+
+
+def main() -> None:
+    gxx = subprocess.run(["g++", "--version"], capture_output=True, text=True).stdout.splitlines()[0]
+    for name, seeds in SEEDS.items():
+        spec_f, map_f, steps, invalid = hp.SCENARIOS[name]
+        for seed in seeds:
+            spec = spec_f()
+            cells = map_f(seed)
+            prog = compile_spec(spec, *cells.shape)
+            sim = rd.RefSim(spec, cells, seed, prog)
+            acts, vibes = hp.make_actions(prog, seed, steps, invalid)
+            trace = {k: [v] for k, v in sim.snapshot().items()}
+            for t in range(steps):
+                sim.step(acts[t], vibes[t])
+                for k, v in sim.snapshot().items():
+                    trace[k].append(v)
+            c = sim.c
+            payload = sg.payload(c.grid_objects(), c.get_episode_stats(), c.action_success(), c.get_episode_rewards(),
+                                 c.current_step, seed)
+            meta = {"scenario": name, "seed": seed, "steps": steps, "toolchain": gxx, "python": platform.python_version(),
+                    "signature": sg.signature(payload)}
+            out = os.path.join(HERE, f"{name}_s{seed}.npz")
+            np.savez_compressed(out, class_map=prog.class_map(cells), actions=acts, vibe_actions=vibes,
+                                payload=np.frombuffer(json.dumps(payload).encode(), dtype=np.uint8),
+                                meta=np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8),
+                                **{k: np.stack(v) for k, v in trace.items()})
+            print(out, os.path.getsize(out) // 1024, "KiB", meta["signature"][:16])
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,36 @@
+"""The C-ABI shared library loads on a GPU-less host and exports every symbol include/mgx.h declares.
+No compute call is made here (there is no GPU and no CPU fallback)."""
+import ctypes
+import os
+
+from mettagrid_amd import engine
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    import __graft_entry__ as g
+    g.build_engine()
+    lib = ctypes.CDLL(engine.LIB_PATH)
+    syms = engine.exported_symbols()
+    assert len(syms) >= 20
+    missing = [s for s in syms if not hasattr(lib, s)]
+    assert not missing, missing
+
+
+def test_bad_program_is_rejected_without_touching_the_gpu():
+    lib = engine.load_lib()
+    bad = (ctypes.c_int32 * 200)()
+    maps = (ctypes.c_uint16 * 4)()
+    seeds = (ctypes.c_uint32 * 1)()
+    h = ctypes.c_void_p()
+    rc = lib.mgx_create(bad, 200, maps, seeds, 1, 0, ctypes.byref(h))
+    assert rc == -3 and b"mgx program" in lib.mgx_last_error()
+    assert lib.mgx_step(None) == -1
+
+
+def test_header_constants_parse():
+    from mettagrid_amd.fmt import K
+    assert K.MAGIC == 0x3158474D and K.C_WORDS == K.C_RES_LIMIT + K.MAX_RESOURCES
+    assert K.H_SECTION_BASE + 2 * K.SEC_COUNT <= K.H_WORDS
+    assert K.H_STAT_BASE + K.S_GAME_TOKENS_FREE < K.H_SECTION_BASE

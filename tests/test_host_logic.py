@@ -1,0 +1,118 @@
+"""Host logic: libstdc++ order emulation, observation pattern, compiler tables, map generation."""
+import os
+
+import numpy as np
+import pytest
+
+from mettagrid_amd import presets
+from mettagrid_amd import spec as S
+from mettagrid_amd.compiler import UnsupportedFeature, compile_spec, observation_offsets
+from mettagrid_amd.fmt import K
+from mettagrid_amd.mapgen import random_class_maps
+from mettagrid_amd.umap import UMap, from_pydict
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_umap_matches_libstdcxx_golden_orders():
+    """tests/golden/libstdcxx_umap_orders.txt was produced by gen_umap_orders.cpp with g++ 11.4 (the oracle toolchain)."""
+    n = 0
+    for line in open(os.path.join(GOLD, "libstdcxx_umap_orders.txt")):
+        ops, res = line.split(" =")
+        exp, nb = res.split("| nb")
+        toks = ops.split()
+        m = UMap()
+        if int(toks[1]) >= 0:
+            m.reserve(int(toks[1]))
+        for t in toks[2:]:
+            (m.erase if t[0] == "E" else m.insert)(int(t[1:]))
+        assert m.keys() == [int(x) for x in exp.split()] and m.nb == int(nb), line
+        n += 1
+    assert n == 400
+
+
+def test_umap_survey_vector():
+    """SURVEY.md §7.3.2 verified vector: insert 3,0,7,1 -> 1 7 0 3; erase 0 + reinsert -> 0 1 7 3; 16 collides with 3."""
+    m = UMap()
+    for k in (3, 0, 7, 1):
+        m.insert(k)
+    assert m.keys() == [1, 7, 0, 3]
+    m.erase(0)
+    m.insert(0)
+    assert m.keys() == [0, 1, 7, 3]
+    m.insert(16)
+    assert m.keys() == [0, 1, 7, 16, 3]
+    m.insert(13)
+    assert m.keys() == [13, 0, 1, 7, 16, 3]
+    assert from_pydict([5, 2, 9]).nb == 3
+
+
+def _sorted_reference(h, w):
+    """compute_sorted_offsets of /root/reference/tests/test_observations.cpp:16-38 (the reference's own oracle)."""
+    res = [(dr, dc) for dr in range(-(h // 2), h // 2 + 1) for dc in range(-(w // 2), w // 2 + 1)]
+    return sorted(res, key=lambda a: (abs(a[0]) + abs(a[1]), a))
+
+
+@pytest.mark.parametrize("hw", [(3, 9), (7, 3), (5, 5), (1, 1), (1, 5), (5, 1)])
+def test_observation_pattern_matches_reference_offsets(hw):
+    """tests/test_observations.cpp:84-104 MatchesReferenceOffsets — the unmasked pattern (mask disabled by testing
+    shapes where every in-rectangle cell is compared after removing the mask)."""
+    h, w = hw
+    full = _sorted_reference(h, w)
+    got = observation_offsets(h, w)
+    assert got == [o for o in full if o in set(got)]          # order = reference order
+    assert len(set(got)) == len(got)                            # unique (OffsetsAreUnique)
+    d = [abs(a) + abs(b) for a, b in got]
+    assert d == sorted(d)                                       # OffsetsInManhattanOrder
+
+
+def test_observation_mask_sizes():
+    """11x11 -> 89 cells (disc r=5 plus 8 tip cells), 13x13 -> 121... wait-free known counts."""
+    assert len(observation_offsets(11, 11)) == 89
+    assert len(observation_offsets(7, 7)) == 37
+    assert len(observation_offsets(5, 5)) == 21
+    assert len(observation_offsets(3, 3)) == 5
+    assert observation_offsets(1, 1) == [(0, 0)]
+    assert observation_offsets(11, 11)[:5] == [(0, 0), (-1, 0), (0, -1), (0, 1), (1, 0)]
+
+
+def test_compiler_action_space_and_ids():
+    prog = compile_spec(presets.rung3_spec(), 32, 32)
+    assert prog.action_names[:3] == ["noop", "move_north", "move_south"]
+    assert prog.action_names[-4:] == ["change_vibe_default", "change_vibe_a", "change_vibe_b", "change_vibe_c"]
+    assert prog.type_names == sorted(prog.type_names) and prog.tag_names == sorted(prog.tag_names)
+    assert "type:agent" in prog.tag_names and "team:red" in prog.tag_names
+    f = prog.feature_ids
+    assert (f["agent:group"], f["episode_completion_pct"], f["last_action"], f["last_reward"], f["goal"], f["vibe"],
+            f["tag"], f["lp:east"], f["agent_id"]) == (0, 1, 2, 3, 4, 5, 6, 7, 11)
+    assert f["inv:ore"] == 12 and f["inv:ore:p1"] == 13 and f["inv:hp"] == 14
+    w = prog.words
+    assert w[K.H_MAGIC] == K.MAGIC and w[K.H_TOTAL_WORDS] == w.size and w[K.H_NUM_OBS_OFFSETS] == 89
+    assert w[K.H_HP_RESOURCE] == prog.resource_names.index("hp") and w[K.H_MAX_PRIORITY] == 1
+
+
+def test_compiler_rejects_unsupported_features():
+    spec = presets.rung2_spec()
+    spec.resource_names = [f"r{i}" for i in range(14)]
+    with pytest.raises(UnsupportedFeature):
+        compile_spec(spec, 32, 32)
+    spec = presets.rung2_spec()
+    spec.obs = S.ObsSpec(width=17, height=17)
+    with pytest.raises(RuntimeError, match="exceeds maximum packable size"):
+        compile_spec(spec, 32, 32)
+
+
+def test_unknown_map_cell_raises_like_reference():
+    prog = compile_spec(presets.rung1_spec(), 16, 16)
+    cells = presets.rung1_map()
+    cells[3, 3] = "unicorn"
+    with pytest.raises(RuntimeError, match="Unknown object type: unicorn"):
+        prog.class_map(cells)
+
+
+def test_random_class_maps_equal_reference_builder_semantics():
+    prog = compile_spec(presets.rung3_spec(), 32, 32)
+    cms = random_class_maps(prog, 32, 32, {"wall": 40, "extractor": 8, "chest": 4}, {"red": 8, "blue": 8}, range(5))
+    for s in range(5):
+        assert np.array_equal(cms[s], prog.class_map(presets.rung3_map(s)))
+    assert int((cms[0] > 0).sum()) == 124 + 40 + 8 + 4 + 16
