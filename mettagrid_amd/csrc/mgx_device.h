@@ -31,6 +31,9 @@ struct MgxDev {
   int feat[16];
   int wk[32];             // well-known stat ids (MGX_S_*)
 
+  // ---- static per-class observation tokens (built by the host at mgx_create) ----
+  const uint32_t* cls_tokinfo;  // [classes] start(16) | group(8) | ntags(6) | is_agent(1) | is_static(1)
+  const uint16_t* cls_tok;      // tag tokens: feature | tag id << 8
   // ---- env-major object state ----
   uint16_t* grid;         // [E][H*W]   0 = empty, else slot + 1
   uint16_t* obj_cls;      // [E][S]     class id, MGX_DEAD_CLASS = unused slot

@@ -203,6 +203,32 @@ int mgx_create(const int32_t* program, size_t program_words, const uint16_t* cla
     e->pool_tokens = (int)std::min<long long>(bound, 16384);
     e->pool_tokens = (e->pool_tokens + 7) & ~7;
   }
+  {  // per-class static tag tokens (ascending tag id, core/grid_object.cpp:181-186)
+    std::vector<uint32_t> info(P[MGX_H_NUM_CLASSES]);
+    std::vector<uint16_t> toks;
+    for (int c = 0; c < P[MGX_H_NUM_CLASSES]; c++) {
+      const int32_t* C = P + d.sec[MGX_SEC_CLASSES] + c * MGX_C_WORDS;
+      uint32_t start = (uint32_t)toks.size();
+      int nt = 0;
+      for (int t = 0; t < 256; t++)
+        if (((uint32_t)C[MGX_C_TAGS + (t >> 5)] >> (t & 31)) & 1u) { toks.push_back((uint16_t)(d.feat[MGX_F_TAG] | (t << 8))); nt++; }
+      if (nt > 63 || start > 0xFFFF) { mgx_destroy(e); return fail(MGX_ERR_PROGRAM, "mgx_create: more than 63 tags on one class"); }
+      info[c] = start | ((uint32_t)(C[MGX_C_GROUP] & 0xFF) << 16) | ((uint32_t)nt << 24) |
+                (C[MGX_C_KIND] == MGX_KIND_AGENT ? 0x40000000u : 0u) | (C[MGX_C_STATIC] ? 0x80000000u : 0u);
+    }
+    if (toks.empty()) toks.push_back(0);
+    uint32_t* dinfo = nullptr;
+    uint16_t* dtoks = nullptr;
+    rc = e->alloc(&dinfo, info.size());
+    if (rc == MGX_OK) rc = e->alloc(&dtoks, toks.size());
+    if (rc != MGX_OK) { mgx_destroy(e); return rc; }
+    hipError_t ce = hipMemcpyAsync(dinfo, info.data(), info.size() * 4, hipMemcpyHostToDevice, e->stream);
+    if (ce == hipSuccess) ce = hipMemcpyAsync(dtoks, toks.data(), toks.size() * 2, hipMemcpyHostToDevice, e->stream);
+    if (ce == hipSuccess) ce = hipStreamSynchronize(e->stream);
+    if (ce != hipSuccess) { mgx_destroy(e); return fail(MGX_ERR_HIP, std::string("class token upload: ") + hipGetErrorString(ce)); }
+    d.cls_tokinfo = dinfo;
+    d.cls_tok = dtoks;
+  }
   e->lds_obs = (size_t)mgx_obs_lds_layout((int)HW, d.NOFF, (int)S, (int)A, d.T, e->pool_tokens).total;
   if (e->lds_obs > 160 * 1024 || e->lds_world > 64 * 1024) {
     mgx_destroy(e);

@@ -20,15 +20,16 @@
 #define MGX_OBS_THREADS 256
 #define MGX_OBS_WAVES (MGX_OBS_THREADS / MGX_WAVE)
 
-__device__ __forceinline__ int mgx_wave_excl_scan(int v, int lane, int* total) {
-  int x = v;
-#pragma unroll
-  for (int off = 1; off < MGX_WAVE; off <<= 1) {
-    int y = __shfl_up(x, off);
-    if (lane >= off) x += y;
-  }
-  *total = __shfl(x, MGX_WAVE - 1);
-  return x - v;
+// Wavefront inclusive scan with DPP row shifts / row broadcasts (no LDS traffic): Hillis-Steele inside each 16-lane
+// row, then row 0->1, 2->3 (row_bcast:15) and rows {0,1}->{2,3} (row_bcast:31).
+__device__ __forceinline__ int mgx_wave_incl_scan(int x) {
+  x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);  // row_shr:1
+  x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);  // row_shr:2
+  x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);  // row_shr:4
+  x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);  // row_shr:8
+  x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1,3
+  x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2,3
+  return x;
 }
 
 __device__ __forceinline__ int mgx_digits(uint32_t v, uint32_t base) {  // encoding_utils.hpp:39-62
@@ -38,23 +39,12 @@ __device__ __forceinline__ int mgx_digits(uint32_t v, uint32_t base) {  // encod
   return n;
 }
 
-struct MgxTokWriter {
-  uint8_t* stage;  // LDS row of this wavefront
-  int T;
-  __device__ __forceinline__ void put(int pos, uint8_t loc, uint8_t f, uint8_t v) const {
-    if (pos < T) {
-      stage[pos * 3] = loc;
-      stage[pos * 3 + 1] = f;
-      stage[pos * 3 + 2] = v;
-    }
-  }
-};
-
 // ---------------------------------------------------------------------------------------------------------------
 // Per-object token cache.  GridObject::write_obs_features / Agent::write_obs_features (core/grid_object.cpp:178-203,
 // objects/agent.cpp:142-154) produce the same (feature, value) list for every observer of an object — only the
 // location byte differs.  One thread per object slot builds that list ONCE per env and step into an LDS pool
-// (u16 = feature | value << 8); the per-agent loop then only copies from LDS.
+// (u16 = feature | value << 8); the per-agent loop then only copies from LDS.  The tag part of the list is static per
+// class and comes from a table the host builds at mgx_create (MgxDev::cls_tok*).
 // ---------------------------------------------------------------------------------------------------------------
 struct MgxObjTok {
   uint16_t* pool;
@@ -62,11 +52,8 @@ struct MgxObjTok {
   __device__ __forceinline__ void put(uint8_t f, uint8_t v) { pool[pos++] = (uint16_t)(f | (v << 8)); }
 };
 
-__device__ int mgx_object_token_count(const MgxDev& d, const MgxEnv& e, int slot, const int32_t* C) {
+__device__ int mgx_object_dyn_token_count(const MgxDev& d, const MgxEnv& e, int slot, uint32_t cinfo) {
   int n = 0;
-#pragma unroll
-  for (int w = 0; w < MGX_TAG_WORDS; w++) n += __popc((uint32_t)C[MGX_C_TAGS + w]);
-  if (C[MGX_C_STATIC]) return n;
   if (d.obj_vibe[e.so(slot)] != 0) n++;
   unsigned long long ord = d.obj_order[e.so(slot)];
   for (int k = 0; k < 16; k++) {
@@ -74,21 +61,11 @@ __device__ int mgx_object_token_count(const MgxDev& d, const MgxEnv& e, int slot
     if (item == 0xF) break;
     n += mgx_digits(e.inv(slot, item), (uint32_t)d.base);
   }
-  if (C[MGX_C_KIND] == MGX_KIND_AGENT) n += 2;
+  if (cinfo & 0x40000000u) n += 2;  // agent: group + agent_id
   return n;
 }
 
-__device__ void mgx_object_tokens_build(const MgxDev& d, const MgxEnv& e, int slot, const int32_t* C, MgxObjTok w) {
-  const uint8_t ftag = (uint8_t)d.feat[MGX_F_TAG];
-  for (int wi = 0; wi < MGX_TAG_WORDS; wi++) {
-    uint32_t m = (uint32_t)C[MGX_C_TAGS + wi];
-    while (m) {
-      int b = __ffs(m) - 1;
-      m &= m - 1;
-      w.put(ftag, (uint8_t)(wi * 32 + b));
-    }
-  }
-  if (C[MGX_C_STATIC]) return;
+__device__ void mgx_object_dyn_tokens_build(const MgxDev& d, const MgxEnv& e, int slot, uint32_t cinfo, MgxObjTok w) {
   uint8_t vibe = d.obj_vibe[e.so(slot)];
   if (vibe != 0) w.put((uint8_t)d.feat[MGX_F_VIBE], vibe);
   unsigned long long ord = d.obj_order[e.so(slot)];
@@ -106,18 +83,19 @@ __device__ void mgx_object_tokens_build(const MgxDev& d, const MgxEnv& e, int sl
       p++;
     }
   }
-  if (C[MGX_C_KIND] == MGX_KIND_AGENT) {
-    w.put((uint8_t)d.feat[MGX_F_GROUP], (uint8_t)C[MGX_C_GROUP]);
+  if (cinfo & 0x40000000u) {
+    w.put((uint8_t)d.feat[MGX_F_GROUP], (uint8_t)((cinfo >> 16) & 0xFF));
     w.put((uint8_t)d.feat[MGX_F_AGENT_ID], d.obj_agent[e.so(slot)]);
   }
 }
 
-// Dynamic LDS layout, all regions 16-byte aligned (sizes mirrored by mgx_obs_lds_bytes on the host):
+// Dynamic LDS layout, all regions 16-byte aligned (the host calls the same function):
 //   grid u16[HW] | offsets i8x2[NOFF] | minobs u32[S] | visited u32[S] | tokinfo u32[S] (start | count << 16) |
-//   agents u32[A] (slot | rc << 16) | written i32[A] | misc u32[4] | pool u16[POOL] | stage u8[WAVES][row]
+//   agents u32[A] (slot | rc << 16) | aginfo u32[A] (executed | moved << 8) | spawn u16[A] | vstat f32[A] |
+//   written i32[A] | misc u32[4] | pool u16[POOL] | rows u32[WAVES][Tpad]
 __host__ __device__ inline int mgx_align16(int x) { return (x + 15) & ~15; }
 struct MgxObsLds {
-  int grid, offs, minobs, visited, tokinfo, agents, written, misc, pool, stage, row_bytes, total;
+  int grid, offs, minobs, visited, tokinfo, agents, aginfo, spawn, vstat, written, misc, pool, rows, row_words, total;
 };
 __host__ __device__ inline MgxObsLds mgx_obs_lds_layout(int HW, int NOFF, int S, int A, int T, int pool_tokens) {
   MgxObsLds l;
@@ -128,11 +106,14 @@ __host__ __device__ inline MgxObsLds mgx_obs_lds_layout(int HW, int NOFF, int S,
   l.visited = o; o += mgx_align16(S * 4);
   l.tokinfo = o; o += mgx_align16(S * 4);
   l.agents = o; o += mgx_align16(A * 4);
+  l.aginfo = o; o += mgx_align16(A * 4);
+  l.spawn = o; o += mgx_align16(A * 2);
+  l.vstat = o; o += mgx_align16(A * 4);
   l.written = o; o += mgx_align16(A * 4);
   l.misc = o; o += 16;
   l.pool = o; o += mgx_align16(pool_tokens * 2);
-  l.row_bytes = mgx_align16(3 * T);
-  l.stage = o; o += MGX_OBS_WAVES * l.row_bytes;
+  l.row_words = (T + 3) & ~3;
+  l.rows = o; o += MGX_OBS_WAVES * l.row_words * 4;
   l.total = o;
   return l;
 }
@@ -150,14 +131,18 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
   uint32_t* s_visited = (uint32_t*)(smem + L.visited);
   uint32_t* s_tokinfo = (uint32_t*)(smem + L.tokinfo);
   uint32_t* s_agents = (uint32_t*)(smem + L.agents);
+  uint32_t* s_aginfo = (uint32_t*)(smem + L.aginfo);
+  uint16_t* s_spawn = (uint16_t*)(smem + L.spawn);
+  float* s_vstat = (float*)(smem + L.vstat);
   int* s_written = (int*)(smem + L.written);
   uint32_t* s_misc = (uint32_t*)(smem + L.misc);
   uint16_t* s_pool = (uint16_t*)(smem + L.pool);
-  uint8_t* s_stage = smem + L.stage + wave * L.row_bytes;
+  uint32_t* s_row = (uint32_t*)(smem + L.rows) + wave * L.row_words;  // one u32 per token: loc | f << 8 | v << 16
 
   MgxEnv e(d, env);
   e.step = d.step[env];
   const uint32_t step = e.step;
+  const int sid_visited = mgx_wk(d, MGX_S_CELL_VISITED);
 
   // ---- phase 0: stage the env (coalesced) and build the per-object token cache ----
   {
@@ -170,7 +155,11 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
     for (int i = tid; i < NOFF; i += MGX_OBS_THREADS) s_offs[i] = make_char2((char)offs[i * 2], (char)offs[i * 2 + 1]);
     for (int i = tid; i < A; i += MGX_OBS_THREADS) {
       uint32_t slot = d.ag_obj[e.ao(i)];
-      s_agents[i] = slot | ((uint32_t)d.obj_rc[e.so(slot)] << 16);
+      uint16_t rc = d.obj_rc[e.so(slot)];
+      s_agents[i] = slot | ((uint32_t)rc << 16);
+      s_aginfo[i] = ((uint32_t)d.executed[e.ao(i)] & 0xFF) | (rc != d.ag_stepprev[e.ao(i)] ? 0x100u : 0u);
+      s_spawn[i] = d.ag_spawn[e.ao(i)];
+      s_vstat[i] = step > 0 ? e.astat_get(i, sid_visited) : 0.f;
     }
     if (tid == 0) s_misc[0] = 0;  // pool top
   }
@@ -180,14 +169,18 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
     uint32_t info = 0;
     uint16_t cls = d.obj_cls[e.so(s)];
     if (cls != MGX_DEAD_CLASS) {
-      const int32_t* C = mgx_cls(d, cls);
-      int n = mgx_object_token_count(d, e, s, C);
+      const uint32_t cinfo = d.cls_tokinfo[cls];  // start(16) | group(8) | ntags(6) | agent(1) | static(1)
+      const int ntags = (cinfo >> 24) & 0x3F;
+      const bool is_static = (cinfo >> 31) != 0;
+      int n = ntags + (is_static ? 0 : mgx_object_dyn_token_count(d, e, s, cinfo));
       uint32_t start = atomicAdd(&s_misc[0], (uint32_t)n);
       if ((int)(start + n) <= pool_tokens) {
-        mgx_object_tokens_build(d, e, s, C, MgxObjTok{s_pool, (int)start});
+        const uint16_t* src = d.cls_tok + (cinfo & 0xFFFF);
+        for (int k = 0; k < ntags; k++) s_pool[start + k] = src[k];
+        if (!is_static) mgx_object_dyn_tokens_build(d, e, s, cinfo, MgxObjTok{s_pool, (int)start + ntags});
         info = start | ((uint32_t)n << 16);
       } else {
-        d.err[env] |= 16u;  // token pool exhausted (sized from the program's per-object maximum; see host)
+        d.err[env] |= 16u;  // token pool exhausted (sized by the host from the program's per-object maximum)
       }
       s_visited[s] = d.obj_visited[e.so(s)];
     }
@@ -196,6 +189,7 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
   __syncthreads();
 
   const int hr = d.feat[14], wr = d.feat[15];  // obs_height >> 1, obs_width >> 1 (stored by the host)
+  const int NPASS = (NOFF + 2 * MGX_WAVE - 1) / (2 * MGX_WAVE);  // two window cells per lane and pass
 
   // ---- phase 1: first observer (lowest agent index) of every visible object ----
   if (step > 0) {
@@ -205,120 +199,136 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
       for (int j = lane; j < NOFF; j += MGX_WAVE) {
         char2 o = s_offs[j];
         int r = r0 + o.x, c = c0 + o.y;
-        if (r < 0 || c < 0 || r >= d.H || c >= d.W) continue;
-        int slot = (int)s_grid[r * d.W + c] - 1;
-        if (slot >= 0) atomicMin(&s_minobs[slot], (uint32_t)a);
+        if ((unsigned)r < (unsigned)d.H && (unsigned)c < (unsigned)d.W) {
+          int slot = (int)s_grid[r * d.W + c] - 1;
+          if (slot >= 0) atomicMin(&s_minobs[slot], (uint32_t)a);
+        }
       }
     }
   }
   __syncthreads();
 
   // ---- phase 2: encode ----
-  MgxTokWriter w{s_stage, T};
   for (int a = wave; a < A; a += MGX_OBS_WAVES) {
     const uint32_t ag = s_agents[a];
     const int my_slot = ag & 0xFFFF;
-    const uint16_t rc = (uint16_t)(ag >> 16);
-    const int r0 = rc >> 8, c0 = rc & 0xFF;
-    for (int i = lane; i < L.row_bytes / 16; i += MGX_WAVE) ((uint4*)s_stage)[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
+    const int r0 = (ag >> 24) & 0xFF, c0 = (ag >> 16) & 0xFF;
+    for (int i = lane; i < L.row_words / 4; i += MGX_WAVE) ((uint4*)s_row)[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
 
     // global tokens (location 0xFE), mettagrid_c.cpp:700-753 — a handful, written by lane 0
     int n_global = 0;
     if (lane == 0) {
       int pos = 0;
+      auto put = [&](int f, uint32_t v) {
+        if (pos < T) s_row[pos] = 0xFEu | ((uint32_t)(f & 0xFF) << 8) | ((v & 0xFF) << 16);
+        pos++;
+      };
+      const uint32_t info = s_aginfo[a];
       if (d.flags & MGX_G_COMPLETION) {
-        uint8_t pct = 0;
-        if (d.max_steps > 0) pct = step >= (uint32_t)d.max_steps ? 255 : (uint8_t)(256u * step / (uint32_t)d.max_steps);
-        w.put(pos++, 0xFE, (uint8_t)d.feat[MGX_F_COMPLETION], pct);
+        uint32_t pct = 0;
+        if (d.max_steps > 0) pct = step >= (uint32_t)d.max_steps ? 255u : (256u * step / (uint32_t)d.max_steps);
+        put(d.feat[MGX_F_COMPLETION], pct);
       }
-      if (d.flags & MGX_G_LAST_ACTION) w.put(pos++, 0xFE, (uint8_t)d.feat[MGX_F_LAST_ACTION], (uint8_t)d.executed[e.ao(a)]);
+      if (d.flags & MGX_G_LAST_ACTION) put(d.feat[MGX_F_LAST_ACTION], info & 0xFF);
       if ((d.flags & MGX_G_LAST_ACTION_MOVE) && d.feat[MGX_F_LAST_ACTION_MOVE] != 0)
-        w.put(pos++, 0xFE, (uint8_t)d.feat[MGX_F_LAST_ACTION_MOVE], rc != d.ag_stepprev[e.ao(a)] ? 1 : 0);
+        put(d.feat[MGX_F_LAST_ACTION_MOVE], (info >> 8) & 1);
       // last_reward: the reference reads the reward buffer it zeroed at the top of the step (:937-938,722-726),
       // so the token is always round(0 * 100) = 0.
-      if (d.flags & MGX_G_LAST_REWARD) w.put(pos++, 0xFE, (uint8_t)d.feat[MGX_F_LAST_REWARD], 0);
+      if (d.flags & MGX_G_LAST_REWARD) put(d.feat[MGX_F_LAST_REWARD], 0);
       if (d.flags & MGX_G_LOCAL_POSITION) {
-        uint16_t sp = d.ag_spawn[e.ao(a)];
+        uint16_t sp = s_spawn[a];
         int dc = c0 - (int)(sp & 0xFF), dr = (int)(sp >> 8) - r0;
-        if (dc > 0) w.put(pos++, 0xFE, (uint8_t)d.feat[MGX_F_LP_EAST], (uint8_t)min(dc, 255));
-        else if (dc < 0) w.put(pos++, 0xFE, (uint8_t)d.feat[MGX_F_LP_WEST], (uint8_t)min(-dc, 255));
-        if (dr > 0) w.put(pos++, 0xFE, (uint8_t)d.feat[MGX_F_LP_NORTH], (uint8_t)min(dr, 255));
-        else if (dr < 0) w.put(pos++, 0xFE, (uint8_t)d.feat[MGX_F_LP_SOUTH], (uint8_t)min(-dr, 255));
+        if (dc > 0) put(d.feat[MGX_F_LP_EAST], (uint32_t)min(dc, 255));
+        else if (dc < 0) put(d.feat[MGX_F_LP_WEST], (uint32_t)min(-dc, 255));
+        if (dr > 0) put(d.feat[MGX_F_LP_NORTH], (uint32_t)min(dr, 255));
+        else if (dr < 0) put(d.feat[MGX_F_LP_SOUTH], (uint32_t)min(-dr, 255));
       }
       for (int i = 0; i < d.n_obs_values; i++) {  // _emit_obs_value_tokens :1207-1238
         const int32_t* V = d.P + d.sec[MGX_SEC_OBS_VALUES] + i * MGX_OV_WORDS;
         float raw = e.eval_code(V[MGX_OV_GV_START], V[MGX_OV_GV_COUNT], my_slot);
         uint32_t rem = (uint32_t)raw;
         int f = V[MGX_OV_FEATURE];
-        w.put(pos++, 0xFE, (uint8_t)f, (uint8_t)(rem % (uint32_t)d.base));
+        put(f, rem % (uint32_t)d.base);
         rem /= (uint32_t)d.base;
         f++;
-        while (rem > 0) { w.put(pos++, 0xFE, (uint8_t)f, (uint8_t)(rem % (uint32_t)d.base)); rem /= (uint32_t)d.base; f++; }
+        while (rem > 0) { put(f, rem % (uint32_t)d.base); rem /= (uint32_t)d.base; f++; }
       }
       n_global = pos;
     }
     int base_pos = __shfl(n_global, 0);
 
-    // window cells in reference order; 64 cells per pass; everything below reads LDS only
-    float visited_acc = 0.f;
+    // window cells in reference order: lane handles cells j and j + 64 of each 128-cell pass; everything is LDS
+    float visited_acc = s_vstat[a];
     bool visited_any = false;
-    const int sid_visited = mgx_wk(d, MGX_S_CELL_VISITED);
-    if (step > 0) visited_acc = e.astat_get(a, sid_visited);
-    for (int j0 = 0; j0 < NOFF; j0 += MGX_WAVE) {
-      const int j = j0 + lane;
-      int n = 0, start = 0;
-      uint8_t loc = 0;
-      float stale = 0.f;
-      bool first = false;
-      if (j < NOFF) {
-        char2 o = s_offs[j];
-        int r = r0 + o.x, c = c0 + o.y;
-        if (r >= 0 && c >= 0 && r < d.H && c < d.W) {
-          int slot = (int)s_grid[r * d.W + c] - 1;
-          if (slot >= 0) {
-            loc = (uint8_t)(((o.x + hr) << 4) | (o.y + wr));
-            uint32_t info = s_tokinfo[slot];
-            start = info & 0xFFFF;
-            n = info >> 16;
-            if (step > 0 && s_minobs[slot] == (uint32_t)a) {
-              uint32_t pv = s_visited[slot];
-              if (pv < step) { first = true; stale = (float)(step - pv); }
+    for (int p = 0; p < NPASS; p++) {
+      int n[2] = {0, 0}, start[2] = {0, 0};
+      uint32_t loc[2] = {0, 0};
+      float stale[2] = {0.f, 0.f};
+      bool first[2] = {false, false};
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const int j = p * 2 * MGX_WAVE + h * MGX_WAVE + lane;
+        if (j < NOFF) {
+          char2 o = s_offs[j];
+          int r = r0 + o.x, c = c0 + o.y;
+          if ((unsigned)r < (unsigned)d.H && (unsigned)c < (unsigned)d.W) {
+            int slot = (int)s_grid[r * d.W + c] - 1;
+            if (slot >= 0) {
+              loc[h] = (uint32_t)(((o.x + hr) << 4) | (o.y + wr));
+              uint32_t info = s_tokinfo[slot];
+              start[h] = info & 0xFFFF;
+              n[h] = info >> 16;
+              if (step > 0 && s_minobs[slot] == (uint32_t)a) {
+                uint32_t pv = s_visited[slot];
+                if (pv < step) { first[h] = true; stale[h] = (float)(step - pv); }
+              }
             }
           }
         }
       }
-      int total;
-      int pos = base_pos + mgx_wave_excl_scan(n, lane, &total);
-      for (int k = 0; k < n; k++) {
-        uint16_t t = s_pool[start + k];
-        w.put(pos + k, loc, (uint8_t)(t & 0xFF), (uint8_t)(t >> 8));
-      }
-      base_pos += total;
+      // one packed scan gives both halves' prefix sums (counts stay far below 65 536)
+      const int packed = n[0] | (n[1] << 16);
+      const int incl = mgx_wave_incl_scan(packed);
+      const int tot = __shfl(incl, MGX_WAVE - 1);
+      const int excl = incl - packed;
+      int pos0 = base_pos + (excl & 0xFFFF);
+      int pos1 = base_pos + (tot & 0xFFFF) + (excl >> 16);
+      for (int k = 0; k < n[0]; k++)
+        if (pos0 + k < T) s_row[pos0 + k] = loc[0] | ((uint32_t)s_pool[start[0] + k] << 8);
+      for (int k = 0; k < n[1]; k++)
+        if (pos1 + k < T) s_row[pos1 + k] = loc[1] | ((uint32_t)s_pool[start[1] + k] << 8);
+      base_pos += (tot & 0xFFFF) + (tot >> 16);
       // cell.visited staleness, added in cell order exactly like the serial reference loop (:789-796)
-      unsigned long long m = __ballot(first);
-      while (m) {
-        int l = __ffsll((long long)m) - 1;
-        m &= m - 1;
-        visited_acc = __fadd_rn(visited_acc, __shfl(stale, l));
-        visited_any = true;
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        unsigned long long m = __ballot(first[h]);
+        while (m) {
+          int l = __ffsll((long long)m) - 1;
+          m &= m - 1;
+          visited_acc = __fadd_rn(visited_acc, __shfl(stale[h], l));
+          visited_any = true;
+        }
       }
     }
     if (lane == 0) {
       if (visited_any) e.astat_set(a, sid_visited, visited_acc);
       s_written[a] = base_pos;
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // LDS staging row complete before it is read back
-    // ---- store the row with the widest access the row pitch allows ----
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // LDS row complete before it is read back
+    // ---- pack 4 tokens (4 x u32, low 3 bytes valid) into 12 bytes and store them: one coalesced pass per row ----
     uint8_t* out = d.obs + ((size_t)env * A + a) * (size_t)T * 3;
-    const int nbytes = 3 * T;
-    if ((nbytes & 15) == 0) {
-      for (int i = lane; i < nbytes / 16; i += MGX_WAVE) ((uint4*)out)[i] = ((const uint4*)s_stage)[i];
-    } else if ((nbytes & 7) == 0) {
-      for (int i = lane; i < nbytes / 8; i += MGX_WAVE) ((uint2*)out)[i] = ((const uint2*)s_stage)[i];
-    } else if ((nbytes & 3) == 0) {
-      for (int i = lane; i < nbytes / 4; i += MGX_WAVE) ((uint32_t*)out)[i] = ((const uint32_t*)s_stage)[i];
-    } else {
-      for (int i = lane; i < nbytes; i += MGX_WAVE) out[i] = s_stage[i];
+    for (int q = lane; q * 4 < T; q += MGX_WAVE) {
+      uint4 t = ((const uint4*)s_row)[q];
+      uint32_t w0 = (t.x & 0xFFFFFFu) | (t.y << 24);
+      uint32_t w1 = ((t.y >> 8) & 0xFFFFu) | (t.z << 16);
+      uint32_t w2 = ((t.z >> 16) & 0xFFu) | (t.w << 8);
+      if (q * 4 + 4 <= T && ((3 * T) & 3) == 0) {
+        uint32_t* o32 = (uint32_t*)(out + q * 12);
+        o32[0] = w0; o32[1] = w1; o32[2] = w2;
+      } else {  // ragged tail or unaligned row pitch
+        uint32_t w[3] = {w0, w1, w2};
+        for (int b = 0; b < 12 && q * 12 + b < 3 * T; b++) out[q * 12 + b] = (uint8_t)(w[b >> 2] >> (8 * (b & 3)));
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
   }
