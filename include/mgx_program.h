@@ -5,7 +5,7 @@
  * (/root/reference/cpp/include/mettagrid/config/mettagrid_config.hpp:45-77, built by
  * /root/reference/python/src/mettagrid/config/mettagrid_c_config.py:576-1007).  A GPU cannot chase that tree, so
  * the host compiles the same information ONCE into a single int32 blob: a fixed header, a section table and flat
- * record arrays (classes, limit groups, handler tree, short-circuit filter code, mutation lists, game-value
+ * record arrays, every section starting on a 16-byte boundary (classes, limit groups, handler tree, short-circuit filter code, mutation lists, game-value
  * postfix code, observation tables, stat ids).  Floats are stored bit-cast into int32 words.  Strings never reach
  * the device; the host keeps the name<->id tables (mettagrid_amd/compiler.py).
  *
@@ -18,7 +18,7 @@
 #include <stdint.h>
 
 #define MGX_MAGIC 0x3158474d /* "MGX1" little-endian */
-#define MGX_VERSION 3
+#define MGX_VERSION 4
 
 #define MGX_MAX_RESOURCES 13 /* inventory order list = 4-bit ids in one u64, 0xF terminator; see DESIGN.md */
 #define MGX_TAG_WORDS 8      /* 256 tags = 8 x u32 (reference kMaxTags, core/types.hpp:62) */
@@ -123,11 +123,12 @@ enum { MGX_II_ITEM = 0, MGX_II_AMOUNT, MGX_II_WORDS };
 
 /* Handler tree (handler/handler.cpp:76-93, multi_handler.cpp:8-21). */
 enum { MGX_HD_KIND = 0, MGX_HD_FILTER_PC, /* first atom or MGX_PC_PASS */ MGX_HD_MUT_START, MGX_HD_MUT_COUNT,
-       MGX_HD_CHILD_START, MGX_HD_CHILD_COUNT, MGX_HD_WORDS };
+       MGX_HD_CHILD_START, MGX_HD_CHILD_COUNT, MGX_HD_PAD0, MGX_HD_PAD1, MGX_HD_WORDS /* 8: two 16-byte loads */ };
 enum { MGX_HK_LEAF = 0, MGX_HK_FIRST_MATCH = 1, MGX_HK_ALL = 2 };
 
 /* Filter atoms: linear short-circuit code; every atom carries the pc to continue at when it is true / false. */
-enum { MGX_AT_OP = 0, MGX_AT_A0, MGX_AT_A1, MGX_AT_A2, MGX_AT_ON_TRUE, MGX_AT_ON_FALSE, MGX_AT_WORDS };
+enum { MGX_AT_OP = 0, MGX_AT_A0, MGX_AT_A1, MGX_AT_A2, MGX_AT_ON_TRUE, MGX_AT_ON_FALSE, MGX_AT_PAD0, MGX_AT_PAD1,
+       MGX_AT_WORDS /* 8 */ };
 #define MGX_PC_PASS (-1)
 #define MGX_PC_FAIL (-2)
 enum {
@@ -145,7 +146,7 @@ enum {
 enum { MGX_ENT_ACTOR = 0, MGX_ENT_TARGET = 1 };
 
 /* Mutations (handler/mutations/). */
-enum { MGX_MU_OP = 0, MGX_MU_A0, MGX_MU_A1, MGX_MU_A2, MGX_MU_A3, MGX_MU_A4, MGX_MU_WORDS };
+enum { MGX_MU_OP = 0, MGX_MU_A0, MGX_MU_A1, MGX_MU_A2, MGX_MU_A3, MGX_MU_A4, MGX_MU_PAD0, MGX_MU_PAD1, MGX_MU_WORDS /* 8 */ };
 enum {
   MGX_MOP_RESOURCE_DELTA = 0, /* a0 entity, a1 resource, a2 delta              resource_mutation.hpp:21-50 */
   MGX_MOP_RESOURCE_TRANSFER,  /* a0 src, a1 dst, a2 resource, a3 amount(-1 all), a4 remove_when_empty  :52-103 */

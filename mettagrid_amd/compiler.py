@@ -294,7 +294,7 @@ class _Compiler:
 
     # ---- filters -> short-circuit atoms ----------------------------------------------------------------------
     def _atom(self, op: int, a0: int, a1: int, a2: int, on_true, on_false) -> None:
-        idx = self.emit(K.SEC_ATOMS, [op, a0, a1, a2, 0, 0])
+        idx = self.emit(K.SEC_ATOMS, [op, a0, a1, a2, 0, 0, 0, 0])
         base = idx * K.AT_WORDS
         self.atom_labels.append((base + K.AT_ON_TRUE, on_true))
         self.atom_labels.append((base + K.AT_ON_FALSE, on_false))
@@ -394,8 +394,8 @@ class _Compiler:
             muts = [self.mutation(m) for m in h.mutations]
             mstart = self.counts[K.SEC_MUTS]
             for rec in muts:
-                self.emit(K.SEC_MUTS, rec)
-            return self.emit(K.SEC_HANDLERS, [K.HK_LEAF, fpc, mstart, len(muts), 0, 0])
+                self.emit(K.SEC_MUTS, rec + [0, 0])
+            return self.emit(K.SEC_HANDLERS, [K.HK_LEAF, fpc, mstart, len(muts), 0, 0, 0, 0])
         if isinstance(h, (S.FirstMatch, S.AllOf)):
             kids = [k for k in (self.handler(c) for c in h.handlers) if k >= 0]
             if not kids:
@@ -404,7 +404,7 @@ class _Compiler:
             for k in kids:
                 self.emit(K.SEC_CHILDREN, [k])
             kind = K.HK_FIRST_MATCH if isinstance(h, S.FirstMatch) else K.HK_ALL
-            return self.emit(K.SEC_HANDLERS, [kind, K.PC_PASS, 0, 0, cstart, len(kids)])
+            return self.emit(K.SEC_HANDLERS, [kind, K.PC_PASS, 0, 0, cstart, len(kids), 0, 0])
         raise TypeError(f"Expected Handler, FirstMatch, or AllOf, got {type(h)}")
 
     # ---- inventory configs -----------------------------------------------------------------------------------
@@ -716,6 +716,8 @@ class _Compiler:
             assert atoms[word_idx] is not None
         off = K.H_WORDS
         for s in range(K.SEC_COUNT):
+            while len(self.sections[s]) % 4:      # every section starts 16-byte aligned (vector loads of records)
+                self.sections[s].append(0)
             h[K.H_SECTION_BASE + 2 * s] = off
             h[K.H_SECTION_BASE + 2 * s + 1] = self.counts[s]
             off += len(self.sections[s])

@@ -27,7 +27,7 @@ struct MgxDev {
   int SEENW;              // words of the per-agent visited-cell bitmap
   int NOFF;               // observation offsets
   int base;               // token_value_base
-  int max_steps, truncates, max_priority, nact, flags, hp_res, n_obs_values, n_move_handlers;
+  int max_steps, truncates, max_priority, nact, flags, hp_res, n_obs_values, n_move_handlers, any_on_tick;
   int feat[16];
   int wk[32];             // well-known stat ids (MGX_S_*)
 
@@ -49,6 +49,7 @@ struct MgxDev {
   uint16_t* ag_prev;      // [E][A] Agent::prev_location
   uint16_t* ag_spawn;     // [E][A]
   uint16_t* ag_stepprev;  // [E][A] MettaGrid::_prev_agent_locations
+  uint16_t* ag_covrc;     // [E][A] position at the last coverage update (0xFFFF = never)
   uint32_t* ag_swm;       // [E][A] steps_without_motion
   uint32_t* ag_maxdist;   // [E][A]
   uint32_t* ag_unique;    // [E][A]
@@ -86,11 +87,11 @@ __device__ __forceinline__ int mgx_wk(const MgxDev& d, int s) { return d.wk[s]; 
 // 2 139 095 039 positive finite floats.  Double arithmetic with contraction disabled.
 __device__ __noinline__ float mgx_logf(float x) {
 #pragma clang fp contract(off)
-  const double INVC[16] = {0x1.661ec79f8f3bep+0, 0x1.571ed4aaf883dp+0, 0x1.49539f0f010bp+0,  0x1.3c995b0b80385p+0,
+  static const double INVC[16] = {0x1.661ec79f8f3bep+0, 0x1.571ed4aaf883dp+0, 0x1.49539f0f010bp+0,  0x1.3c995b0b80385p+0,
                            0x1.30d190c8864a5p+0, 0x1.25e227b0b8eap+0,  0x1.1bb4a4a1a343fp+0, 0x1.12358f08ae5bap+0,
                            0x1.0953f419900a7p+0, 0x1p+0,               0x1.e608cfd9a47acp-1, 0x1.ca4b31f026aap-1,
                            0x1.b2036576afce6p-1, 0x1.9c2d163a1aa2dp-1, 0x1.886e6037841edp-1, 0x1.767dcf5534862p-1};
-  const double LOGC[16] = {-0x1.57bf7808caadep-2, -0x1.2bef0a7c06ddbp-2, -0x1.01eae7f513a67p-2, -0x1.b31d8a68224e9p-3,
+  static const double LOGC[16] = {-0x1.57bf7808caadep-2, -0x1.2bef0a7c06ddbp-2, -0x1.01eae7f513a67p-2, -0x1.b31d8a68224e9p-3,
                            -0x1.6574f0ac07758p-3, -0x1.1aa2bc79c81p-3,   -0x1.a4e76ce8c0e5ep-4, -0x1.1973c5a611cccp-4,
                            -0x1.252f438e10c1ep-5, 0x0p+0,                0x1.aa5aa5df25984p-5,  0x1.c5e53aa362eb4p-4,
                            0x1.526e57720db08p-3,  0x1.bc2860d22477p-3,   0x1.1058bc8a07ee1p-2,  0x1.4043057b6ee09p-2};

@@ -43,6 +43,7 @@ struct mgx_engine {
   bool external = false;
   size_t lds_world = 0, lds_obs = 0;
   int pool_tokens = 0;
+  bool prog_in_lds = false;
   bool profiling = false;
   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
   float last_ms[2] = {0.f, 0.f};
@@ -135,6 +136,9 @@ int mgx_create(const int32_t* program, size_t program_words, const uint16_t* cla
   for (int c = 0; c < P[MGX_H_NUM_CLASSES]; c++)
     nrw = std::max(nrw, (int)P[d.sec[MGX_SEC_CLASSES] + c * MGX_C_WORDS + MGX_C_REWARD_COUNT]);
   d.NRW = nrw;
+  d.any_on_tick = 0;
+  for (int c = 0; c < P[MGX_H_NUM_CLASSES]; c++)
+    if (P[d.sec[MGX_SEC_CLASSES] + c * MGX_C_WORDS + MGX_C_ON_TICK] >= 0) d.any_on_tick = 1;
 
   const size_t E = d.E, HW = (size_t)d.H * d.W, S = d.S, A = d.A, rows = E * A;
   int rc = MGX_OK;
@@ -156,6 +160,7 @@ int mgx_create(const int32_t* program, size_t program_words, const uint16_t* cla
   A_(e->alloc(&d.ag_prev, rows));
   A_(e->alloc(&d.ag_spawn, rows));
   A_(e->alloc(&d.ag_stepprev, rows));
+  A_(e->alloc(&d.ag_covrc, rows, 0xFF));
   A_(e->alloc(&d.ag_swm, rows));
   A_(e->alloc(&d.ag_maxdist, rows));
   A_(e->alloc(&d.ag_unique, rows));
@@ -186,7 +191,9 @@ int mgx_create(const int32_t* program, size_t program_words, const uint16_t* cla
   d.obs = e->own_obs; d.terminals = e->own_term; d.truncations = e->own_trunc; d.rewards = e->own_rew;
   d.actions = e->own_act; d.vibe_actions = e->own_vact;
 
-  e->lds_world = (size_t)d.A * MGX_WAVE;
+  e->lds_world = (size_t)((d.A * MGX_WAVE + 15) & ~15);
+  e->prog_in_lds = program_words * 4 + e->lds_world <= 36 * 1024;  // 4 workgroups per CU keep their copy resident
+  if (e->prog_in_lds) e->lds_world += program_words * 4;
   {  // LDS token pool: every object of an env caches its (feature, value) list once per step.  Upper bound per
      // object from the program: tags + vibe + R * digits + 2; capped so that several workgroups fit one CU.
     int digits = 1;
@@ -308,8 +315,15 @@ int mgx_step(mgx_engine* e) {
     HIP_TRY(hipMemcpyAsync(e->own_act, e->h_act, rows * 4, hipMemcpyHostToDevice, e->stream));
     HIP_TRY(hipMemcpyAsync(e->own_vact, e->h_vact, rows * 4, hipMemcpyHostToDevice, e->stream));
   }
+  HIP_TRY(hipMemsetAsync(d.executed, 0, rows * 4, e->stream));  // executed_actions / _action_success cleared (:944,962-964)
+  HIP_TRY(hipMemsetAsync(d.success, 0, rows, e->stream));
   if (e->profiling) HIP_TRY(hipEventRecord(e->ev[0], e->stream));
-  hipLaunchKernelGGL(mgx_world_kernel, dim3((d.E + MGX_WAVE - 1) / MGX_WAVE), dim3(MGX_WAVE), e->lds_world, e->stream, e->d);
+  {
+    dim3 grid((d.E + MGX_WAVE - 1) / MGX_WAVE), block(MGX_WAVE);
+    int pw = (int)e->prog.size();
+    if (e->prog_in_lds) hipLaunchKernelGGL(mgx_world_kernel<true>, grid, block, e->lds_world, e->stream, e->d, pw);
+    else hipLaunchKernelGGL(mgx_world_kernel<false>, grid, block, e->lds_world, e->stream, e->d, pw);
+  }
   HIP_TRY(hipGetLastError());
   if (e->profiling) HIP_TRY(hipEventRecord(e->ev[1], e->stream));
   int rc = launch_obs(e, true);
@@ -381,9 +395,10 @@ int mgx_get_stats(mgx_engine* e, int32_t env, float* game_values, uint8_t* game_
   if (rc) return rc;
   rc = d2h(e, at.data(), d.ag_touched + (size_t)env * d.A * d.NSW, (size_t)d.A * d.NSW * 4);
   if (rc) return rc;
-  for (int i = 0; i < d.NG; i++) game_touched[i] = (gt[i >> 5] >> (i & 31)) & 1u;
+  for (int i = 0; i < d.NG; i++) game_touched[i] = ((gt[i >> 5] >> (i & 31)) & 1u) | (game_values[i] != 0.f);
   for (int a = 0; a < d.A; a++)
-    for (int i = 0; i < d.NS; i++) agent_touched[(size_t)a * d.NS + i] = (at[(size_t)a * d.NSW + (i >> 5)] >> (i & 31)) & 1u;
+    for (int i = 0; i < d.NS; i++) agent_touched[(size_t)a * d.NS + i] =
+          ((at[(size_t)a * d.NSW + (i >> 5)] >> (i & 31)) & 1u) | (agent_values[(size_t)a * d.NS + i] != 0.f);
   return MGX_OK;
 }
 

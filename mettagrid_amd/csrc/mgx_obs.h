@@ -139,7 +139,7 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
   uint16_t* s_pool = (uint16_t*)(smem + L.pool);
   uint32_t* s_row = (uint32_t*)(smem + L.rows) + wave * L.row_words;  // one u32 per token: loc | f << 8 | v << 16
 
-  MgxEnv e(d, env);
+  MgxEnv e(d, d.P, env);
   e.step = d.step[env];
   const uint32_t step = e.step;
   const int sid_visited = mgx_wk(d, MGX_S_CELL_VISITED);

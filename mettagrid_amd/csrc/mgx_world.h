@@ -18,16 +18,24 @@ struct MgxCtx {  // handler/handler_context.hpp:38-112 (the fields the supported
   bool mutation_failed;
 };
 
-struct MgxEnv {  // per-lane view of one env
+// Program pointer types: the world kernel keeps the whole program in LDS when it fits (address space 3 pointer ->
+// ds_read, no vector-memory traffic for table lookups); everything else reads it from global memory.
+typedef const int32_t* MgxGlobalProg;
+typedef const __attribute__((address_space(3))) int32_t* MgxLdsProg;
+
+template <class PP>
+struct MgxEnvT {  // per-lane view of one env
   const MgxDev& d;
+  PP P;
   int env;
   uint32_t step;
-  __device__ MgxEnv(const MgxDev& dd, int e) : d(dd), env(e), step(0) {}
+  __device__ MgxEnvT(const MgxDev& dd, PP prog, int e) : d(dd), P(prog), env(e), step(0) {}
+  __device__ __forceinline__ PP cls(int c) const { return P + d.sec[MGX_SEC_CLASSES] + c * MGX_C_WORDS; }
 
   __device__ __forceinline__ size_t so(int slot) const { return (size_t)env * d.S + slot; }
   __device__ __forceinline__ size_t ao(int agent) const { return (size_t)env * d.A + agent; }
   __device__ __forceinline__ uint16_t& inv(int slot, int item) const { return d.obj_inv[so(slot) * d.R + item]; }
-  __device__ __forceinline__ const int32_t* cls_of(int slot) const { return mgx_cls(d, d.obj_cls[so(slot)]); }
+  __device__ __forceinline__ PP cls_of(int slot) const { return cls(d.obj_cls[so(slot)]); }
   __device__ __forceinline__ int agent_of(int slot) const {
     if (slot < 0) return -1;
     int a = d.obj_agent[so(slot)];
@@ -37,10 +45,11 @@ struct MgxEnv {  // per-lane view of one env
 
   // ---- stats (systems/stats_tracker.hpp:69-90) ----
   __device__ void astat_touch(int agent, int id) const { d.ag_touched[ao(agent) * d.NSW + (id >> 5)] |= 1u << (id & 31); }
+  // add(): every caller adds a strictly positive amount to a key that only ever grows, so "value != 0" already
+  // says the key exists; the host ORs that into the touched flags (mgx_get_stats) and the bit RMW is skipped here.
   __device__ void astat_add(int agent, int id, float v) const {
     if (id < 0) return;
     d.ag_stats[ao(agent) * d.NS + id] += v;
-    astat_touch(agent, id);
   }
   __device__ void astat_set(int agent, int id, float v) const {
     if (id < 0) return;
@@ -61,15 +70,15 @@ struct MgxEnv {  // per-lane view of one env
   }
 
   // ---- inventory (cpp/src/mettagrid/objects/inventory.cpp) ----
-  __device__ int effective_limit(int slot, const int32_t* L) const {  // objects/inventory.hpp:26-40
+  __device__ int effective_limit(int slot, PP L) const {  // objects/inventory.hpp:26-40
     int sum = 0;
-    const int32_t* mods = d.P + d.sec[MGX_SEC_MODS] + L[MGX_L_MOD_START] * MGX_MOD_WORDS;
+    PP mods = P + d.sec[MGX_SEC_MODS] + L[MGX_L_MOD_START] * MGX_MOD_WORDS;
     for (int i = 0; i < L[MGX_L_MOD_COUNT]; i++)
       sum += (int)inv(slot, mods[i * MGX_MOD_WORDS + MGX_MOD_ITEM]) * mods[i * MGX_MOD_WORDS + MGX_MOD_BONUS];
     int eff = min(L[MGX_L_MAX], max(L[MGX_L_MIN], sum));
     return min(max(eff, 0), 65535);
   }
-  __device__ int group_amount(int slot, const int32_t* L) const {
+  __device__ int group_amount(int slot, PP L) const {
     int s = 0;
     uint32_t mask = (uint32_t)L[MGX_L_RES_MASK];
     while (mask) {
@@ -79,9 +88,9 @@ struct MgxEnv {  // per-lane view of one env
     }
     return s;
   }
-  __device__ const int32_t* limit_of(const int32_t* C, int item) const {
+  __device__ PP limit_of(PP C, int item) const {
     int li = C[MGX_C_RES_LIMIT + item];
-    return li < 0 ? nullptr : d.P + d.sec[MGX_SEC_LIMITS] + li * MGX_L_WORDS;
+    return li < 0 ? (PP)nullptr : P + d.sec[MGX_SEC_LIMITS] + li * MGX_L_WORDS;
   }
   __device__ void on_inventory_change(int slot, int item, int delta, int amount) const {  // objects/agent.cpp:106-121
     int a = agent_of(slot);
@@ -94,12 +103,12 @@ struct MgxEnv {  // per-lane view of one env
   // Inventory::update (inventory.cpp:38-86).  DEPTH bounds the update -> enforce_all_limits -> update recursion.
   template <int DEPTH>
   __device__ int inv_update(int slot, int item, int delta, bool ignore_limits = false, bool notify = true) const {
-    const int32_t* C = cls_of(slot);
+    PP C = cls_of(slot);
     int initial = inv(slot, item);
     int new_amount = initial + delta;
     int mx = 65535;
     if (!ignore_limits) {
-      const int32_t* L = limit_of(C, item);
+      PP L = limit_of(C, item);
       if (L) {
         int used = group_amount(slot, L) - initial;
         if (used < 0) used = 0;
@@ -131,13 +140,13 @@ struct MgxEnv {  // per-lane view of one env
     return dl;
   }
   template <int DEPTH>
-  __device__ void enforce_all_limits(int slot, const int32_t* C) const {  // inventory.cpp:141-173
+  __device__ void enforce_all_limits(int slot, PP C) const {  // inventory.cpp:141-173
     for (int li = 0; li < C[MGX_C_LIMIT_COUNT]; li++) {
-      const int32_t* L = d.P + d.sec[MGX_SEC_LIMITS] + (C[MGX_C_LIMIT_START] + li) * MGX_L_WORDS;
+      PP L = P + d.sec[MGX_SEC_LIMITS] + (C[MGX_C_LIMIT_START] + li) * MGX_L_WORDS;
       if (L[MGX_L_DROP_COUNT] == 0) continue;
       int excess = group_amount(slot, L) - effective_limit(slot, L);
       if (excess <= 0) continue;
-      const int32_t* drop = d.P + d.sec[MGX_SEC_DROP_ORDER] + L[MGX_L_DROP_START];
+      PP drop = P + d.sec[MGX_SEC_DROP_ORDER] + L[MGX_L_DROP_START];
       for (int k = 0; k < L[MGX_L_DROP_COUNT]; k++) {
         int item = drop[k];
         int to_drop = min((int)inv(slot, item), excess);
@@ -150,7 +159,7 @@ struct MgxEnv {  // per-lane view of one env
     }
   }
   __device__ int free_space(int slot, int item) const {  // inventory.cpp:97-110
-    const int32_t* L = limit_of(cls_of(slot), item);
+    PP L = limit_of(cls_of(slot), item);
     if (!L) return 65535 - inv(slot, item);
     int used = group_amount(slot, L), eff = effective_limit(slot, L);
     return eff > used ? eff - used : 0;
@@ -168,7 +177,7 @@ struct MgxEnv {  // per-lane view of one env
   __device__ float eval_code(int start, int count, int entity) const {
     float st[8];
     int sp = 0;
-    const int32_t* code = d.P + d.sec[MGX_SEC_GV_CODE] + start * MGX_GV_WORDS;
+    PP code = P + d.sec[MGX_SEC_GV_CODE] + start * MGX_GV_WORDS;
     for (int i = 0; i < count; i++, code += MGX_GV_WORDS) {
       int a0 = code[MGX_GV_A0], a1 = code[MGX_GV_A1], a2 = code[MGX_GV_A2];
       switch (code[MGX_GV_OP]) {
@@ -197,21 +206,21 @@ struct MgxEnv {  // per-lane view of one env
     return sp > 0 ? st[(sp - 1) & 7] : 0.f;
   }
   __device__ float eval_value(int rec, int entity) const {
-    const int32_t* V = d.P + d.sec[MGX_SEC_OBS_VALUES] + rec * MGX_OV_WORDS;
+    PP V = P + d.sec[MGX_SEC_OBS_VALUES] + rec * MGX_OV_WORDS;
     return eval_code(V[MGX_OV_GV_START], V[MGX_OV_GV_COUNT], entity);
   }
 
   // ---- filters (handler/filters/*.hpp) as short-circuit code ----
   __device__ __forceinline__ int resolve(const MgxCtx& c, int ent) const { return ent == MGX_ENT_ACTOR ? c.actor : c.target; }
-  __device__ bool atom(const int32_t* a, const MgxCtx& c) const {
+  __device__ bool atom(PP a, const MgxCtx& c) const {
     int a0 = a[MGX_AT_A0], a1 = a[MGX_AT_A1], a2 = a[MGX_AT_A2];
     switch (a[MGX_AT_OP]) {
       case MGX_FOP_VIBE: { int e = resolve(c, a0); return e >= 0 && d.obj_vibe[so(e)] == a1; }
       case MGX_FOP_RESOURCE: { int e = resolve(c, a0); return e >= 0 && (int)inv(e, a1) >= a2; }
       case MGX_FOP_SHARED_TAG: {
         if (c.actor < 0 || c.target < 0) return false;
-        const int32_t* mask = d.P + d.sec[MGX_SEC_WORDLIST] + a0;
-        const int32_t *x = cls_of(c.actor) + MGX_C_TAGS, *y = cls_of(c.target) + MGX_C_TAGS;
+        PP mask = P + d.sec[MGX_SEC_WORDLIST] + a0;
+        PP x = cls_of(c.actor) + MGX_C_TAGS; PP y = cls_of(c.target) + MGX_C_TAGS;
         uint32_t any = 0;
         for (int w = 0; w < MGX_TAG_WORDS; w++) any |= (uint32_t)x[w] & (uint32_t)y[w] & (uint32_t)mask[w];
         return any != 0;
@@ -219,8 +228,8 @@ struct MgxEnv {  // per-lane view of one env
       case MGX_FOP_TAG: {
         int e = resolve(c, a0);
         if (e < 0) return false;
-        const int32_t* mask = d.P + d.sec[MGX_SEC_WORDLIST] + a1;
-        const int32_t* x = cls_of(e) + MGX_C_TAGS;
+        PP mask = P + d.sec[MGX_SEC_WORDLIST] + a1;
+        PP x = cls_of(e) + MGX_C_TAGS;
         uint32_t any = 0;
         for (int w = 0; w < MGX_TAG_WORDS; w++) any |= (uint32_t)x[w] & (uint32_t)mask[w];
         return any != 0;
@@ -239,9 +248,9 @@ struct MgxEnv {  // per-lane view of one env
     }
   }
   __device__ bool check_filters(int pc, const MgxCtx& c) const {  // handler/handler.cpp:95-103
-    const int32_t* atoms = d.P + d.sec[MGX_SEC_ATOMS];
+    PP atoms = P + d.sec[MGX_SEC_ATOMS];
     while (pc >= 0) {
-      const int32_t* a = atoms + pc * MGX_AT_WORDS;
+      PP a = atoms + pc * MGX_AT_WORDS;
       pc = atom(a, c) ? a[MGX_AT_ON_TRUE] : a[MGX_AT_ON_FALSE];
     }
     return pc == MGX_PC_PASS;
@@ -261,7 +270,7 @@ struct MgxEnv {  // per-lane view of one env
 
   // ---- mutations (handler/mutations/*.hpp) ----
   template <int DEPTH>
-  __device__ void mutate(const int32_t* m, MgxCtx& c) const {
+  __device__ void mutate(PP m, MgxCtx& c) const {
     int a0 = m[MGX_MU_A0], a1 = m[MGX_MU_A1], a2 = m[MGX_MU_A2], a3 = m[MGX_MU_A3];
     switch (m[MGX_MU_OP]) {
       case MGX_MOP_RESOURCE_DELTA: { int e = resolve(c, a0); if (e >= 0) inv_update<1>(e, a1, a2); break; }
@@ -285,7 +294,7 @@ struct MgxEnv {  // per-lane view of one env
             inv_update<1>(e, item, -(int)inv(e, item));
           }
         } else {
-          const int32_t* ids = d.P + d.sec[MGX_SEC_WORDLIST] + a1;
+          PP ids = P + d.sec[MGX_SEC_WORDLIST] + a1;
           for (int i = 0; i < a2; i++) inv_update<1>(e, ids[i], -(int)inv(e, ids[i]));
         }
         break;
@@ -338,11 +347,11 @@ struct MgxEnv {  // per-lane view of one env
   // DEPTH bounds nesting (multi -> leaf -> use_target -> on_use multi -> leaf); exceeded depth raises MGX_ENV_DEPTH.
   template <int DEPTH>
   __device__ bool apply_handler(int h, MgxCtx& c) const {
-    const int32_t* hd = d.P + d.sec[MGX_SEC_HANDLERS] + h * MGX_HD_WORDS;
+    PP hd = P + d.sec[MGX_SEC_HANDLERS] + h * MGX_HD_WORDS;
     if (hd[MGX_HD_KIND] == MGX_HK_LEAF) {
       if (!check_filters(hd[MGX_HD_FILTER_PC], c)) return false;
       c.mutation_failed = false;
-      const int32_t* m = d.P + d.sec[MGX_SEC_MUTS] + hd[MGX_HD_MUT_START] * MGX_MU_WORDS;
+      PP m = P + d.sec[MGX_SEC_MUTS] + hd[MGX_HD_MUT_START] * MGX_MU_WORDS;
       for (int i = 0; i < hd[MGX_HD_MUT_COUNT]; i++, m += MGX_MU_WORDS) {
         mutate<DEPTH>(m, c);
         if (c.mutation_failed) return false;
@@ -351,7 +360,7 @@ struct MgxEnv {  // per-lane view of one env
     }
     bool any = false;
     if constexpr (DEPTH > 0) {
-      const int32_t* kids = d.P + d.sec[MGX_SEC_CHILDREN] + hd[MGX_HD_CHILD_START];
+      PP kids = P + d.sec[MGX_SEC_CHILDREN] + hd[MGX_HD_CHILD_START];
       bool first = hd[MGX_HD_KIND] == MGX_HK_FIRST_MATCH;
       for (int i = 0; i < hd[MGX_HD_CHILD_COUNT]; i++) {
         if (apply_handler<DEPTH - 1>(kids[i], c)) {
@@ -369,7 +378,7 @@ struct MgxEnv {  // per-lane view of one env
   __device__ bool do_move(int slot, int orient) const {  // actions/move.hpp:81-115, orientation.hpp:28-48
     const int dx = (orient == 2 || orient == 4 || orient == 6) ? -1 : (orient == 3 || orient == 5 || orient == 7) ? 1 : 0;
     const int dy = (orient == 0 || orient == 4 || orient == 5) ? -1 : (orient == 1 || orient == 6 || orient == 7) ? 1 : 0;
-    const int32_t* mh = d.P + d.sec[MGX_SEC_MOVE_HANDLERS];
+    PP mh = P + d.sec[MGX_SEC_MOVE_HANDLERS];
     for (int k = 0; k < d.n_move_handlers; k++, mh += MGX_MH_WORDS) {
       uint16_t rc = d.obj_rc[so(slot)];
       for (int i = 1; i <= mh[MGX_MH_MAX_RANGE]; i++) {
@@ -380,14 +389,14 @@ struct MgxEnv {  // per-lane view of one env
         MgxCtx ctx;
         ctx.actor = slot; ctx.target = t; ctx.target_r = r; ctx.target_c = c; ctx.move_direction = orient;
         ctx.mutation_failed = false;
-        if (apply_handler<4>(mh[MGX_MH_HANDLER], ctx)) return true;
+        if (apply_handler<3>(mh[MGX_MH_HANDLER], ctx)) return true;
         break;
       }
     }
     return false;
   }
   __device__ bool handle_action(int ai, int action) const {  // actions/action_handler.hpp:78-105
-    const int32_t* ac = d.P + d.sec[MGX_SEC_ACTIONS] + action * MGX_AC_WORDS;
+    PP ac = P + d.sec[MGX_SEC_ACTIONS] + action * MGX_AC_WORDS;
     int kind = ac[MGX_AC_KIND];
     int slot = d.ag_obj[ao(ai)];
     bool ok = true;
@@ -409,7 +418,12 @@ struct MgxEnv {  // per-lane view of one env
   }
 
   __device__ void track_coverage(int ai) const {  // objects/agent.cpp:49-57
-    uint16_t rc = d.obj_rc[so(d.ag_obj[ao(ai)])], sp = d.ag_spawn[ao(ai)];
+    uint16_t rc = d.obj_rc[so(d.ag_obj[ao(ai)])];
+    // Unchanged position since the last call => the set is unchanged and both stats.set() calls would store the
+    // values they already hold (keys exist since Agent::init): nothing to do.
+    if (rc == d.ag_covrc[ao(ai)]) return;
+    d.ag_covrc[ao(ai)] = rc;
+    uint16_t sp = d.ag_spawn[ao(ai)];
     int r = rc >> 8, c = rc & 0xFF;
     int bit = r * d.W + c;
     uint32_t& w = d.ag_seen[ao(ai) * d.SEENW + (bit >> 5)];
@@ -452,6 +466,8 @@ struct MgxEnv {  // per-lane view of one env
   }
 };
 
+typedef MgxEnvT<MgxGlobalProg> MgxEnv;
+
 // order: LDS, [k][lane] bytes (k-major so that a wavefront access is bank-conflict free)
 __device__ __forceinline__ void mgx_swap(uint8_t* order, int lane, int i, int j) {
   uint8_t a = order[i * MGX_WAVE + lane], b = order[j * MGX_WAVE + lane];
@@ -459,19 +475,15 @@ __device__ __forceinline__ void mgx_swap(uint8_t* order, int lane, int i, int j)
   order[j * MGX_WAVE + lane] = a;
 }
 
-__global__ void __launch_bounds__(MGX_WAVE) mgx_world_kernel(MgxDev d) {
-  extern __shared__ uint8_t order[];  // [A][64]
-  const int lane = threadIdx.x;
-  const int env = blockIdx.x * MGX_WAVE + lane;
-  if (env >= d.E) return;
-  MgxEnv e(d, env);
+template <class PP>
+__device__ __forceinline__ void mgx_world_body(const MgxDev& d, PP P, uint8_t* order, int lane, int env) {
+  MgxEnvT<PP> e(d, P, env);
   const int A = d.A;
   e.step = ++d.step[env];
 
-  for (int i = 0; i < A; i++) {  // mettagrid_c.cpp:929-944
-    d.ag_stepprev[e.ao(i)] = d.obj_rc[e.so(d.ag_obj[e.ao(i)])];
-    d.executed[e.ao(i)] = 0;
-    d.success[e.ao(i)] = 0;
+  const bool want_stepprev = (d.flags & MGX_G_LAST_ACTION_MOVE) != 0;
+  for (int i = 0; i < A; i++) {  // mettagrid_c.cpp:929-944 (executed/success are cleared by the host-side memset)
+    if (want_stepprev) d.ag_stepprev[e.ao(i)] = d.obj_rc[e.so(d.ag_obj[e.ao(i)])];
     order[i * MGX_WAVE + lane] = (uint8_t)i;
   }
   // std::shuffle (bits/stl_algo.h:3729-3795): one draw for an even n, then paired draws
@@ -490,43 +502,69 @@ __global__ void __launch_bounds__(MGX_WAVE) mgx_world_kernel(MgxDev d) {
       i += 2;
     }
   }
-  // action dispatch: priority levels high -> low, primary stream then vibe stream (mettagrid_c.cpp:966-999)
-  const int32_t* acts = d.P + d.sec[MGX_SEC_ACTIONS];
-  for (int off = 0; off <= d.max_priority; off++) {
-    const int prio = d.max_priority - off;
-    for (int stream = 0; stream < 2; stream++) {
-      const int32_t* src = stream == 0 ? d.actions : d.vibe_actions;
-      for (int k = 0; k < A; k++) {
-        int ai = order[k * MGX_WAVE + lane];
-        int a = src[e.ao(ai)];
-        if (a < 0 || a >= d.nact) {  // _handle_invalid_action :914-919 (runs once per priority level, as there)
+  // Action dispatch (mettagrid_c.cpp:966-999).  The reference loops over priority levels max..0 and, inside each,
+  // over the primary then the vibe stream.  Every real action handler has priority 0 and the only thing the
+  // higher (empty) levels do is repeat the invalid-index bookkeeping, so one pass per stream with the invalid-index
+  // stats added (max_priority + 1) times is equivalent — the stat keys involved are touched by nothing else.
+  PP acts = P + d.sec[MGX_SEC_ACTIONS];
+  const int repeats = d.max_priority + 1;
+  for (int stream = 0; stream < 2; stream++) {
+    const int32_t* src = stream == 0 ? d.actions : d.vibe_actions;
+    for (int k = 0; k < A; k++) {
+      int ai = order[k * MGX_WAVE + lane];
+      int a = src[e.ao(ai)];
+      if (a < 0 || a >= d.nact) {  // _handle_invalid_action :914-919
+        for (int rep = 0; rep < repeats; rep++) {
           e.astat_add(ai, mgx_wk(d, MGX_S_INVALID_INDEX), 1.f);
           if (a < 0 && a >= -MGX_INVALID_WINDOW) e.astat_add(ai, mgx_wk(d, MGX_S_INVALID_NEG_BASE) + a + MGX_INVALID_WINDOW, 1.f);
           else if (a >= d.nact && a < d.nact + MGX_INVALID_WINDOW) e.astat_add(ai, mgx_wk(d, MGX_S_INVALID_POS_BASE) + a - d.nact, 1.f);
           else e.flag(2u);
-          d.success[e.ao(ai)] = 0;
-          continue;
         }
-        bool is_vibe = acts[a * MGX_AC_WORDS + MGX_AC_KIND] == MGX_AK_VIBE;
-        if (is_vibe != (stream == 1)) continue;
-        if (prio != 0) continue;  // noop / move / change_vibe handlers all have priority 0
-        if (e.handle_action(ai, a)) {
-          d.executed[e.ao(ai)] = a;
-          d.success[e.ao(ai)] = 1;
-        }
+        d.success[e.ao(ai)] = 0;
+        continue;
+      }
+      bool is_vibe = acts[a * MGX_AC_WORDS + MGX_AC_KIND] == MGX_AK_VIBE;
+      if (is_vibe != (stream == 1)) continue;
+      if (e.handle_action(ai, a)) {
+        d.executed[e.ao(ai)] = a;
+        d.success[e.ao(ai)] = 1;
       }
     }
   }
-  for (int i = 0; i < A; i++) {  // per-agent on_tick (mettagrid_c.cpp:1019-1024)
-    int slot = d.ag_obj[e.ao(i)];
-    int h = e.cls_of(slot)[MGX_C_ON_TICK];
-    if (h >= 0) {
-      MgxCtx c;
-      c.actor = c.target = slot; c.target_r = c.target_c = 0; c.move_direction = 0; c.mutation_failed = false;
-      e.apply_handler<4>(h, c);
+  if (d.any_on_tick) {
+    for (int i = 0; i < A; i++) {  // per-agent on_tick (mettagrid_c.cpp:1019-1024)
+      int slot = d.ag_obj[e.ao(i)];
+      int h = e.cls_of(slot)[MGX_C_ON_TICK];
+      if (h >= 0) {
+        MgxCtx c;
+        c.actor = c.target = slot; c.target_r = c.target_c = 0; c.move_direction = 0; c.mutation_failed = false;
+        e.template apply_handler<3>(h, c);
+      }
     }
   }
   for (int i = 0; i < A; i++) e.track_coverage(i);  // mettagrid_c.cpp:1054-1056
+}
+
+// PROG_LDS: the program blob is first copied into LDS (16-byte coalesced loads) and every table lookup of the
+// handler VM becomes a ds_read.  Dynamic LDS: order u8[A][64] | program i32[prog_words].
+template <bool PROG_LDS>
+__global__ void __launch_bounds__(MGX_WAVE) mgx_world_kernel(MgxDev d, int prog_words) {
+  extern __shared__ __align__(16) uint8_t wsmem[];
+  uint8_t* order = wsmem;
+  const int lane = threadIdx.x;
+  const int env = blockIdx.x * MGX_WAVE + lane;
+  if (PROG_LDS) {
+    int32_t* lprog = (int32_t*)(wsmem + ((d.A * MGX_WAVE + 15) & ~15));
+    const int4* src = (const int4*)d.P;
+    int4* dst = (int4*)lprog;
+    for (int i = lane; i < prog_words / 4; i += MGX_WAVE) dst[i] = src[i];
+    __syncthreads();
+    if (env >= d.E) return;
+    mgx_world_body<MgxLdsProg>(d, (MgxLdsProg)lprog, order, lane, env);
+  } else {
+    if (env >= d.E) return;
+    mgx_world_body<MgxGlobalProg>(d, d.P, order, lane, env);
+  }
 }
 
 // Construction: MettaGrid ctor + _init_grid (mettagrid_c.cpp:42-191, 200-269).  One lane per env scans the class
@@ -534,7 +572,7 @@ __global__ void __launch_bounds__(MGX_WAVE) mgx_world_kernel(MgxDev d) {
 __global__ void __launch_bounds__(MGX_WAVE) mgx_init_kernel(MgxDev d, const uint16_t* class_maps, const uint32_t* seeds) {
   const int env = blockIdx.x * MGX_WAVE + threadIdx.x;
   if (env >= d.E) return;
-  MgxEnv e(d, env);
+  MgxEnv e(d, d.P, env);
   const size_t E = (size_t)d.E;
   uint32_t x = seeds[env];  // std::mt19937(seed): bits/random.tcc seed()
   d.mt[env] = x;
@@ -571,6 +609,7 @@ __global__ void __launch_bounds__(MGX_WAVE) mgx_init_kernel(MgxDev d, const uint
       d.ag_prev[e.ao(ai)] = rc;
       d.ag_spawn[e.ao(ai)] = rc;
       d.ag_stepprev[e.ao(ai)] = rc;
+      d.ag_covrc[e.ao(ai)] = 0xFFFF;
     }
     d.obj_agent[e.so(slot)] = ai < 0 ? MGX_NO_AGENT : (uint8_t)ai;
     const int32_t* ii = d.P + d.sec[MGX_SEC_INIT_INV] + C[MGX_C_INIT_INV_START] * MGX_II_WORDS;
