@@ -80,9 +80,10 @@ int mgx_get_stats(mgx_engine* e, int32_t env, float* game_values, uint8_t* game_
 
 /* grid_objects() — mettagrid_py.cpp:28-139.  One record of MGX_OBJ_RECORD_WORDS int32 per object slot of env `env`:
  * [0] id (slot+1)  [1] class  [2] r  [3] c  [4] vibe  [5] alive  [6] agent_id or -1  [7] n inventory items,
- * [8..20] inventory items in the reference's iteration order (-1 padded), [21..33] amount by resource id.
+ * [8..20] inventory items in the reference's iteration order (-1 padded), [21..33] amount by resource id,
+ * [34..41] tag bitset (8 x u32).
  * Returns the number of records written via *n_objects; `out` must hold MAX_OBJECTS records. */
-#define MGX_OBJ_RECORD_WORDS 34
+#define MGX_OBJ_RECORD_WORDS 42
 int mgx_get_objects(mgx_engine* e, int32_t env, int32_t* out, int32_t* n_objects);
 /* current_stat_reward per agent of env `env` (RewardHelper::current_reward, systems/reward.hpp:36-42). f32 [A]. */
 int mgx_get_reward_state(mgx_engine* e, int32_t env, float* out);

@@ -18,7 +18,7 @@
 #include <stdint.h>
 
 #define MGX_MAGIC 0x3158474d /* "MGX1" little-endian */
-#define MGX_VERSION 4
+#define MGX_VERSION 5
 
 #define MGX_MAX_RESOURCES 13 /* inventory order list = 4-bit ids in one u64, 0xF terminator; see DESIGN.md */
 #define MGX_TAG_WORDS 8      /* 256 tags = 8 x u32 (reference kMaxTags, core/types.hpp:62) */
@@ -53,10 +53,18 @@ enum {
   MGX_H_NUM_OBS_OFFSETS,
   MGX_H_NUM_MOVE_HANDLERS,
   MGX_H_NUM_OBS_VALUES,
-  MGX_H_FEAT_BASE = 32, /* MGX_F_* feature ids follow */
-  MGX_H_STAT_BASE = 48, /* MGX_S_* well-known stat ids follow */
-  MGX_H_SECTION_BASE = 96, /* section s: offset at BASE+2s, record count at BASE+2s+1 */
-  MGX_H_WORDS = 160
+  MGX_H_NUM_EVENTS,
+  MGX_H_NUM_SCHEDULE,
+  MGX_H_NUM_MATQ,
+  MGX_H_NUM_TERRITORIES,
+  MGX_H_GAME_ON_TICK,    /* handler index or -1 (GameConfig.on_tick, mettagrid_c.cpp:1050-1052) */
+  MGX_H_DYNAMIC_TAGS,    /* 1: objects carry their own tag bitset (tag mutations / materialized queries / territories) */
+  MGX_H_NUM_INDEXED_TAGS,/* tags that own a TagIndex list (referenced by a TagQuery) */
+  MGX_H_QUERY_DEPTH,     /* max nesting of queries */
+  MGX_H_FEAT_BASE = 40, /* MGX_F_* feature ids follow */
+  MGX_H_STAT_BASE = 56, /* MGX_S_* well-known stat ids follow */
+  MGX_H_SECTION_BASE = 104, /* section s: offset at BASE+2s, record count at BASE+2s+1 */
+  MGX_H_WORDS = 176
 };
 
 enum { /* MGX_H_GLOBAL_FLAGS bits (config/mettagrid_config.hpp:37-45 GlobalObsConfig) */
@@ -90,7 +98,10 @@ enum { /* well-known stat ids, offsets from MGX_H_STAT_BASE; agent scope unless 
 enum {
   MGX_SEC_CLASSES = 0, MGX_SEC_LIMITS, MGX_SEC_MODS, MGX_SEC_DROP_ORDER, MGX_SEC_INIT_INV, MGX_SEC_HANDLERS,
   MGX_SEC_CHILDREN, MGX_SEC_ATOMS, MGX_SEC_MUTS, MGX_SEC_ACTIONS, MGX_SEC_MOVE_HANDLERS, MGX_SEC_OBS_OFFSETS,
-  MGX_SEC_INV_FEATURES, MGX_SEC_GV_CODE, MGX_SEC_REWARDS, MGX_SEC_OBS_VALUES, MGX_SEC_WORDLIST, MGX_SEC_COUNT
+  MGX_SEC_INV_FEATURES, MGX_SEC_GV_CODE, MGX_SEC_REWARDS, MGX_SEC_OBS_VALUES, MGX_SEC_WORDLIST,
+  MGX_SEC_QUERIES, MGX_SEC_EVENTS, MGX_SEC_SCHEDULE, MGX_SEC_MATQ, MGX_SEC_TAG_HANDLERS, MGX_SEC_AOES,
+  MGX_SEC_PRESENCE, MGX_SEC_TERRITORIES, MGX_SEC_TERR_CONTROLS, MGX_SEC_TAG_LISTS /* 256 words: tag -> list idx or -1 */,
+  MGX_SEC_COUNT
 };
 
 /* Object class = one entry of GameConfig.objects (keyed by map cell name; per-agent cells "agent.red.3" are
@@ -111,7 +122,11 @@ enum {
   MGX_C_MODIFIER_MASK,  /* bit r set: resource r is a limit modifier for this class (Inventory::is_modifier) */
   MGX_C_TAGS,           /* MGX_TAG_WORDS words */
   MGX_C_RES_LIMIT = MGX_C_TAGS + MGX_TAG_WORDS, /* MGX_MAX_RESOURCES words: limit index (global) or -1 */
-  MGX_C_WORDS = MGX_C_RES_LIMIT + MGX_MAX_RESOURCES
+  MGX_C_TAG_ADD_START = MGX_C_RES_LIMIT + MGX_MAX_RESOURCES, MGX_C_TAG_ADD_COUNT, /* MGX_SEC_TAG_HANDLERS records */
+  MGX_C_TAG_REMOVE_START, MGX_C_TAG_REMOVE_COUNT,
+  MGX_C_AOE_START, MGX_C_AOE_COUNT,        /* MGX_SEC_AOES records */
+  MGX_C_TERR_START, MGX_C_TERR_COUNT,      /* MGX_SEC_TERR_CONTROLS records */
+  MGX_C_WORDS = ((MGX_C_TERR_COUNT + 1 + 3) / 4) * 4
 };
 enum { MGX_KIND_WALL = 0, MGX_KIND_OBJECT = 1, MGX_KIND_AGENT = 2 };
 
@@ -140,10 +155,13 @@ enum {
   MGX_FOP_TARGET_IS_USABLE,  /*                                         filters/target_is_usable_filter.hpp */
   MGX_FOP_PERIODIC,          /* a0 period, a1 start_on                  filters/periodic_filter.hpp:15-29 */
   MGX_FOP_GAME_VALUE,        /* a0 entity, a1 value code, a2 threshold  filters/game_value_filter.hpp:17-29 */
-  MGX_FOP_MAX_DISTANCE,      /* a0 entity, a1 radius (binary form)      filters/max_distance_filter.hpp:27-45 */
+  MGX_FOP_MAX_DISTANCE,      /* a0 entity, a1 radius, a2 source query or -1 (binary form)  filters/max_distance_filter.hpp:27-67 */
+  MGX_FOP_QUERY_RESOURCE,    /* a0 query, a1 WORDLIST start of (resource, min) pairs, a2 pair count  query_resource_filter.hpp:20-47 */
   MGX_FOP_TRUE, MGX_FOP_FALSE
 };
 enum { MGX_ENT_ACTOR = 0, MGX_ENT_TARGET = 1 };
+#define MGX_SLOT_NONE (-1)
+#define MGX_SLOT_PROXY (-2) /* territory proxy cell: carries only the winning tag (territory_tracker.cpp:289-342) */
 
 /* Mutations (handler/mutations/). */
 enum { MGX_MU_OP = 0, MGX_MU_A0, MGX_MU_A1, MGX_MU_A2, MGX_MU_A3, MGX_MU_A4, MGX_MU_PAD0, MGX_MU_PAD1, MGX_MU_WORDS /* 8 */ };
@@ -158,7 +176,11 @@ enum {
   MGX_MOP_SWAP,               /*                                               swap_mutation.hpp */
   MGX_MOP_USE_TARGET,         /*                                               use_target_mutation.hpp */
   MGX_MOP_GAME_VALUE,         /* a0 target entity, a1 value code, a2 source code  game_value_mutation.hpp */
-  MGX_MOP_ADD_TAG, MGX_MOP_REMOVE_TAG /* a0 entity, a1 tag                     tag_mutation.hpp */
+  MGX_MOP_ADD_TAG, MGX_MOP_REMOVE_TAG, /* a0 entity, a1 tag                    tag_mutation.hpp:16-45 */
+  MGX_MOP_REMOVE_TAGS_PREFIX, /* a0 entity, a1 WORDLIST start, a2 count         tag_mutation.hpp:47-67 */
+  MGX_MOP_RECOMPUTE_QUERY,    /* a0 tag                                         recompute_materialized_query_mutation.hpp */
+  MGX_MOP_QUERY_INVENTORY     /* a0 query, a1 WORDLIST (res, delta) pairs, a2 count, a3 source entity or -1,
+                                 a4 WORDLIST (res, game stat id) pairs, PAD0 = their count   query_inventory_mutation.hpp:22-75 */
 };
 
 /* Actions (actions/action_handler_factory.cpp:15-79): index space [noop, move_<dir>..., change_vibe_<v>...]. */
@@ -181,7 +203,9 @@ enum {
   MGX_GOP_ADD_TERM,      /* SumValue step: t=pop; if a0: t=logf(t+1); if a1: t*=f32(a2); acc=pop; push(acc+t)     */
   MGX_GOP_RATIO,         /* den=pop, num=pop; push(den>0 ? num/den : num)                                          */
   MGX_GOP_MAX2,          /* v=pop, best=pop; push(std::max(best,v))                                                */
-  MGX_GOP_MIN2
+  MGX_GOP_MIN2,
+  MGX_GOP_QUERY_INVENTORY, /* a0 resource, a1 query: sum of f32(amount) over the query result (game_value.cpp:45-57) */
+  MGX_GOP_QUERY_COUNT      /* a0 query */
 };
 /* A "value code" argument elsewhere is the index of a MGX_SEC_OBS_VALUES-style (start,count) pair:
  * MGX_SEC_REWARDS record = {gv_start, gv_count, accumulate, init_touch_stat_scope, init_touch_stat_id} */
@@ -189,6 +213,30 @@ enum { MGX_RW_GV_START = 0, MGX_RW_GV_COUNT, MGX_RW_ACCUMULATE, MGX_RW_TOUCH_SCO
 /* MGX_SEC_OBS_VALUES record = {gv_start, gv_count, feature_id}; also used as the generic "value code" table:
  * filters/mutations reference values by record index in this section. */
 enum { MGX_OV_GV_START = 0, MGX_OV_GV_COUNT, MGX_OV_FEATURE, MGX_OV_WORDS };
+
+/* Queries (core/query_config.hpp, core/query_system.cpp:178-330). */
+enum { MGX_Q_KIND = 0, MGX_Q_A0, MGX_Q_A1, MGX_Q_A2, MGX_Q_A3, MGX_Q_MAX_ITEMS /* value record or -1 */,
+       MGX_Q_ORDER /* bit0 random, bit8 include_blocker */, MGX_Q_A4, MGX_Q_WORDS };
+enum {
+  MGX_QK_TAG = 0,   /* a0 tag, a1 filter pc */
+  MGX_QK_FILTERED,  /* a0 source query, a1 filter pc */
+  MGX_QK_CLOSURE,   /* a0 source, a1 candidates or -1, a2 edge filter pc, a3 result filter pc */
+  MGX_QK_RAYCAST    /* a0 source, a1 max_range value record, a2 WORDLIST (dr, dc) pairs, a3 pair count, a4 blocker pc */
+};
+/* Events (handler/event.cpp:34-101, event_scheduler.cpp:8-53). Schedule = (timestep, event) sorted as the reference. */
+enum { MGX_EV_QUERY = 0, MGX_EV_FILTER_PC, MGX_EV_MUT_START, MGX_EV_MUT_COUNT, MGX_EV_MAX_TARGETS, MGX_EV_FALLBACK,
+       MGX_EV_PAD0, MGX_EV_PAD1, MGX_EV_WORDS };
+enum { MGX_SC_TIMESTEP = 0, MGX_SC_EVENT, MGX_SC_WORDS };
+enum { MGX_MQ_TAG = 0, MGX_MQ_QUERY, MGX_MQ_WORDS };
+enum { MGX_TH_TAG = 0, MGX_TH_HANDLER, MGX_TH_WORDS };  /* on_tag_add / on_tag_remove (core/grid_object.cpp:93-123) */
+/* AoE (handler/handler_config.hpp:55-66, core/aoe_tracker.cpp). */
+enum { MGX_AO_RADIUS = 0, MGX_AO_STATIC, MGX_AO_EFFECT_SELF, MGX_AO_FILTER_PC, MGX_AO_MUT_START, MGX_AO_MUT_COUNT,
+       MGX_AO_PRES_START, MGX_AO_PRES_COUNT, MGX_AO_WORDS };
+enum { MGX_PR_RESOURCE = 0, MGX_PR_DELTA, MGX_PR_WORDS };
+/* Territories (handler/territory_config.hpp, core/territory_tracker.cpp). Handler lists = consecutive leaf handlers. */
+enum { MGX_TE_TAGS_START = 0 /* WORDLIST */, MGX_TE_TAGS_COUNT, MGX_TE_ENTER_START, MGX_TE_ENTER_COUNT,
+       MGX_TE_EXIT_START, MGX_TE_EXIT_COUNT, MGX_TE_PRES_START, MGX_TE_PRES_COUNT, MGX_TE_WORDS };
+enum { MGX_TC_STRENGTH = 0, MGX_TC_DECAY, MGX_TC_TERRITORY, MGX_TC_PAD, MGX_TC_WORDS };
 
 static inline int mgx_sec_off(const int32_t* p, int s) { return p[MGX_H_SECTION_BASE + 2 * s]; }
 static inline int mgx_sec_cnt(const int32_t* p, int s) { return p[MGX_H_SECTION_BASE + 2 * s + 1]; }

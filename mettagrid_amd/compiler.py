@@ -149,6 +149,9 @@ class _Compiler:
         self.counts: dict[int, int] = {s: 0 for s in range(K.SEC_COUNT)}
         self.header = [0] * K.H_WORDS
         self.atom_labels: list = []  # (word index in atoms section, label)
+        self.indexed_tags: set = set()
+        self.query_depth = 0
+        self.dynamic_tags = False
 
     # ---- id tables -------------------------------------------------------------------------------------------
     def build_ids(self) -> None:
@@ -170,6 +173,7 @@ class _Compiler:
         for a in sp.agents:
             tags.update(a.tags)
             tags.add(type_tag(a.name))
+        tags.update(mq.tag for mq in sp.materialize_queries)
         self.tag_names = sorted(tags)                              # :629-646
         if len(self.tag_names) > 256:
             raise ValueError("Too many unique tags (max 256)")
@@ -274,6 +278,10 @@ class _Compiler:
             for child in v.values:
                 self.gv_code(child, code)
                 code.append([K.GOP_MAX2 if is_max else K.GOP_MIN2, 0, 0, 0])
+        elif isinstance(v, S.QueryInventoryValue):
+            code.append([K.GOP_QUERY_INVENTORY, self.res_id[v.item], self.query(v.query), 0])
+        elif isinstance(v, S.QueryCountValue):
+            code.append([K.GOP_QUERY_COUNT, self.query(v.query), 0, 0])
         elif isinstance(v, (int, float)):
             code.append([K.GOP_CONST, f32_bits(float(v)), 0, 0])
         else:
@@ -291,6 +299,38 @@ class _Compiler:
         """Index of a (start,count,feature) record in SEC_OBS_VALUES (generic value table)."""
         start, count = self.gv_emit(v)
         return self.emit(K.SEC_OBS_VALUES, [start, count, feature])
+
+    # ---- queries (core/query_config.hpp; converter mettagrid_c_config.py:83-180) -------------------------------
+    def query(self, q, depth: int = 1) -> int:
+        self.query_depth = max(self.query_depth, depth)
+        if isinstance(q, str):
+            q = S.TagQuery(q)
+        if isinstance(q, S.MaterializedQuery):
+            q = S.TagQuery(q.tag)
+        mx = -1 if q.max_items is None else self.value_ref(q.max_items)
+        order = 1 if q.order_by == "random" else 0
+        if isinstance(q, S.TagQuery):
+            if q.tag not in self.tag_id:
+                raise ValueError(f"Tag query references unknown tag '{q.tag}'. Add it to GameSpec.tags or object tags.")
+            self.indexed_tags.add(self.tag_id[q.tag])
+            return self.emit(K.SEC_QUERIES, [K.QK_TAG, self.tag_id[q.tag], self.filters_emit(q.filters), 0, 0, mx, order, 0])
+        if isinstance(q, S.FilteredQuery):
+            src = self.query(q.source, depth + 1)
+            return self.emit(K.SEC_QUERIES, [K.QK_FILTERED, src, self.filters_emit(q.filters), 0, 0, mx, order, 0])
+        if isinstance(q, S.ClosureQuery):
+            src = self.query(q.source, depth + 1)
+            cand = -1 if q.candidates is None else self.query(q.candidates, depth + 1)
+            return self.emit(K.SEC_QUERIES, [K.QK_CLOSURE, src, cand, self.filters_emit(q.edge_filters),
+                                             self.filters_emit(q.result_filters), mx, order, 0])
+        if isinstance(q, S.RaycastQuery):
+            src = self.query(q.source, depth + 1)
+            dirs = list(q.directions) or [(-1, 0), (1, 0), (0, 1), (0, -1)]  # query_system.cpp:265-266
+            doff = self.emit_words([x for d in dirs for x in d])
+            blocker = self.filters_emit([S.OrFilter(list(q.blocker))]) if q.blocker else K.PC_FAIL
+            if q.include_blocker:
+                order |= 0x100
+            return self.emit(K.SEC_QUERIES, [K.QK_RAYCAST, src, self.value_ref(q.max_range), doff, len(dirs), mx, order, blocker])
+        raise UnsupportedFeature(f"query {type(q).__name__} is not supported")
 
     # ---- filters -> short-circuit atoms ----------------------------------------------------------------------
     def _atom(self, op: int, a0: int, a1: int, a2: int, on_true, on_false) -> None:
@@ -331,6 +371,13 @@ class _Compiler:
         elif isinstance(f, S.PeriodicFilter):
             start_on = f.period if f.start_on is None else f.start_on  # mettagrid_c_config.py:302-310
             self._atom(K.FOP_PERIODIC, f.period, start_on, 0, on_true, on_false)
+        elif isinstance(f, S.MaxDistanceFilter):
+            qi = -1 if f.source is None else self.query(f.source)
+            self._atom(K.FOP_MAX_DISTANCE, self.ent(f.entity), f.radius, qi, on_true, on_false)
+        elif isinstance(f, S.QueryResourceFilter):
+            pairs = [x for r, m in f.requirements.items() for x in (self.res_id[r], m)]
+            off = self.emit_words(pairs) if pairs else 0
+            self._atom(K.FOP_QUERY_RESOURCE, self.query(f.query), off, len(pairs) // 2, on_true, on_false)
         elif isinstance(f, S.GameValueFilter):
             self._atom(K.FOP_GAME_VALUE, self.ent(f.entity), self.value_ref(f.value), self.value_ref(f.threshold),
                        on_true, on_false)
@@ -376,6 +423,26 @@ class _Compiler:
             return [K.MOP_STATS, scope, self.ent(m.entity), sid, self.value_ref(m.value), 0]
         if isinstance(m, S.ChangeVibe):
             return [K.MOP_CHANGE_VIBE, self.ent(m.entity), self.vibe_id[m.vibe], 0, 0, 0]
+        if isinstance(m, (S.AddTag, S.RemoveTag)):
+            self.dynamic_tags = True
+            op = K.MOP_ADD_TAG if isinstance(m, S.AddTag) else K.MOP_REMOVE_TAG
+            return [op, self.ent(m.entity), self.tag_id[m.tag], 0, 0, 0]
+        if isinstance(m, S.RemoveTagsWithPrefix):
+            self.dynamic_tags = True
+            ids = self.prefix_tags(m.prefix)
+            return [K.MOP_REMOVE_TAGS_PREFIX, self.ent(m.entity), self.emit_words(ids) if ids else 0, len(ids), 0, 0]
+        if isinstance(m, S.GameValueMutation):
+            if not isinstance(m.value, (S.InventoryValue, S.StatValue)):
+                raise RuntimeError("Cannot update a read-only ResolvedGameValue")  # resolved_game_value.hpp:52-56
+            return [K.MOP_GAME_VALUE, self.ent(m.target), self.value_ref(m.value), self.value_ref(m.source), 0, 0]
+        if isinstance(m, S.RecomputeMaterializedQuery):
+            return [K.MOP_RECOMPUTE_QUERY, self.tag_id[m.tag], 0, 0, 0, 0]
+        if isinstance(m, S.QueryInventoryMutation):
+            pairs = [x for r, dl in m.deltas.items() for x in (self.res_id[r], dl)]
+            stats = [x for r, n in m.transfer_stat_names.items() for x in (self.res_id[r], self.stat("game", n))]
+            return [K.MOP_QUERY_INVENTORY, self.query(m.query), self.emit_words(pairs) if pairs else 0, len(pairs) // 2,
+                    -1 if m.source is None else self.ent(m.source), self.emit_words(stats) if stats else 0,
+                    len(stats) // 2]
         if isinstance(m, S.Relocate):
             return [K.MOP_RELOCATE, 0, 0, 0, 0, 0]
         if isinstance(m, S.Swap):
@@ -383,6 +450,54 @@ class _Compiler:
         if isinstance(m, S.UseTarget):
             return [K.MOP_USE_TARGET, 0, 0, 0, 0, 0]
         raise UnsupportedFeature(f"mutation {type(m).__name__} is not supported yet")
+
+    def mutations_emit(self, mutations) -> tuple[int, int]:
+        recs = [self.mutation(m) for m in mutations]
+        start = self.counts[K.SEC_MUTS]
+        for rec in recs:
+            self.emit(K.SEC_MUTS, (rec + [0, 0])[:K.MU_WORDS])
+        return start, len(recs)
+
+    def tag_handlers(self, mapping: dict) -> tuple[int, int]:
+        """on_tag_add / on_tag_remove: one (tag, leaf handler) record per tag matching the prefix
+        (mettagrid_c_config.py:448-469)."""
+        recs = []
+        for prefix, h in mapping.items():
+            ids = self.prefix_tags(prefix)
+            if not ids:
+                raise ValueError(f"on_tag handler prefix '{prefix}' matched no tags")
+            hid = self.handler(S.Handler(h.filters, h.mutations, prefix))
+            recs += [[t, hid] for t in ids]
+        start = self.counts[K.SEC_TAG_HANDLERS]
+        for r in recs:
+            self.emit(K.SEC_TAG_HANDLERS, r)
+        if recs:
+            self.dynamic_tags = True
+        return start, len(recs)
+
+    def aoes(self, aoes: list) -> tuple[int, int]:
+        recs = []
+        for a in aoes:
+            fpc = self.filters_emit(a.filters)
+            ms, mc = self.mutations_emit(a.mutations)
+            ps = self.counts[K.SEC_PRESENCE]
+            for r, dl in a.presence_deltas.items():
+                self.emit(K.SEC_PRESENCE, [self.res_id[r], dl])
+            recs.append([a.radius, 1 if a.is_static else 0, 1 if a.effect_self else 0, fpc, ms, mc, ps,
+                         len(a.presence_deltas)])
+        start = self.counts[K.SEC_AOES]
+        for r in recs:
+            self.emit(K.SEC_AOES, r)
+        return start, len(recs)
+
+    def terr_controls(self, controls: list) -> tuple[int, int]:
+        names = list(self.spec.territories.keys())
+        start = self.counts[K.SEC_TERR_CONTROLS]
+        for tc in controls:
+            if tc.territory not in names:
+                raise ValueError(f"TerritoryControl references unknown territory '{tc.territory}'.")
+            self.emit(K.SEC_TERR_CONTROLS, [tc.strength, tc.decay, names.index(tc.territory), 0])
+        return start, len(controls)
 
     # ---- handlers --------------------------------------------------------------------------------------------
     def handler(self, h) -> int:
@@ -394,7 +509,7 @@ class _Compiler:
             muts = [self.mutation(m) for m in h.mutations]
             mstart = self.counts[K.SEC_MUTS]
             for rec in muts:
-                self.emit(K.SEC_MUTS, rec + [0, 0])
+                self.emit(K.SEC_MUTS, (rec + [0, 0])[:K.MU_WORDS])
             return self.emit(K.SEC_HANDLERS, [K.HK_LEAF, fpc, mstart, len(muts), 0, 0, 0, 0])
         if isinstance(h, (S.FirstMatch, S.AllOf)):
             kids = [k for k in (self.handler(c) for c in h.handlers) if k >= 0]
@@ -456,7 +571,7 @@ class _Compiler:
         return start, n
 
     def emit_class(self, *, kind, type_id, vibe, group, on_use, on_tick, on_after_use, lim, init_inv, rewards,
-                   static, cell, tags) -> int:
+                   static, cell, tags, src=None) -> int:
         lstart, lcount, res_limit, mod_mask = lim
         rec = [0] * K.C_WORDS
         rec[K.C_KIND] = kind
@@ -474,6 +589,13 @@ class _Compiler:
         rec[K.C_MODIFIER_MASK] = mod_mask
         rec[K.C_TAGS:K.C_TAGS + K.TAG_WORDS] = self.tag_mask_words(tags)
         rec[K.C_RES_LIMIT:K.C_RES_LIMIT + K.MAX_RESOURCES] = res_limit
+        if src is not None:
+            rec[K.C_TAG_ADD_START], rec[K.C_TAG_ADD_COUNT] = self.tag_handlers(src.on_tag_add)
+            rec[K.C_TAG_REMOVE_START], rec[K.C_TAG_REMOVE_COUNT] = self.tag_handlers(src.on_tag_remove)
+            rec[K.C_AOE_START], rec[K.C_AOE_COUNT] = self.aoes(src.aoes)
+            rec[K.C_TERR_START], rec[K.C_TERR_COUNT] = self.terr_controls(src.territory_controls)
+            if src.aoes or src.territory_controls:
+                rec[K.C_STATIC] = 0
         return self.emit(K.SEC_CLASSES, rec)
 
     # ---- top level -------------------------------------------------------------------------------------------
@@ -513,6 +635,8 @@ class _Compiler:
             add_feature(name)
             for p in range(1, digits):
                 add_feature(f"{name}:p{p}")
+        if obs.aoe_mask:
+            add_feature("aoe_mask")
         if obs.last_action_move:
             add_feature("last_action_move")
         if len(feats) > 255:
@@ -591,7 +715,7 @@ class _Compiler:
                     on_use=self.handler(a.on_use), on_tick=self.handler(a.on_tick),
                     on_after_use=self.handler(a.on_after_use), lim=self.limits(limit_defs),
                     init_inv=self.init_inventory(a.inventory.initial, keep_zero=True),
-                    rewards=(rstart, len(a.rewards)), static=False, cell=cell,
+                    rewards=(rstart, len(a.rewards)), static=False, cell=cell, src=a,
                     tags=[self.tag_id[t] for t in list(a.tags) + [type_tag(a.name)]])
                 class_cells.append(cell)
                 cell_to_class[cell] = cid
@@ -627,7 +751,7 @@ class _Compiler:
                 cid = self.emit_class(kind=K.KIND_WALL, type_id=self.type_id[o.name], vibe=o.vibe, group=0,
                                       on_use=-1, on_tick=-1, on_after_use=-1, lim=(0, 0, [-1] * K.MAX_RESOURCES, 0),
                                       init_inv=(0, 0), rewards=(0, 0), static=not any_custom_move, cell=o.cell,
-                                      tags=tags)
+                                      tags=tags, src=o)
             elif o.kind == "object":
                 limit_defs, init = [], (0, 0)
                 if o.inventory is not None:
@@ -647,11 +771,55 @@ class _Compiler:
                 static = (on_use < 0 and o.inventory is None and not any_custom_move)
                 cid = self.emit_class(kind=K.KIND_OBJECT, type_id=self.type_id[o.name], vibe=o.vibe, group=0,
                                       on_use=on_use, on_tick=-1, on_after_use=-1, lim=self.limits(limit_defs),
-                                      init_inv=init, rewards=(0, 0), static=static, cell=o.cell, tags=tags)
+                                      init_inv=init, rewards=(0, 0), static=static, cell=o.cell, tags=tags, src=o)
             else:
                 raise ValueError(f"Unknown object kind: {o.kind} (key={key})")
             class_cells.append(o.cell)
             cell_to_class[o.cell] = cid
+
+        # ---- events (sorted by name = std::map order; schedule stable-sorted by timestep: event_scheduler.cpp:8-34)
+        ev_names = sorted(sp.events.keys())
+        ev_recs = []
+        for name in ev_names:
+            ev = sp.events[name]
+            qi = self.query(ev.target_query)
+            fpc = self.filters_emit(ev.filters)
+            ms, mc = self.mutations_emit(ev.mutations)
+            mt = -1 if ev.max_targets is None else int(ev.max_targets)   # mettagrid_c_config.py:434
+            fb = -1
+            if ev.fallback:
+                if ev.fallback not in ev_names:
+                    raise ValueError(f"event '{name}': unknown fallback '{ev.fallback}'")
+                fb = ev_names.index(ev.fallback)
+            ev_recs.append([qi, fpc, ms, mc, mt, fb, 0, 0])
+        for r in ev_recs:
+            self.emit(K.SEC_EVENTS, r)
+        sched = [(int(t), i) for i, name in enumerate(ev_names) for t in sp.events[name].timesteps]
+        sched.sort(key=lambda x: x[0])  # Python's sort is stable, like std::stable_sort
+        for t, i in sched:
+            self.emit(K.SEC_SCHEDULE, [t, i])
+        # ---- materialized queries (query_system.cpp:91-117) ----
+        for mq in sp.materialize_queries:
+            self.dynamic_tags = True
+            self.indexed_tags.add(self.tag_id[mq.tag])
+            self.emit(K.SEC_MATQ, [self.tag_id[mq.tag], self.query(mq.query)])
+        # ---- territories (territory_tracker.cpp:72-100) ----
+        def leaf_list(handlers) -> tuple[int, int]:
+            ids = [self.handler(S.Handler(h.filters, h.mutations, "t")) for h in handlers]
+            for a, b in zip(ids, ids[1:]):
+                assert b == a + 1
+            return (ids[0] if ids else 0), len(ids)
+        for name, tc in sp.territories.items():
+            self.dynamic_tags = True
+            tg = self.prefix_tags(tc.tag_prefix)
+            toff = self.emit_words(tg) if tg else 0
+            es, ec = leaf_list(tc.on_enter)
+            xs, xc = leaf_list(tc.on_exit)
+            ps, pc = leaf_list(tc.presence)
+            self.emit(K.SEC_TERRITORIES, [toff, len(tg), es, ec, xs, xc, ps, pc])
+        game_on_tick = self.handler(sp.on_tick)
+        if sp.events or sp.materialize_queries:
+            self.dynamic_tags = self.dynamic_tags or bool(sp.materialize_queries)
 
         # ---- observation tables ----
         offs = observation_offsets(obs.height, obs.width)
@@ -690,6 +858,23 @@ class _Compiler:
         h[K.H_NUM_OBS_OFFSETS] = len(offs)
         h[K.H_NUM_MOVE_HANDLERS] = len(move_handlers)
         h[K.H_NUM_OBS_VALUES] = n_obs_values
+        h[K.H_NUM_EVENTS] = self.counts[K.SEC_EVENTS]
+        h[K.H_NUM_SCHEDULE] = self.counts[K.SEC_SCHEDULE]
+        h[K.H_NUM_MATQ] = self.counts[K.SEC_MATQ]
+        h[K.H_NUM_TERRITORIES] = self.counts[K.SEC_TERRITORIES]
+        h[K.H_GAME_ON_TICK] = game_on_tick
+        h[K.H_DYNAMIC_TAGS] = 1 if self.dynamic_tags else 0
+        h[K.H_QUERY_DEPTH] = self.query_depth
+        tag_lists = [-1] * 256
+        for li, t in enumerate(sorted(self.indexed_tags)):
+            tag_lists[t] = li
+        h[K.H_NUM_INDEXED_TAGS] = len(self.indexed_tags)
+        self.sections[K.SEC_TAG_LISTS] = tag_lists
+        self.counts[K.SEC_TAG_LISTS] = 256
+        if self.dynamic_tags:   # nothing is immutable once tags can change under an object
+            cw = self.sections[K.SEC_CLASSES]
+            for c in range(self.counts[K.SEC_CLASSES]):
+                cw[c * K.C_WORDS + K.C_STATIC] = 0
         fb = K.H_FEAT_BASE
         h[fb + K.F_GROUP] = feats["agent:group"]
         h[fb + K.F_COMPLETION] = feats["episode_completion_pct"]
@@ -701,7 +886,7 @@ class _Compiler:
         h[fb + K.F_LP_EAST], h[fb + K.F_LP_WEST] = feats["lp:east"], feats["lp:west"]
         h[fb + K.F_LP_NORTH], h[fb + K.F_LP_SOUTH] = feats["lp:north"], feats["lp:south"]
         h[fb + K.F_AGENT_ID] = feats["agent_id"]
-        h[fb + K.F_AOE_MASK] = 0
+        h[fb + K.F_AOE_MASK] = feats.get("aoe_mask", 0)
         for key, sid in self.stat_well_known.items():
             h[K.H_STAT_BASE + key] = sid
         h[K.H_NUM_AGENT_STATS] = len(self.agent_stats)

@@ -24,7 +24,7 @@ from .signature import objects_from_raw, stats_dicts
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmgx.so")
 _lib = None
-OBJ_RECORD_WORDS = 34
+OBJ_RECORD_WORDS = 42
 
 ENV_TOKEN_OVERFLOW, ENV_INVALID_KEY_RANGE, ENV_DEPTH, ENV_TOO_MANY_OBJECTS = 1, 2, 4, 8
 

@@ -41,7 +41,8 @@ def objects_from_raw(prog, raw: np.ndarray, current_stat_reward=None) -> dict:
         if not alive:
             continue
         C = words[coff + cls * K.C_WORDS: coff + (cls + 1) * K.C_WORDS]
-        tags = [t for t in range(256) if (int(C[K.C_TAGS + (t >> 5)]) >> (t & 31)) & 1]
+        tw = rec[8 + 2 * _MAXR: 8 + 2 * _MAXR + 8]
+        tags = [t for t in range(256) if (int(tw[t >> 5]) >> (t & 31)) & 1]
         amounts = rec[8 + _MAXR: 8 + 2 * _MAXR]
         d = {"id": oid, "type_name": prog.type_names[int(C[K.C_TYPE_ID])], "r": r, "c": c, "location": (c, r),
              "tag_ids": tags, "vibe": vibe,

@@ -60,7 +60,65 @@ class MinValue:
     values: list
 
 
-GameValue = Union[InventoryValue, StatValue, ConstValue, SumValue, RatioValue, MaxValue, MinValue]
+@dataclass
+class QueryInventoryValue:
+    item: str
+    query: object
+
+
+@dataclass
+class QueryCountValue:
+    query: object
+
+
+GameValue = Union[InventoryValue, StatValue, ConstValue, SumValue, RatioValue, MaxValue, MinValue,
+                  QueryInventoryValue, QueryCountValue]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Queries (reference: cpp/include/mettagrid/core/query_config.hpp)
+# ---------------------------------------------------------------------------------------------------------------
+@dataclass
+class TagQuery:
+    tag: str
+    filters: list = field(default_factory=list)
+    max_items: object = None      # GameValue / number; None = unlimited (-1)
+    order_by: str = "none"        # "none" | "random"
+
+
+@dataclass
+class FilteredQuery:
+    source: object
+    filters: list = field(default_factory=list)
+    max_items: object = None
+    order_by: str = "none"
+
+
+@dataclass
+class ClosureQuery:
+    source: object
+    candidates: object = None
+    edge_filters: list = field(default_factory=list)
+    result_filters: list = field(default_factory=list)
+    max_items: object = None
+    order_by: str = "none"
+
+
+@dataclass
+class RaycastQuery:
+    source: object
+    max_range: object = 2
+    directions: list = field(default_factory=list)   # [(dr, dc)]; empty = 4 cardinals
+    blocker: list = field(default_factory=list)      # filters, any match blocks the ray
+    include_blocker: bool = True
+    max_items: object = None
+    order_by: str = "none"
+
+
+@dataclass
+class MaterializedQuery:
+    tag: str
+    query: object
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -117,6 +175,19 @@ class PeriodicFilter:
 
 
 @dataclass
+class MaxDistanceFilter:
+    entity: str
+    radius: int = 0
+    source: object = None   # query; None = binary form (distance to ctx.source / actor)
+
+
+@dataclass
+class QueryResourceFilter:
+    query: object
+    requirements: dict = field(default_factory=dict)   # resource -> min total
+
+
+@dataclass
 class GameValueFilter:
     entity: str
     value: object
@@ -168,6 +239,44 @@ class SetStat:
 class ChangeVibe:
     entity: str
     vibe: str
+
+
+@dataclass
+class AddTag:
+    entity: str
+    tag: str
+
+
+@dataclass
+class RemoveTag:
+    entity: str
+    tag: str
+
+
+@dataclass
+class RemoveTagsWithPrefix:
+    entity: str
+    prefix: str
+
+
+@dataclass
+class GameValueMutation:
+    value: object            # InventoryValue or StatValue (the mutable kinds)
+    source: object           # delta expression
+    target: str = TARGET
+
+
+@dataclass
+class RecomputeMaterializedQuery:
+    tag: str
+
+
+@dataclass
+class QueryInventoryMutation:
+    query: object
+    deltas: dict = field(default_factory=dict)          # resource -> delta
+    source: Optional[str] = None                         # entity; set = transfer mode
+    transfer_stat_names: dict = field(default_factory=dict)  # resource -> game stat name
 
 
 @dataclass
@@ -227,6 +336,41 @@ class Inventory:
 # Objects and agents
 # ---------------------------------------------------------------------------------------------------------------
 @dataclass
+class AOESpec:
+    radius: int = 1
+    is_static: bool = True
+    effect_self: bool = False
+    filters: list = field(default_factory=list)
+    mutations: list = field(default_factory=list)
+    presence_deltas: dict = field(default_factory=dict)   # resource -> delta (+ on enter, - on exit)
+
+
+@dataclass
+class TerritoryControl:
+    territory: str
+    strength: int = 1
+    decay: int = 1
+
+
+@dataclass
+class TerritorySpec:
+    tag_prefix: str
+    on_enter: list = field(default_factory=list)   # list[Handler]
+    on_exit: list = field(default_factory=list)
+    presence: list = field(default_factory=list)
+
+
+@dataclass
+class EventSpec:
+    target_query: object
+    timesteps: list
+    filters: list = field(default_factory=list)
+    mutations: list = field(default_factory=list)
+    max_targets: Optional[int] = None
+    fallback: Optional[str] = None
+
+
+@dataclass
 class ObjectSpec:
     name: str                      # type name
     map_name: Optional[str] = None  # cell name in the map (defaults to name)
@@ -235,6 +379,10 @@ class ObjectSpec:
     vibe: int = 0
     inventory: Optional[Inventory] = None
     on_use: object = None
+    aoes: list = field(default_factory=list)                 # list[AOESpec]
+    territory_controls: list = field(default_factory=list)   # list[TerritoryControl]
+    on_tag_add: dict = field(default_factory=dict)           # tag prefix -> Handler
+    on_tag_remove: dict = field(default_factory=dict)
 
     @property
     def cell(self) -> str:
@@ -258,6 +406,10 @@ class AgentSpec:
     on_use: object = None
     on_tick: object = None
     on_after_use: object = None
+    aoes: list = field(default_factory=list)
+    territory_controls: list = field(default_factory=list)
+    on_tag_add: dict = field(default_factory=dict)
+    on_tag_remove: dict = field(default_factory=dict)
 
 
 TEAM_NAMES = {0: "red", 1: "blue", 2: "green", 3: "yellow", 4: "purple", 5: "orange"}
@@ -275,6 +427,7 @@ class ObsSpec:
     last_reward: bool = True
     local_position: bool = False
     values: dict = field(default_factory=dict)  # feature name -> GameValue (global obs tokens)
+    aoe_mask: bool = False                       # per-tile territory observability token
 
 
 @dataclass
@@ -291,6 +444,10 @@ class GameSpec:
     max_steps: int = 0
     episode_truncates: bool = False
     protocol_details_obs: bool = False
+    events: dict = field(default_factory=dict)              # name -> EventSpec
+    materialize_queries: list = field(default_factory=list) # list[MaterializedQuery]
+    territories: dict = field(default_factory=dict)         # name -> TerritorySpec
+    on_tick: object = None                                  # game-level handler
 
     @property
     def num_agents(self) -> int:

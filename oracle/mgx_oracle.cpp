@@ -99,6 +99,7 @@ struct Obj {
   uint16_t inv[MGX_MAX_RESOURCES] = {0};
   uint8_t order[MGX_MAX_RESOURCES];  // inventory iteration order (front = begin())
   int norder = 0;
+  uint32_t tags[MGX_TAG_WORDS] = {0};  // GridObject::tag_bits (core/grid_object.hpp:117)
 };
 
 struct Agent {
@@ -113,12 +114,26 @@ struct Agent {
   Stats stats;
 };
 
+struct Deferred {  // AOETracker::apply_fixed accumulators (core/aoe_tracker.cpp:283-289)
+  int delta[MGX_MAX_RESOURCES] = {0};
+  bool seen[MGX_MAX_RESOURCES] = {false};
+  int order[MGX_MAX_RESOURCES];
+  int n = 0;
+};
+
 struct Ctx {  // handler/handler_context.hpp:38-112
-  int actor = -1, target = -1;
+  int actor = -1, target = -1, source = -1;  // object index, MGX_SLOT_NONE or MGX_SLOT_PROXY
+  int proxy_tag = -1;                        // tag carried by the territory proxy cell
   int target_r = 0, target_c = 0;
   int move_direction = 0;
   bool mutation_failed = false;
+  bool skip_trigger = false;                 // skip_on_update_trigger
+  Deferred* deferred = nullptr;
 };
+
+struct FixedSrc { int obj, aoe, r, c; bool alive; std::vector<uint8_t> inside; };
+struct MobileSrc { int obj, aoe; bool alive; std::vector<uint8_t> inside; };
+struct TerrSrc { int obj, ctrl, r, c; };
 
 struct Engine {
   const int32_t* P = nullptr;
@@ -131,6 +146,12 @@ struct Engine {
   MT rng;
   uint32_t step = 0;
   int error = 0;
+  std::vector<int> tag_lists[256];   // TagIndex::_objects_by_tag (core/tag_index.cpp)
+  std::vector<FixedSrc> fixed;       // AOETracker fixed sources in registration order
+  std::vector<MobileSrc> mobile;
+  std::vector<TerrSrc> terr;         // TerritoryTracker sources in registration order
+  std::vector<int> terr_prev;        // [A][num_territories] previous owner tag or -1
+  size_t next_event = 0;
   std::vector<uint8_t> obs;
   std::vector<float> rewards, episode_rewards;
   std::vector<uint8_t> terminals, truncations, action_success;
@@ -240,11 +261,11 @@ struct Engine {
   }
 
   // ---- game values (cpp/src/mettagrid/core/game_value.cpp:14-148) ---------------------------------------------
-  float eval_value(int rec, int entity) {
+  float eval_value(int rec, int entity, const Ctx& c) {
     const int32_t* V = sec(MGX_SEC_OBS_VALUES) + rec * MGX_OV_WORDS;
-    return eval_code(V[MGX_OV_GV_START], V[MGX_OV_GV_COUNT], entity);
+    return eval_code(V[MGX_OV_GV_START], V[MGX_OV_GV_COUNT], entity, c);
   }
-  float eval_code(int start, int count, int entity) {
+  float eval_code(int start, int count, int entity, const Ctx& outer) {
     float st[32];
     int sp = 0;
     const int32_t* code = sec(MGX_SEC_GV_CODE) + start * MGX_GV_WORDS;
@@ -269,46 +290,218 @@ struct Engine {
         case MGX_GOP_RATIO: { float den = st[--sp], num = st[--sp]; st[sp++] = den > 0.f ? num / den : num; break; }
         case MGX_GOP_MAX2: { float v = st[--sp], b = st[--sp]; st[sp++] = std::max(b, v); break; }
         case MGX_GOP_MIN2: { float v = st[--sp], b = st[--sp]; st[sp++] = std::min(b, v); break; }
+        case MGX_GOP_QUERY_INVENTORY: {  // game_value.cpp:45-57 (captured ctx: actor = the value's entity)
+          Ctx q = outer; q.actor = entity;
+          float total = 0.f;
+          for (int o : eval_query(a1, q)) total += (float)objs[o].inv[a0];
+          st[sp++] = total;
+          break;
+        }
+        case MGX_GOP_QUERY_COUNT: {
+          Ctx q = outer; q.actor = entity;
+          st[sp++] = (float)eval_query(a0, q).size();
+          break;
+        }
       }
     }
     return sp > 0 ? st[sp - 1] : 0.f;
   }
 
+  // ---- tags -------------------------------------------------------------------------------------------------
+  bool has_tag(int o, int t) const { return o >= 0 && ((objs[o].tags[t >> 5] >> (t & 31)) & 1u); }
+  void tags_of(int o, const Ctx& c, uint32_t* out) const {  // proxy cell carries exactly the winning tag
+    for (int w = 0; w < MGX_TAG_WORDS; w++) out[w] = o >= 0 ? objs[o].tags[w] : 0u;
+    if (o == MGX_SLOT_PROXY && c.proxy_tag >= 0) out[c.proxy_tag >> 5] |= 1u << (c.proxy_tag & 31);
+  }
+  void fire_tag_handlers(int o, int tag, int start_field, const Ctx& c) {  // core/grid_object.cpp:83-123
+    const int32_t* C = cls(objs[o].cls);
+    const int32_t* th = sec(MGX_SEC_TAG_HANDLERS) + C[start_field] * MGX_TH_WORDS;
+    for (int i = 0; i < C[start_field + 1]; i++, th += MGX_TH_WORDS) {
+      if (th[MGX_TH_TAG] != tag) continue;
+      Ctx h = c;
+      h.actor = h.target = o;
+      h.skip_trigger = false;
+      apply_handler(th[MGX_TH_HANDLER], h);
+    }
+  }
+  void add_tag(int o, int tag, const Ctx& c) {
+    if (o < 0 || tag < 0 || tag >= 256 || has_tag(o, tag)) return;
+    objs[o].tags[tag >> 5] |= 1u << (tag & 31);
+    tag_lists[tag].push_back(o);
+    if (!c.skip_trigger) fire_tag_handlers(o, tag, MGX_C_TAG_ADD_START, c);
+  }
+  void remove_tag(int o, int tag, const Ctx& c) {
+    if (o < 0 || tag < 0 || tag >= 256 || !has_tag(o, tag)) return;
+    objs[o].tags[tag >> 5] &= ~(1u << (tag & 31));
+    auto& v = tag_lists[tag];
+    v.erase(std::remove(v.begin(), v.end(), o), v.end());
+    if (!c.skip_trigger) fire_tag_handlers(o, tag, MGX_C_TAG_REMOVE_START, c);
+  }
+
+  // ---- queries (cpp/src/mettagrid/core/query_system.cpp:28-89, 178-330) ---------------------------------------
+  bool matches(int pc, Ctx c, int obj) { c.target = obj; return pc == MGX_PC_PASS || check_filters(pc, c); }
+  std::vector<int> apply_limits(std::vector<int> res, const int32_t* Q, const Ctx& c) {
+    if (Q[MGX_Q_ORDER] & 1) rng.shuffle(res.data(), (uint32_t)res.size());
+    int mx = Q[MGX_Q_MAX_ITEMS] >= 0 ? (int)eval_value(Q[MGX_Q_MAX_ITEMS], c.actor, c) : -1;
+    if (mx >= 0 && (int)res.size() > mx) res.resize(mx);
+    return res;
+  }
+  std::vector<int> eval_query(int qi, const Ctx& c) {
+    const int32_t* Q = sec(MGX_SEC_QUERIES) + qi * MGX_Q_WORDS;
+    std::vector<int> res;
+    switch (Q[MGX_Q_KIND]) {
+      case MGX_QK_TAG:
+        for (int o : tag_lists[Q[MGX_Q_A0]]) if (matches(Q[MGX_Q_A1], c, o)) res.push_back(o);
+        break;
+      case MGX_QK_FILTERED:
+        for (int o : eval_query(Q[MGX_Q_A0], c)) if (matches(Q[MGX_Q_A1], c, o)) res.push_back(o);
+        break;
+      case MGX_QK_CLOSURE: {
+        std::vector<int> roots = eval_query(Q[MGX_Q_A0], c);
+        if (Q[MGX_Q_A1] < 0) return apply_limits(std::move(roots), Q, c);
+        std::vector<int> pool = eval_query(Q[MGX_Q_A1], c);
+        std::vector<uint8_t> visited(objs.size(), 0);
+        std::vector<int> frontier;
+        for (int o : roots) if (!visited[o]) { visited[o] = 1; frontier.push_back(o); res.push_back(o); }
+        for (size_t head = 0; head < frontier.size(); head++) {
+          int cur = frontier[head];
+          for (int cand : pool) {
+            if (visited[cand]) continue;
+            if (Q[MGX_Q_A2] != MGX_PC_PASS) {
+              Ctx e = c; e.source = cur; e.target = cand;
+              if (!check_filters(Q[MGX_Q_A2], e)) continue;
+            }
+            visited[cand] = 1; frontier.push_back(cand); res.push_back(cand);
+          }
+        }
+        if (Q[MGX_Q_A3] != MGX_PC_PASS) {
+          std::vector<int> f;
+          for (int o : res) if (matches(Q[MGX_Q_A3], c, o)) f.push_back(o);
+          res = std::move(f);
+        }
+        break;
+      }
+      case MGX_QK_RAYCAST: {
+        std::vector<int> sources = eval_query(Q[MGX_Q_A0], c);
+        std::vector<uint8_t> seen(objs.size(), 0);
+        const int32_t* dirs = sec(MGX_SEC_WORDLIST) + Q[MGX_Q_A2];
+        for (int src : sources) {
+          Ctx sc = c; sc.actor = sc.target = src;
+          int range = (int)eval_value(Q[MGX_Q_A1], src, sc);
+          if (range <= 0) continue;
+          for (int d = 0; d < Q[MGX_Q_A3]; d++)
+            for (int dist = 1; dist <= range; dist++) {
+              int r = objs[src].r + dirs[d * 2] * dist, cc = objs[src].c + dirs[d * 2 + 1] * dist;
+              if (r < 0 || cc < 0 || r >= H || cc >= W) break;
+              int o = grid[r * W + cc] - 1;
+              if (o < 0) continue;
+              bool blocker = false;
+              if (Q[MGX_Q_A4] != MGX_PC_FAIL) { Ctx b = c; b.target = o; blocker = check_filters(Q[MGX_Q_A4], b); }
+              if (blocker) {
+                if ((Q[MGX_Q_ORDER] & 0x100) && !seen[o]) { seen[o] = 1; res.push_back(o); }
+                break;
+              }
+              if (!seen[o]) { seen[o] = 1; res.push_back(o); }
+            }
+        }
+        break;
+      }
+    }
+    return apply_limits(std::move(res), Q, c);
+  }
+  void compute_all_queries() {  // query_system.cpp:91-117
+    Ctx t; t.skip_trigger = true;
+    const int32_t* mq = sec(MGX_SEC_MATQ);
+    for (int i = 0; i < P[MGX_H_NUM_MATQ]; i++, mq += MGX_MQ_WORDS) {
+      std::vector<int> tagged = tag_lists[mq[MGX_MQ_TAG]];
+      for (int o : tagged) remove_tag(o, mq[MGX_MQ_TAG], t);
+      Ctx g;
+      for (int o : eval_query(mq[MGX_MQ_QUERY], g)) add_tag(o, mq[MGX_MQ_TAG], t);
+    }
+  }
+  void recompute_query(int tag, const Ctx& c) {  // query_system.cpp:119-175
+    Ctx t = c; t.skip_trigger = true;
+    std::vector<int> lost, keep;
+    const int32_t* mq = sec(MGX_SEC_MATQ);
+    for (int i = 0; i < P[MGX_H_NUM_MATQ]; i++, mq += MGX_MQ_WORDS) {
+      if (mq[MGX_MQ_TAG] != tag) continue;
+      lost = tag_lists[tag];
+      for (int o : lost) { t.actor = t.target = o; remove_tag(o, tag, t); }
+      for (int o : eval_query(mq[MGX_MQ_QUERY], c)) {
+        if (std::find(keep.begin(), keep.end(), o) == keep.end()) keep.push_back(o);
+        t.actor = t.target = o; add_tag(o, tag, t);
+      }
+      break;
+    }
+    t.skip_trigger = false;
+    for (int o : lost)
+      if (std::find(keep.begin(), keep.end(), o) == keep.end()) { t.actor = t.target = o; fire_tag_handlers(o, tag, MGX_C_TAG_REMOVE_START, t); }
+    for (int o : keep)
+      if (std::find(lost.begin(), lost.end(), o) == lost.end()) { t.actor = t.target = o; fire_tag_handlers(o, tag, MGX_C_TAG_ADD_START, t); }
+  }
+
   // ---- filters (cpp/include/mettagrid/handler/filters/*.hpp), short-circuit code ------------------------------
   int resolve(const Ctx& c, int ent) const { return ent == MGX_ENT_ACTOR ? c.actor : c.target; }
-  void masked_tags(int o, const int32_t* mask, uint32_t* out) const {
-    for (int w = 0; w < MGX_TAG_WORDS; w++)
-      out[w] = o < 0 ? 0u : ((uint32_t)cls(objs[o].cls)[MGX_C_TAGS + w] & (uint32_t)mask[w]);
-  }
+  int inv_of(int e, int item) const { return e >= 0 ? objs[e].inv[item] : 0; }
   bool atom(const int32_t* a, const Ctx& c) {
     int a0 = a[MGX_AT_A0], a1 = a[MGX_AT_A1], a2 = a[MGX_AT_A2];
     switch (a[MGX_AT_OP]) {
-      case MGX_FOP_VIBE: { int e = resolve(c, a0); return e >= 0 && objs[e].vibe == a1; }
-      case MGX_FOP_RESOURCE: { int e = resolve(c, a0); return e >= 0 && objs[e].inv[a1] >= a2; }
+      case MGX_FOP_VIBE: { int e = resolve(c, a0); return e != MGX_SLOT_NONE && (e >= 0 ? objs[e].vibe : 0) == a1; }
+      case MGX_FOP_RESOURCE: { int e = resolve(c, a0); return e != MGX_SLOT_NONE && inv_of(e, a1) >= a2; }
       case MGX_FOP_SHARED_TAG: {
         uint32_t x[MGX_TAG_WORDS], y[MGX_TAG_WORDS];
         const int32_t* mask = sec(MGX_SEC_WORDLIST) + a0;
-        masked_tags(c.actor, mask, x);
-        masked_tags(c.target, mask, y);
-        for (int w = 0; w < MGX_TAG_WORDS; w++) if (x[w] & y[w]) return true;
+        tags_of(c.actor, c, x);
+        tags_of(c.target, c, y);
+        for (int w = 0; w < MGX_TAG_WORDS; w++) if (x[w] & y[w] & (uint32_t)mask[w]) return true;
         return false;
       }
       case MGX_FOP_TAG: {
         int e = resolve(c, a0);
-        if (e < 0) return false;
+        if (e == MGX_SLOT_NONE) return false;
         uint32_t x[MGX_TAG_WORDS];
-        masked_tags(e, sec(MGX_SEC_WORDLIST) + a1, x);
-        for (int w = 0; w < MGX_TAG_WORDS; w++) if (x[w]) return true;
+        const int32_t* mask = sec(MGX_SEC_WORDLIST) + a1;
+        tags_of(e, c, x);
+        for (int w = 0; w < MGX_TAG_WORDS; w++) if (x[w] & (uint32_t)mask[w]) return true;
         return false;
       }
-      case MGX_FOP_TARGET_LOC_EMPTY: return c.target < 0;
-      case MGX_FOP_TARGET_IS_USABLE: return c.target >= 0;  // every GridObject derives from Usable
+      case MGX_FOP_TARGET_LOC_EMPTY: return c.target == MGX_SLOT_NONE;
+      case MGX_FOP_TARGET_IS_USABLE: return c.target != MGX_SLOT_NONE;  // every GridObject derives from Usable
       case MGX_FOP_PERIODIC: return step >= (uint32_t)a1 && ((step - (uint32_t)a1) % (uint32_t)a0) == 0;
       case MGX_FOP_GAME_VALUE: {
         int e = resolve(c, a0);
-        float v = eval_value(a1, e);
-        float t = eval_value(a2, e);
+        float v = eval_value(a1, e, c);
+        float t = eval_value(a2, e, c);
         return v >= t;
+      }
+      case MGX_FOP_MAX_DISTANCE: {  // filters/max_distance_filter.hpp:27-67
+        int e = resolve(c, a0);
+        if (e < 0) return false;
+        long r = a1;
+        if (a2 < 0) {
+          int ref = c.source >= 0 ? c.source : c.actor;
+          if (ref < 0) return false;
+          if (a1 == 0) return true;
+          long dr = objs[e].r - objs[ref].r, dc = objs[e].c - objs[ref].c;
+          return dr * dr + dc * dc <= r * r;
+        }
+        std::vector<int> srcs = eval_query(a2, c);
+        if (a1 == 0) return !srcs.empty();
+        for (int sidx : srcs) {
+          long dr = objs[e].r - objs[sidx].r, dc = objs[e].c - objs[sidx].c;
+          if (dr * dr + dc * dc <= r * r) return true;
+        }
+        return false;
+      }
+      case MGX_FOP_QUERY_RESOURCE: {  // filters/query_resource_filter.hpp:26-41
+        std::vector<int> res = eval_query(a0, c);
+        const int32_t* req = sec(MGX_SEC_WORDLIST) + a1;
+        for (int i = 0; i < a2; i++) {
+          uint32_t total = 0;
+          for (int o : res) { total += objs[o].inv[req[i * 2]]; if (total >= (uint32_t)req[i * 2 + 1]) break; }
+          if (total < (uint32_t)req[i * 2 + 1]) return false;
+        }
+        return true;
       }
       case MGX_FOP_TRUE: return true;
       default: return false;
@@ -338,7 +531,18 @@ struct Engine {
   void mutate(const int32_t* m, Ctx& c) {
     int a0 = m[MGX_MU_A0], a1 = m[MGX_MU_A1], a2 = m[MGX_MU_A2], a3 = m[MGX_MU_A3];
     switch (m[MGX_MU_OP]) {
-      case MGX_MOP_RESOURCE_DELTA: { int e = resolve(c, a0); if (e >= 0) inv_update(e, a1, a2); break; }
+      case MGX_MOP_RESOURCE_DELTA: {  // resource_mutation.hpp:25-47
+        if (c.deferred && a0 == MGX_ENT_TARGET && c.target >= 0 &&
+            !(cls(objs[c.target].cls)[MGX_C_MODIFIER_MASK] & (1 << a1))) {
+          Deferred& D = *c.deferred;
+          if (!D.seen[a1]) { D.seen[a1] = true; D.order[D.n++] = a1; }
+          D.delta[a1] += a2;
+          break;
+        }
+        int e = resolve(c, a0);
+        if (e >= 0) inv_update(e, a1, a2); else if (e == MGX_SLOT_PROXY) error |= 32;
+        break;
+      }
       case MGX_MOP_RESOURCE_TRANSFER: {  // resource_mutation.hpp:60-98
         int s = resolve(c, a0), d = resolve(c, a1);
         if (s < 0 || d < 0) break;
@@ -371,20 +575,73 @@ struct Engine {
       }
       case MGX_MOP_STATS: {  // stats_mutation.hpp:21-41: a0 scope (0 game, 1 agent), a1 entity, a2 stat, a3 value
         int e = resolve(c, a1);
-        float v = eval_value(a3, e);
+        float v = eval_value(a3, e, c);
         if (a0 == 0) game.set(a2, v);
         else if (is_agent(e)) agents[objs[e].agent].stats.set(a2, v);
         break;
       }
       case MGX_MOP_CHANGE_VIBE: { int e = resolve(c, a0); if (e >= 0) objs[e].vibe = a1; break; }
-      case MGX_MOP_RELOCATE: if (is_agent(c.actor)) move_object(c.actor, c.target_r, c.target_c); break;
+      case MGX_MOP_ADD_TAG: add_tag(resolve(c, a0), a1, c); break;          // tag_mutation.hpp:16-30
+      case MGX_MOP_REMOVE_TAG: remove_tag(resolve(c, a0), a1, c); break;    // :32-45
+      case MGX_MOP_REMOVE_TAGS_PREFIX: {                                    // :47-67
+        int e = resolve(c, a0);
+        const int32_t* ids = sec(MGX_SEC_WORDLIST) + a1;
+        for (int i = 0; i < a2; i++) remove_tag(e, ids[i], c);
+        break;
+      }
+      case MGX_MOP_GAME_VALUE: {  // game_value_mutation.hpp:21-27 (a0 target entity, a1 value, a2 source)
+        int e = resolve(c, a0);
+        float delta = eval_value(a2, e, c);
+        const int32_t* V = sec(MGX_SEC_OBS_VALUES) + a1 * MGX_OV_WORDS;
+        const int32_t* code = sec(MGX_SEC_GV_CODE) + V[MGX_OV_GV_START] * MGX_GV_WORDS;
+        if (code[MGX_GV_OP] == MGX_GOP_INVENTORY) {
+          if (e >= 0) inv_update(e, code[MGX_GV_A0], (int)delta);
+        } else if (code[MGX_GV_OP] == MGX_GOP_STAT) {
+          Stats* tr = code[MGX_GV_A0] == 1 ? &game : (is_agent(e) ? &agents[objs[e].agent].stats : nullptr);
+          if (tr) tr->add(code[MGX_GV_A1], delta);
+        }
+        break;
+      }
+      case MGX_MOP_RECOMPUTE_QUERY: recompute_query(a0, c); break;
+      case MGX_MOP_QUERY_INVENTORY: {  // query_inventory_mutation.hpp:26-52
+        std::vector<int> res = eval_query(a0, c);
+        const int32_t* dl = sec(MGX_SEC_WORDLIST) + a1;
+        const int32_t* sn = sec(MGX_SEC_WORDLIST) + m[MGX_MU_A4];
+        int nsn = m[MGX_MU_PAD0];
+        if (a3 >= 0) {
+          int srcobj = resolve(c, a3);
+          if (srcobj < 0) break;
+          for (int o : res)
+            for (int i = 0; i < a2; i++) {
+              int item = dl[i * 2], delta = dl[i * 2 + 1], actual = 0;
+              if (delta > 0) actual = transfer(srcobj, o, item, delta);
+              else if (delta < 0) actual = transfer(o, srcobj, item, -delta);
+              if (actual != 0)
+                for (int k = nsn - 1; k >= 0; k--)  // later duplicates win in the reference's map build
+                  if (sn[k * 2] == item) { game.add(sn[k * 2 + 1], (float)actual); break; }
+            }
+        } else {
+          for (int o : res)
+            for (int i = 0; i < a2; i++) inv_update(o, dl[i * 2], dl[i * 2 + 1]);
+        }
+        break;
+      }
+      case MGX_MOP_RELOCATE:
+        if (is_agent(c.actor)) {
+          int orr = objs[c.actor].r, occ = objs[c.actor].c;
+          if (move_object(c.actor, c.target_r, c.target_c)) territory_moved(c.actor, orr, occ);
+        }
+        break;
       case MGX_MOP_SWAP: {  // swap_mutation.hpp:15-21, core/grid.hpp:92-105
         if (!is_agent(c.actor) || !is_agent(c.target)) break;
         Obj &x = objs[c.actor], &y = objs[c.target];
         grid[x.r * W + x.c] = c.target + 1;
         grid[y.r * W + y.c] = c.actor + 1;
+        int xr = x.r, xc = x.c, yr = y.r, yc = y.c;
         std::swap(x.r, y.r);
         std::swap(x.c, y.c);
+        territory_moved(c.actor, xr, xc);  // Grid::swap_objects -> on_object_moved twice (core/grid.hpp:100-103)
+        territory_moved(c.target, yr, yc);
         agents[x.agent].stats.add(wk(MGX_S_SWAP), 1.f);
         break;
       }
@@ -421,6 +678,195 @@ struct Engine {
       }
     }
     return any;
+  }
+
+  // Leaf handler with "apply every mutation" semantics (events, AoE sources, territory handlers do not stop on
+  // mutation_failed: handler/event.cpp:86-92, core/aoe_tracker.cpp:99-113, core/territory_tracker.cpp:62-66).
+  bool apply_all(int filter_pc, int mut_start, int mut_count, Ctx& c) {
+    if (!check_filters(filter_pc, c)) return false;
+    const int32_t* m = sec(MGX_SEC_MUTS) + mut_start * MGX_MU_WORDS;
+    for (int i = 0; i < mut_count; i++, m += MGX_MU_WORDS) mutate(m, c);
+    return true;
+  }
+
+  // ---- events (handler/event.cpp:34-101, handler/event_scheduler.cpp:36-53) -----------------------------------
+  int execute_event(int ev) {
+    const int32_t* E = sec(MGX_SEC_EVENTS) + ev * MGX_EV_WORDS;
+    Ctx g;
+    std::vector<int> targets = eval_query(E[MGX_EV_QUERY], g);
+    int mt = E[MGX_EV_MAX_TARGETS];
+    if (mt >= 0 && (int)targets.size() > mt) rng.shuffle(targets.data(), (uint32_t)targets.size());
+    int applied = 0;
+    for (int t : targets) {
+      if (mt >= 0 && applied >= mt) break;
+      Ctx c;
+      c.actor = c.target = t;
+      c.target_r = objs[t].r; c.target_c = objs[t].c;
+      if (apply_all(E[MGX_EV_FILTER_PC], E[MGX_EV_MUT_START], E[MGX_EV_MUT_COUNT], c)) applied++;
+    }
+    if (applied == 0 && E[MGX_EV_FALLBACK] >= 0) return execute_event(E[MGX_EV_FALLBACK]);
+    return applied;
+  }
+  void process_events() {
+    const int32_t* sc = sec(MGX_SEC_SCHEDULE);
+    size_t n = (size_t)P[MGX_H_NUM_SCHEDULE];
+    while (next_event < n && (uint32_t)sc[next_event * MGX_SC_WORDS + MGX_SC_TIMESTEP] <= step) {
+      execute_event(sc[next_event * MGX_SC_WORDS + MGX_SC_EVENT]);
+      next_event++;
+    }
+  }
+
+  // ---- AoE (core/aoe_tracker.cpp) -----------------------------------------------------------------------------
+  const int32_t* aoe(int a) const { return sec(MGX_SEC_AOES) + a * MGX_AO_WORDS; }
+  void register_aoes(int oi) {  // register_source :128-134, register_fixed :166-200, register_mobile :202-205
+    const int32_t* C = cls(objs[oi].cls);
+    for (int i = 0; i < C[MGX_C_AOE_COUNT]; i++) {
+      int a = C[MGX_C_AOE_START] + i;
+      if (aoe(a)[MGX_AO_STATIC]) fixed.push_back({oi, a, objs[oi].r, objs[oi].c, true, std::vector<uint8_t>(A, 0)});
+      else mobile.push_back({oi, a, true, std::vector<uint8_t>(A, 0)});
+    }
+  }
+  bool fixed_covers(const FixedSrc& f, int r, int c) const {
+    const int32_t* a = aoe(f.aoe);
+    long range = a[MGX_AO_RADIUS], dr = r - f.r, dc = c - f.c;
+    if (dr < -range || dr > range || dc < -range || dc > range) return false;
+    long d2 = dr * dr + dc * dc;
+    if (d2 > range * range) return false;
+    bool territory_style = a[MGX_AO_MUT_COUNT] == 0 && a[MGX_AO_PRES_COUNT] == 0 && range > 0;
+    if (territory_style && range >= 2 && d2 == range * range && (dr == 0 || dc == 0)) return false;
+    return true;
+  }
+  void presence(int a, int target, int mult) {  // apply_presence_deltas :122-126
+    const int32_t* A_ = aoe(a);
+    const int32_t* pr = sec(MGX_SEC_PRESENCE) + A_[MGX_AO_PRES_START] * MGX_PR_WORDS;
+    for (int i = 0; i < A_[MGX_AO_PRES_COUNT]; i++, pr += MGX_PR_WORDS) inv_update(target, pr[MGX_PR_RESOURCE], pr[MGX_PR_DELTA] * mult);
+  }
+  void apply_fixed(int ai) {  // :278-362
+    int tgt = agents[ai].obj;
+    Deferred D;
+    Ctx tc;
+    tc.actor = MGX_SLOT_NONE; tc.target = tgt; tc.deferred = &D;
+    int r = objs[tgt].r, c = objs[tgt].c;
+    // exits: sources the target was inside whose cell list no longer holds the target's cell.  The reference walks
+    // an unordered_set<AOESource*> here (address order); registration order is used instead.
+    for (auto& f : fixed)
+      if (f.alive && f.inside[ai] && !fixed_covers(f, r, c)) { f.inside[ai] = 0; presence(f.aoe, tgt, -1); }
+    for (auto& f : fixed) {
+      if (!f.alive || !fixed_covers(f, r, c)) continue;
+      const int32_t* a = aoe(f.aoe);
+      if (a[MGX_AO_MUT_COUNT] == 0 && a[MGX_AO_PRES_COUNT] == 0) continue;
+      bool skip_self = !a[MGX_AO_EFFECT_SELF] && f.obj == tgt;
+      Ctx fc = tc; fc.actor = f.obj;
+      bool passes = !skip_self && check_filters(a[MGX_AO_FILTER_PC], fc);
+      bool was = f.inside[ai];
+      if (passes && !was) { f.inside[ai] = 1; presence(f.aoe, tgt, +1); }
+      else if (!passes && was) { f.inside[ai] = 0; presence(f.aoe, tgt, -1); }
+      if (passes && a[MGX_AO_MUT_COUNT] > 0) { Ctx ac = tc; ac.actor = f.obj; apply_all(a[MGX_AO_FILTER_PC], a[MGX_AO_MUT_START], a[MGX_AO_MUT_COUNT], ac); }
+    }
+    for (int k = 0; k < D.n; k++)
+      if (D.delta[D.order[k]] != 0) inv_update(tgt, D.order[k], D.delta[D.order[k]]);
+  }
+  void apply_mobile() {  // :364-415
+    for (auto& m : mobile) {
+      if (!m.alive) continue;
+      const int32_t* a = aoe(m.aoe);
+      long range = a[MGX_AO_RADIUS];
+      for (int ai = 0; ai < A; ai++) {
+        int tgt = agents[ai].obj;
+        if (!a[MGX_AO_EFFECT_SELF] && m.obj == tgt) continue;
+        bool was = m.inside[ai];
+        long dr = objs[m.obj].r - objs[tgt].r, dc = objs[m.obj].c - objs[tgt].c;
+        if (dr * dr + dc * dc > range * range) {
+          if (was) { m.inside[ai] = 0; presence(m.aoe, tgt, -1); }
+          continue;
+        }
+        Ctx c; c.actor = m.obj; c.target = tgt;
+        if (check_filters(a[MGX_AO_FILTER_PC], c)) {
+          if (!was) { m.inside[ai] = 1; presence(m.aoe, tgt, +1); }
+          if (a[MGX_AO_MUT_COUNT] > 0) { Ctx ac; ac.actor = m.obj; ac.target = tgt; apply_all(a[MGX_AO_FILTER_PC], a[MGX_AO_MUT_START], a[MGX_AO_MUT_COUNT], ac); }
+        } else if (was) {
+          m.inside[ai] = 0; presence(m.aoe, tgt, -1);
+        }
+      }
+    }
+  }
+
+  // ---- territory (core/territory_tracker.cpp) -----------------------------------------------------------------
+  const int32_t* tctrl(int i) const { return sec(MGX_SEC_TERR_CONTROLS) + i * MGX_TC_WORDS; }
+  void register_territory(int oi) {  // register_source :102-127
+    const int32_t* C = cls(objs[oi].cls);
+    for (int i = 0; i < C[MGX_C_TERR_COUNT]; i++) terr.push_back({oi, C[MGX_C_TERR_START] + i, objs[oi].r, objs[oi].c});
+  }
+  void territory_moved(int oi, int, int) {  // notify_source_moved :187-199: entries re-registered at the end
+    std::vector<TerrSrc> mine;
+    for (size_t i = 0; i < terr.size();)
+      if (terr[i].obj == oi) { mine.push_back(terr[i]); terr.erase(terr.begin() + i); } else i++;
+    for (auto t : mine) { t.r = objs[oi].r; t.c = objs[oi].c; terr.push_back(t); }
+  }
+  static uint64_t floor_sqrt_u64(uint64_t value) {  // :17-33
+    uint64_t root = 0, bit = 1ULL << 62;
+    while (bit > value) bit >>= 2;
+    while (bit != 0) {
+      if (value >= root + bit) { value -= root + bit; root = (root >> 1) + bit; } else root >>= 1;
+      bit >>= 2;
+    }
+    return root;
+  }
+  int cell_owner(int r, int c, int ti) const {  // compute_cell_ownership :215-252 -> winning tag or -1
+    const int32_t* TE = sec(MGX_SEC_TERRITORIES) + ti * MGX_TE_WORDS;
+    const int32_t* prefix = sec(MGX_SEC_WORDLIST) + TE[MGX_TE_TAGS_START];
+    int64_t score[256];
+    bool used[256] = {false};
+    for (const auto& t : terr) {
+      const int32_t* tc = tctrl(t.ctrl);
+      if (tc[MGX_TC_TERRITORY] != ti) continue;
+      int strength = tc[MGX_TC_STRENGTH], decay = tc[MGX_TC_DECAY];
+      long range = decay > 0 ? strength / decay : strength;
+      long dr = r - t.r, dc = c - t.c;
+      if (dr < -range || dr > range || dc < -range || dc > range || dr * dr + dc * dc > range * range) continue;
+      int tag = -1;
+      for (int k = 0; k < TE[MGX_TE_TAGS_COUNT]; k++) if (has_tag(t.obj, prefix[k])) { tag = prefix[k]; break; }
+      if (tag < 0) continue;
+      long sr = objs[t.obj].r - r, sc = objs[t.obj].c - c;  // score uses the source's CURRENT location
+      uint64_t d2 = (uint64_t)(sr * sr + sc * sc);
+      int64_t sc_ = (int64_t)strength * 1024 - (int64_t)decay * (int64_t)floor_sqrt_u64(d2 * 1024ull * 1024ull);
+      if (sc_ > 0) { if (!used[tag]) { used[tag] = true; score[tag] = 0; } score[tag] += sc_; }
+    }
+    int win = -1; int64_t best = 0; bool tied = false;
+    for (int t = 0; t < 256; t++) {
+      if (!used[t]) continue;
+      if (score[t] > best) { win = t; best = score[t]; tied = false; }
+      else if (score[t] == best && win >= 0) tied = true;
+    }
+    return tied ? -1 : win;
+  }
+  void run_territory_handlers(int start, int count, int tag, int tgt) {
+    for (int i = 0; i < count; i++) {
+      const int32_t* hd = sec(MGX_SEC_HANDLERS) + (start + i) * MGX_HD_WORDS;
+      Ctx c; c.actor = MGX_SLOT_PROXY; c.proxy_tag = tag; c.target = tgt; c.target_r = objs[tgt].r; c.target_c = objs[tgt].c;
+      apply_all(hd[MGX_HD_FILTER_PC], hd[MGX_HD_MUT_START], hd[MGX_HD_MUT_COUNT], c);
+    }
+  }
+  void apply_territory(int ai) {  // apply_effects :275-346
+    int NT = P[MGX_H_NUM_TERRITORIES];
+    int tgt = agents[ai].obj;
+    for (int ti = 0; ti < NT; ti++) {
+      const int32_t* TE = sec(MGX_SEC_TERRITORIES) + ti * MGX_TE_WORDS;
+      int cur = cell_owner(objs[tgt].r, objs[tgt].c, ti);
+      int prev = terr_prev[ai * NT + ti];
+      if (prev != cur && prev >= 0) run_territory_handlers(TE[MGX_TE_EXIT_START], TE[MGX_TE_EXIT_COUNT], prev, tgt);
+      if (prev != cur && cur >= 0) run_territory_handlers(TE[MGX_TE_ENTER_START], TE[MGX_TE_ENTER_COUNT], cur, tgt);
+      terr_prev[ai * NT + ti] = cur;
+      if (cur >= 0) run_territory_handlers(TE[MGX_TE_PRES_START], TE[MGX_TE_PRES_COUNT], cur, tgt);
+    }
+  }
+  int tile_observability(int r, int c, int observer) const {  // compute_observability_at :254-273
+    for (int ti = 0; ti < P[MGX_H_NUM_TERRITORIES]; ti++) {
+      int w = cell_owner(r, c, ti);
+      if (w < 0) continue;
+      return has_tag(observer, w) ? 1 : 2;
+    }
+    return 0;
   }
 
   // ---- actions ------------------------------------------------------------------------------------------------
@@ -471,7 +917,7 @@ struct Engine {
     int n = 0;
     const int32_t* C = cls(o.cls);
     for (int t = 0; t < 256; t++)
-      if ((uint32_t)C[MGX_C_TAGS + (t >> 5)] & (1u << (t & 31))) out[n++] = {(uint8_t)feat(MGX_F_TAG), (uint8_t)t};
+      if (o.tags[t >> 5] & (1u << (t & 31))) out[n++] = {(uint8_t)feat(MGX_F_TAG), (uint8_t)t};
     if (o.vibe != 0) out[n++] = {(uint8_t)feat(MGX_F_VIBE), (uint8_t)o.vibe};
     for (int k = 0; k < o.norder; k++) {  // systems/observation_encoder.hpp:198-225, encoding_utils.hpp:39-62
       int item = o.order[k];
@@ -517,7 +963,8 @@ struct Engine {
     }
     for (int i = 0; i < P[MGX_H_NUM_OBS_VALUES]; i++) {  // mettagrid_c.cpp:1207-1238
       const int32_t* V = sec(MGX_SEC_OBS_VALUES) + i * MGX_OV_WORDS;
-      float raw = eval_code(V[MGX_OV_GV_START], V[MGX_OV_GV_COUNT], ag.obj);
+      Ctx vc; vc.actor = vc.target = ag.obj;
+      float raw = eval_code(V[MGX_OV_GV_START], V[MGX_OV_GV_COUNT], ag.obj, vc);
       uint32_t rem = (uint32_t)raw;
       int f = V[MGX_OV_FEATURE];
       put(0xFE, f, rem % base);
@@ -532,6 +979,10 @@ struct Engine {
       int r = me.r + offs[k * 2], c = me.c + offs[k * 2 + 1];
       if (r < 0 || c < 0 || r >= H || c >= W) continue;
       int oi = grid[r * W + c] - 1;
+      if (feat(MGX_F_AOE_MASK) != 0) {  // _emit_tile_observability_tokens :337-362
+        int mask = tile_observability(r, c, ag.obj);
+        if (mask != 0) put((uint8_t)(((r - me.r + hr) << 4) | (c - me.c + wr)), feat(MGX_F_AOE_MASK), mask);
+      }
       if (oi < 0) continue;
       Obj& o = objs[oi];
       if (o.visited < step) {  // mettagrid_c.cpp:789-796
@@ -598,6 +1049,7 @@ struct Engine {
           ag.reward_prev.assign(C[MGX_C_REWARD_COUNT], 0.f);
           agents.push_back(std::move(ag));
         }
+        for (int w = 0; w < MGX_TAG_WORDS; w++) o.tags[w] = (uint32_t)C[MGX_C_TAGS + w];
         objs.push_back(o);
         grid[r * W + c] = oi + 1;
         const int32_t* ii = sec(MGX_SEC_INIT_INV) + C[MGX_C_INIT_INV_START] * MGX_II_WORDS;
@@ -608,7 +1060,14 @@ struct Engine {
             agents[objs[oi].agent].stats.set(wk(MGX_S_RES_AMOUNT_BASE) + ii[MGX_II_ITEM], (float)ii[MGX_II_AMOUNT]);
         }
         game.add(C[MGX_C_OBJECTS_STAT], 1.f);
+        for (int t = 0; t < 256; t++) if (has_tag(oi, t)) tag_lists[t].push_back(oi);  // TagIndex::register_object
       }
+    // AoE / territory registration happens per object in creation order, after every agent exists so that the
+    // per-agent "inside" vectors have their final size (mettagrid_c.cpp:249-257).
+    A = (int)agents.size();
+    for (int oi = 0; oi < (int)objs.size(); oi++) { register_aoes(oi); register_territory(oi); }
+    terr_prev.assign((size_t)A * std::max(1, P[MGX_H_NUM_TERRITORIES]), -1);
+    compute_all_queries();  // mettagrid_c.cpp:162-163
     for (auto& ag : agents) {
       track_coverage(ag);  // Agent::init -> reset_coverage_tracking (agent.cpp:25-28,41-47)
       const int32_t* C = cls(objs[ag.obj].cls);
@@ -657,10 +1116,17 @@ struct Engine {
           if (handle_action(ai, a)) { executed[ai] = a; action_success[ai] = 1; }
         }
     }
+    process_events();  // mettagrid_c.cpp:1009-1011
     for (auto& ag : agents) {  // per-agent on_tick (mettagrid_c.cpp:1019-1024)
       int h = cls(objs[ag.obj].cls)[MGX_C_ON_TICK];
       if (h >= 0) { Ctx c; c.actor = c.target = ag.obj; apply_handler(h, c); }
     }
+    for (int ai = 0; ai < A; ai++) {  // mettagrid_c.cpp:1032-1035
+      apply_fixed(ai);
+      apply_territory(ai);
+    }
+    apply_mobile();  // :1038
+    if (P[MGX_H_GAME_ON_TICK] >= 0) { Ctx c; apply_handler(P[MGX_H_GAME_ON_TICK], c); }  // :1050-1052
     for (auto& ag : agents) track_coverage(ag);
     compute_observations(executed);
     for (int i = 0; i < A; i++) {  // systems/reward.hpp:56-77
@@ -670,7 +1136,8 @@ struct Engine {
       if (C[MGX_C_REWARD_COUNT] == 0) continue;
       float total = 0.f;
       for (int k = 0; k < C[MGX_C_REWARD_COUNT]; k++, rw += MGX_RW_WORDS) {
-        float val = eval_code(rw[MGX_RW_GV_START], rw[MGX_RW_GV_COUNT], ag.obj);
+        Ctx vc; vc.actor = vc.target = ag.obj;
+        float val = eval_code(rw[MGX_RW_GV_START], rw[MGX_RW_GV_COUNT], ag.obj, vc);
         if (rw[MGX_RW_ACCUMULATE]) total += val;
         else total += val - ag.reward_prev[k];
         ag.reward_prev[k] = val;
@@ -706,16 +1173,17 @@ const uint8_t* mgxo_action_success(void* h) { return ((Engine*)h)->action_succes
 int mgxo_error(void* h) { return ((Engine*)h)->error; }
 uint32_t mgxo_current_step(void* h) { return ((Engine*)h)->step; }
 int mgxo_num_objects(void* h) { return (int)((Engine*)h)->objs.size(); }
-// Per object record, int32 x (8 + 2*MGX_MAX_RESOURCES): id, class, r, c, vibe, alive, agent_id, norder,
-// order[13], amounts-by-item[13]
+// Per object record, int32 x (8 + 2*MGX_MAX_RESOURCES + MGX_TAG_WORDS): id, class, r, c, vibe, alive, agent_id,
+// norder, order[13], amounts-by-item[13], tag words[8]
 void mgxo_objects(void* h, int32_t* out) {
   Engine* e = (Engine*)h;
-  const int RW = 8 + 2 * MGX_MAX_RESOURCES;
+  const int RW = 8 + 2 * MGX_MAX_RESOURCES + MGX_TAG_WORDS;
   for (size_t i = 0; i < e->objs.size(); i++) {
     const Obj& o = e->objs[i];
     int32_t* w = out + i * RW;
     w[0] = (int)i + 1; w[1] = o.cls; w[2] = o.r; w[3] = o.c; w[4] = o.vibe; w[5] = o.alive; w[6] = o.agent; w[7] = o.norder;
     for (int k = 0; k < MGX_MAX_RESOURCES; k++) { w[8 + k] = k < o.norder ? o.order[k] : -1; w[8 + MGX_MAX_RESOURCES + k] = o.inv[k]; }
+    for (int k = 0; k < MGX_TAG_WORDS; k++) w[8 + 2 * MGX_MAX_RESOURCES + k] = (int32_t)o.tags[k];
   }
 }
 void mgxo_stats(void* h, float* game_v, uint8_t* game_t, float* agent_v, uint8_t* agent_t) {

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.path.join(_HERE, "libmgx_oracle.so")
 _lib = None
 _MAXR = 13
-_RW = 8 + 2 * _MAXR
+_RW = 8 + 2 * _MAXR + 8
 
 
 def build(force: bool = False) -> str:

@@ -95,39 +95,105 @@ class _Lower:
             c = m.MinValueConfig()
             c.values = [self.value(x) for x in v.values]
             return c
+        if isinstance(v, S.QueryInventoryValue):
+            c = m.QueryInventoryValueConfig()
+            c.id = self.res[v.item]
+            c.set_query(self.query(v.query))
+            return c
+        if isinstance(v, S.QueryCountValue):
+            c = m.QueryCountValueConfig()
+            c.set_query(self.query(v.query))
+            return c
         raise TypeError(v)
 
-    # ---- filters ----
-    def add_filter(self, holder, f):
+    # ---- queries ----
+    def query(self, q):
         m = self.m
+        if isinstance(q, str):
+            q = S.TagQuery(q)
+        if isinstance(q, S.MaterializedQuery):
+            q = S.TagQuery(q.tag)
+        if isinstance(q, S.TagQuery):
+            c = m.TagQueryConfig()
+            c.tag_id = self.tag[q.tag]
+            for f in q.filters:
+                self.add_filter(c, f)
+        elif isinstance(q, S.FilteredQuery):
+            c = m.FilteredQueryConfig()
+            c.set_source(self.query(q.source))
+            for f in q.filters:
+                self.add_filter(c, f)
+        elif isinstance(q, S.ClosureQuery):
+            c = m.ClosureQueryConfig()
+            c.set_source(self.query(q.source))
+            if q.candidates is not None:
+                c.set_candidates(self.query(q.candidates))
+            for f in q.edge_filters:
+                self.add_filter(c, f, "edge_")
+            for f in q.result_filters:
+                self.add_filter(c, f, "result_")
+        elif isinstance(q, S.RaycastQuery):
+            c = m.RaycastQueryConfig()
+            c.set_source(self.query(q.source))
+            c.max_range = self.value(q.max_range)
+            c.directions = [tuple(d) for d in q.directions]
+            c.include_blocker = bool(q.include_blocker)
+            for f in q.blocker:
+                self.add_filter(c, f, "blocker_")
+        else:
+            raise TypeError(q)
+        if q.max_items is not None:
+            c.max_items = self.value(q.max_items)
+        if q.order_by == "random":
+            c.order_by = m.QueryOrderBy.random
+        return m.make_query_config(c)
+
+    # ---- filters ----
+    def add_filter(self, holder, f, prefix=""):
+        m = self.m
+
+        def add(kind, cfg):
+            getattr(holder, f"add_{prefix}{kind}_filter")(cfg)
+
         if isinstance(f, S.VibeFilter):
             if f.vibe in self.vibe:
-                holder.add_vibe_filter(m.VibeFilterConfig(self.ent(f.entity), self.vibe[f.vibe]))
+                add("vibe", m.VibeFilterConfig(self.ent(f.entity), self.vibe[f.vibe]))
         elif isinstance(f, S.ResourceFilter):
-            holder.add_resource_filter(m.ResourceFilterConfig(self.ent(f.entity), self.res[f.resource], f.min_amount))
+            add("resource", m.ResourceFilterConfig(self.ent(f.entity), self.res[f.resource], f.min_amount))
         elif isinstance(f, S.SharedTagPrefixFilter):
-            holder.add_shared_tag_prefix_filter(m.SharedTagPrefixFilterConfig(self.prefix(f.prefix)))
+            add("shared_tag_prefix", m.SharedTagPrefixFilterConfig(self.prefix(f.prefix)))
         elif isinstance(f, S.TagPrefixFilter):
-            holder.add_tag_prefix_filter(m.TagPrefixFilterConfig(self.ent(f.entity), self.prefix(f.prefix)))
+            add("tag_prefix", m.TagPrefixFilterConfig(self.ent(f.entity), self.prefix(f.prefix)))
         elif isinstance(f, S.NegFilter):
             n = m.NegFilterConfig()
             for g in f.inner:
                 self.add_filter(n, g)
-            holder.add_neg_filter(n)
+            add("neg", n)
         elif isinstance(f, S.OrFilter):
             o = m.OrFilterConfig()
             for g in f.inner:
                 self.add_filter(o, g)
-            holder.add_or_filter(o)
+            add("or", o)
         elif isinstance(f, S.TargetLocEmptyFilter):
-            holder.add_target_loc_empty_filter(m.TargetLocEmptyFilterConfig())
+            add("target_loc_empty", m.TargetLocEmptyFilterConfig())
         elif isinstance(f, S.TargetIsUsableFilter):
-            holder.add_target_is_usable_filter(m.TargetIsUsableFilterConfig())
+            add("target_is_usable", m.TargetIsUsableFilterConfig())
         elif isinstance(f, S.PeriodicFilter):
-            holder.add_periodic_filter(m.PeriodicFilterConfig(f.period, f.period if f.start_on is None else f.start_on))
+            add("periodic", m.PeriodicFilterConfig(f.period, f.period if f.start_on is None else f.start_on))
         elif isinstance(f, S.GameValueFilter):
-            holder.add_game_value_filter(
-                m.GameValueFilterConfig(self.value(f.value), self.value(f.threshold), self.ent(f.entity)))
+            add("game_value", m.GameValueFilterConfig(self.value(f.value), self.value(f.threshold), self.ent(f.entity)))
+        elif isinstance(f, S.MaxDistanceFilter):
+            c = m.MaxDistanceFilterConfig()
+            c.entity = self.ent(f.entity)
+            c.radius = f.radius
+            if f.source is not None:
+                c.set_source(self.query(f.source))
+            add("max_distance", c)
+        elif isinstance(f, S.QueryResourceFilter):
+            c = m.QueryResourceFilterConfig()
+            c.requirements = [(self.res[r], v) for r, v in f.requirements.items()]
+            c.set_query(self.query(f.query))
+            add("query_resource", c)
         else:
             raise TypeError(f)
 
@@ -153,6 +219,28 @@ class _Lower:
             hc.add_stats_mutation(c)
         elif isinstance(mu, S.ChangeVibe):
             hc.add_change_vibe_mutation(m.ChangeVibeMutationConfig(self.ent(mu.entity), self.vibe[mu.vibe]))
+        elif isinstance(mu, S.AddTag):
+            hc.add_add_tag_mutation(m.AddTagMutationConfig(self.ent(mu.entity), self.tag[mu.tag]))
+        elif isinstance(mu, S.RemoveTag):
+            hc.add_remove_tag_mutation(m.RemoveTagMutationConfig(self.ent(mu.entity), self.tag[mu.tag]))
+        elif isinstance(mu, S.RemoveTagsWithPrefix):
+            hc.add_remove_tags_with_prefix_mutation(
+                m.RemoveTagsWithPrefixMutationConfig(self.ent(mu.entity), self.prefix(mu.prefix)))
+        elif isinstance(mu, S.GameValueMutation):
+            hc.add_game_value_mutation(m.GameValueMutationConfig(self.value(mu.value), self.ent(mu.target), self.value(mu.source)))
+        elif isinstance(mu, S.RecomputeMaterializedQuery):
+            c = m.RecomputeMaterializedQueryMutationConfig()
+            c.tag_id = self.tag[mu.tag]
+            hc.add_recompute_materialized_query_mutation(c)
+        elif isinstance(mu, S.QueryInventoryMutation):
+            c = m.QueryInventoryMutationConfig()
+            c.deltas = [(self.res[r], d) for r, d in mu.deltas.items()]
+            if mu.source is not None:
+                c.source = self.ent(mu.source)
+                c.has_source = True
+            c.transfer_stat_names = [(self.res[r], n) for r, n in mu.transfer_stat_names.items()]
+            c.set_query(self.query(mu.query))
+            hc.add_query_inventory_mutation(c)
         elif isinstance(mu, S.Relocate):
             hc.add_relocate_mutation(m.RelocateMutationConfig())
         elif isinstance(mu, S.Swap):
@@ -181,6 +269,35 @@ class _Lower:
             return None
         mode = m.HandlerMode.FirstMatch if isinstance(h, S.FirstMatch) else m.HandlerMode.All
         return m.MultiHandler(kids, mode)
+
+    def object_extras(self, cfg, src):
+        m = self.m
+        if src.aoes:
+            lst = []
+            for a in src.aoes:
+                c = m.AOEConfig()
+                c.name = "aoe"
+                c.radius, c.is_static, c.effect_self = a.radius, a.is_static, a.effect_self
+                for f in a.filters:
+                    self.add_filter(c, f)
+                for mu in a.mutations:
+                    self.add_mutation(c, mu)
+                c.presence_deltas = [m.ResourceDelta(self.res[r], d) for r, d in a.presence_deltas.items()]
+                lst.append(c)
+            cfg.aoe_configs = lst
+        if src.territory_controls:
+            names = list(self.spec.territories.keys())
+            lst = []
+            for tc in src.territory_controls:
+                c = m.TerritoryControlConfig()
+                c.strength, c.decay, c.territory_index = tc.strength, tc.decay, names.index(tc.territory)
+                lst.append(c)
+            cfg.territory_controls = lst
+        for mapping, adder in ((src.on_tag_add, cfg.add_on_tag_add_handler), (src.on_tag_remove, cfg.add_on_tag_remove_handler)):
+            for prefix, h in mapping.items():
+                hc = self.handler_config(S.Handler(h.filters, h.mutations, prefix))
+                for t in self.prefix(prefix):
+                    adder(t, hc)
 
     # ---- inventory ----
     def limit_defs_agent(self, a: S.AgentSpec, default_limit: int):
@@ -224,6 +341,7 @@ class _Lower:
                 cfg.on_tick = self.handler(a.on_tick)
                 cfg.on_use_handler = self.handler(a.on_use)
                 cfg.on_after_use_handler = self.handler(a.on_after_use)
+                self.object_extras(cfg, a)
                 objects[f"agent.{gname}.{idx}"] = cfg
                 first = first or cfg
             aliases = [f"agent.{gname}", f"agent.team_{gid}"]
@@ -256,6 +374,7 @@ class _Lower:
                         cfg.inventory_config = inv
                 cfg.on_use_handler = self.handler(o.on_use)
             cfg.tag_ids = [self.tag[t] for t in list(o.tags) + [type_tag(o.name)]]
+            self.object_extras(cfg, o)
             objects[o.cell] = cfg
 
         obs = sp.obs
@@ -281,7 +400,43 @@ class _Lower:
                 required_resources={}, consumed_resources={},
                 number_of_vibes=len(sp.vibe_names) if sp.change_vibe_enabled else 0),
         }
+        extra = {}
+        if sp.territories:
+            terr = []
+            for _name, tc in sp.territories.items():
+                c = m.TerritoryConfig()
+                c.tag_prefix_ids = self.prefix(tc.tag_prefix)
+                c.on_enter = [self.handler_config(S.Handler(h.filters, h.mutations, "on_enter")) for h in tc.on_enter]
+                c.on_exit = [self.handler_config(S.Handler(h.filters, h.mutations, "on_exit")) for h in tc.on_exit]
+                c.presence = [self.handler_config(S.Handler(h.filters, h.mutations, "presence")) for h in tc.presence]
+                terr.append(c)
+            extra["territories"] = terr
+        if sp.events:
+            evs = {}
+            for name, ev in sp.events.items():
+                c = m.EventConfig(name)
+                c.timesteps = [int(t) for t in ev.timesteps]
+                c.max_targets = -1 if ev.max_targets is None else int(ev.max_targets)
+                c.fallback = ev.fallback or ""
+                c.set_target_query(self.query(ev.target_query))
+                for f in ev.filters:
+                    self.add_filter(c, f)
+                for mu in ev.mutations:
+                    self.add_mutation(c, mu)
+                evs[name] = c
+            extra["events"] = evs
+        if sp.materialize_queries:
+            mqs = []
+            for mq in sp.materialize_queries:
+                c = m.MaterializedQueryTag()
+                c.tag_id = self.tag[mq.tag]
+                c.set_query(self.query(mq.query))
+                mqs.append(c)
+            extra["materialized_queries"] = mqs
+        if sp.on_tick is not None:
+            extra["on_tick"] = self.handler(sp.on_tick)
         return m.GameConfig(
+            **extra,
             num_agents=len(sp.agents), max_steps=sp.max_steps, episode_truncates=sp.episode_truncates,
             obs_width=obs.width, obs_height=obs.height, resource_names=list(sp.resource_names),
             vibe_names=list(sp.vibe_names), num_observation_tokens=obs.num_tokens, global_obs=gobs,

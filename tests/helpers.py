@@ -134,3 +134,93 @@ def diff_payload(pa: dict, pb: dict) -> str:
             else:
                 out.append(f"{k}: {pa[k]} vs {pb[k]}")
     return "; ".join(out)
+
+
+def rung4_spec(max_steps: int = 0) -> S.GameSpec:
+    """Rung 4: static + mobile AoE, a territory type with enter/exit/presence handlers and the aoe_mask
+    token, timestep events (max_targets with the shared RNG, a fallback, a once event), tag mutations with a
+    lifecycle handler, a materialized closure query that an event recomputes, query values/filters/mutations."""
+    A, T = S.ACTOR, S.TARGET
+    teams = ["red", "blue", "green"]
+
+    def agent(team: int, i: int) -> S.AgentSpec:
+        return S.AgentSpec(
+            team_id=team, tags=[f"team:{teams[team]}"],
+            inventory=S.Inventory(initial={"hp": 50, "energy": 10}, default_limit=200,
+                                  limits=[S.Limit(["shield"], base=3)]),
+            rewards=[S.RewardSpec(S.InventoryValue("hp")), S.RewardSpec(S.StatValue("zone.entered", "agent")),
+                     S.RewardSpec(S.QueryCountValue(S.TagQuery("marked")), per_tick=True)],
+            aoes=[S.AOESpec(radius=1, is_static=False, filters=[S.NegFilter([S.SharedTagPrefixFilter("team:")])],
+                            mutations=[S.ResourceDelta(T, "hp", -1)])],
+            on_tag_add={"marked": S.Handler([], [S.ResourceDelta(T, "energy", 5)], "marked_bonus")},
+            on_tag_remove={"marked": S.Handler([], [S.ResourceDelta(T, "energy", -1)], "unmarked")},
+            on_use=S.FirstMatch([
+                S.Handler([S.NegFilter([S.SharedTagPrefixFilter("team:")])],
+                          [S.AddTag(T, "marked"), S.GameValueMutation(S.InventoryValue("energy"), S.ConstValue(-2.0), A),
+                           S.GameValueMutation(S.StatValue("tags.given", "agent"), S.ConstValue(1.0), A)], "mark"),
+                S.Handler([], [S.Swap()], "swap")]))
+
+    heal = S.AOESpec(radius=3, filters=[S.TagPrefixFilter(T, "team:")],
+                     mutations=[S.ResourceDelta(T, "hp", 2), S.ResourceDelta(T, "energy", -1)],
+                     presence_deltas={"shield": 1})
+    burn = S.AOESpec(radius=2, filters=[], mutations=[S.ResourceDelta(T, "hp", -3)])
+    zone = S.TerritorySpec(
+        tag_prefix="team:",
+        on_enter=[S.Handler([], [S.SetStat("zone.entered", S.SumValue([S.StatValue("zone.entered", "agent"), S.ConstValue(1.0)]),
+                                           scope="agent", entity=T)])],
+        on_exit=[S.Handler([S.SharedTagPrefixFilter("team:")], [S.ResourceDelta(T, "energy", -1)])],
+        presence=[S.Handler([S.SharedTagPrefixFilter("team:")], [S.ResourceDelta(T, "energy", 1)]),
+                  S.Handler([S.NegFilter([S.SharedTagPrefixFilter("team:")])], [S.ResourceDelta(T, "hp", -1)])])
+
+    def flag(team: str) -> S.ObjectSpec:
+        return S.ObjectSpec(name=f"flag_{team}", tags=[f"team:{team}"],
+                            territory_controls=[S.TerritoryControl("zone", strength=4, decay=1)])
+
+    events = {
+        "supply": S.EventSpec(S.TagQuery("type:agent"), list(range(5, 200, 10)), [S.ResourceFilter(T, "hp", 1)],
+                              [S.ResourceDelta(T, "energy", 3)], max_targets=4),
+        "purge": S.EventSpec(S.TagQuery("marked"), [12, 30, 31, 60], [], [S.RemoveTag(T, "marked")], fallback="mercy"),
+        "mercy": S.EventSpec(S.TagQuery("type:agent", max_items=2, order_by="random"), [],
+                             [], [S.ResourceDelta(T, "hp", 4)]),
+        "rewire": S.EventSpec(S.TagQuery("type:hub"), [8, 25, 50], [], [S.RecomputeMaterializedQuery("net")]),
+        "tax": S.EventSpec(S.TagQuery("type:hub"), [20, 40],
+                           # EventConfig has no add_query_resource_filter binding; NOT(NOT(x)) carries it
+                           [S.NegFilter([S.NegFilter([S.QueryResourceFilter(S.TagQuery("type:agent"), {"energy": 30})])])],
+                           [S.QueryInventoryMutation(S.FilteredQuery(S.TagQuery("type:agent"), [S.MaxDistanceFilter(T, 6, S.TagQuery("type:hub"))]),
+                                                     {"energy": -2}, source=T, transfer_stat_names={"energy": "tax.energy"})]),
+        "beam": S.EventSpec(S.RaycastQuery(S.TagQuery("type:hub"), max_range=5, blocker=[S.TagPrefixFilter(T, "type:wall")],
+                                           include_blocker=False), [15, 35], [S.TagPrefixFilter(T, "team:")],
+                            [S.ResourceDelta(T, "hp", -2), S.RemoveTagsWithPrefix(T, "mark")]),
+    }
+    return S.GameSpec(
+        resource_names=["hp", "energy", "shield", "ore"],
+        agents=[agent(t, i) for t in range(3) for i in range(4)],
+        objects={
+            "wall": S.ObjectSpec("wall", kind="wall"),
+            "healer": S.ObjectSpec("healer", aoes=[heal]),
+            "fire": S.ObjectSpec("fire", aoes=[burn]),
+            "hub": S.ObjectSpec("hub", inventory=S.Inventory(initial={}, default_limit=1000)),
+            "wire": S.ObjectSpec("wire"),
+            "flag_red": flag("red"), "flag_blue": flag("blue"), "flag_green": flag("green"),
+        },
+        tags=["team:red", "team:blue", "team:green", "marked", "net"],
+        vibe_names=["default", "a"], change_vibe_enabled=True,
+        move_directions=["north", "south", "west", "east", "northwest", "southeast"],
+        obs=S.ObsSpec(width=9, height=9, num_tokens=160, aoe_mask=True,
+                      values={"marked_n": S.QueryCountValue(S.TagQuery("marked")),
+                              "team_hp": S.QueryInventoryValue("hp", S.FilteredQuery(S.TagQuery("type:agent"), [S.SharedTagPrefixFilter("team:")]))}),
+        events=events,
+        materialize_queries=[S.MaterializedQuery("net", S.ClosureQuery(S.TagQuery("type:hub"), S.TagQuery("type:wire"),
+                                                                       edge_filters=[S.MaxDistanceFilter(T, 2)]))],
+        territories={"zone": zone},
+        on_tick=S.Handler([S.PeriodicFilter(7, 3)], [S.SetStat("ticks7", S.SumValue([S.StatValue("ticks7", "game"), S.ConstValue(1.0)]))]),
+        max_steps=max_steps, episode_truncates=True)
+
+
+def rung4_map(seed: int) -> np.ndarray:
+    return random_map(20, 22, {"wall": 18, "healer": 3, "fire": 3, "hub": 2, "wire": 10, "flag_red": 2, "flag_blue": 2,
+                               "flag_green": 2}, {"red": 4, "blue": 4, "green": 4}, seed)
+
+
+SCENARIOS["rung4"] = (rung4_spec, rung4_map, 70, False)
+SCENARIOS["rung4_truncating"] = (lambda: rung4_spec(33), rung4_map, 36, True)
