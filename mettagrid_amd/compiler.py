@@ -151,6 +151,7 @@ class _Compiler:
         self.atom_labels: list = []  # (word index in atoms section, label)
         self.indexed_tags: set = set()
         self.query_depth = 0
+        self._qdepth = 0          # nesting level of the query currently being emitted (filters/values inherit it)
         self.dynamic_tags = False
 
     # ---- id tables -------------------------------------------------------------------------------------------
@@ -301,7 +302,16 @@ class _Compiler:
         return self.emit(K.SEC_OBS_VALUES, [start, count, feature])
 
     # ---- queries (core/query_config.hpp; converter mettagrid_c_config.py:83-180) -------------------------------
-    def query(self, q, depth: int = 1) -> int:
+    def query(self, q, depth: int | None = None) -> int:
+        depth = self._qdepth + 1 if depth is None else depth
+        prev = self._qdepth
+        self._qdepth = depth
+        try:
+            return self._query(q, depth)
+        finally:
+            self._qdepth = prev
+
+    def _query(self, q, depth: int) -> int:
         self.query_depth = max(self.query_depth, depth)
         if isinstance(q, str):
             q = S.TagQuery(q)

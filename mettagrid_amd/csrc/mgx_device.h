@@ -64,6 +64,34 @@ struct MgxDev {
   int32_t* executed;      // [E][A] action executed this step (0 = noop / failed)
   uint8_t* success;       // [E][A]
   float* episode_rewards; // [E*A]
+  // ---- extended state (rung 4: dynamic tags, tag index, AoE, territory, events, query workspace) ----
+  int X;                  // 1: extended kernels are in use
+  int NL;                 // indexed tags (TagIndex lists)
+  int NF, NM, NTS, NT;    // capacities: fixed AoE sources, mobile AoE sources, territory sources; territory types
+  int AW;                 // words of a per-source agent bitmap
+  int QB, QD;             // query workspace buffers per env, max query nesting
+  int SW;                 // words of a per-env object bitmap
+  int game_on_tick, n_events, n_schedule, n_matq, aoe_mask_feat;
+  uint32_t* obj_tags;     // [E][S][8]   GridObject::tag_bits
+  uint16_t* tl_items;     // [E][NL][S]  TagIndex lists in registration order
+  uint16_t* tl_count;     // [E][NL]
+  uint16_t* fx_obj;       // [E][NF] fixed AoE sources in registration order
+  uint16_t* fx_aoe;       // [E][NF]
+  uint16_t* fx_rc;        // [E][NF] location at registration
+  uint32_t* fx_inside;    // [E][NF][AW]
+  uint16_t* fx_count;     // [E]
+  uint16_t* mb_obj;       // [E][NM] mobile AoE sources
+  uint16_t* mb_aoe;       // [E][NM]
+  uint32_t* mb_inside;    // [E][NM][AW]
+  uint16_t* mb_count;     // [E]
+  uint16_t* ts_obj;       // [E][NTS] territory sources in registration order
+  uint16_t* ts_ctrl;      // [E][NTS]
+  uint16_t* ts_rc;        // [E][NTS] registered location
+  uint16_t* ts_count;     // [E]
+  int16_t* terr_prev;     // [E][A][NT] previous owner tag or -1
+  uint32_t* next_event;   // [E]
+  uint16_t* qws;          // [E][QB][S] query workspace
+  uint32_t* qvis;         // [E][QD+1][SW] visited bitmaps
   // ---- env-minor RNG ----
   uint32_t* mt;           // [624][E]
   uint32_t* mt_idx;       // [E]

@@ -2,6 +2,7 @@
 // gfx950 only.  There is NO CPU fallback in this library: every entry point that computes runs HIP kernels.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -66,8 +67,13 @@ struct mgx_engine {
 
 static int launch_obs(mgx_engine* e, bool with_rewards) {
   dim3 grid(e->d.E), block(MGX_OBS_THREADS);
-  if (with_rewards) hipLaunchKernelGGL(mgx_obs_kernel<true>, grid, block, e->lds_obs, e->stream, e->d, e->pool_tokens);
-  else hipLaunchKernelGGL(mgx_obs_kernel<false>, grid, block, e->lds_obs, e->stream, e->d, e->pool_tokens);
+  if (e->d.X) {
+    if (with_rewards) hipLaunchKernelGGL((mgx_obs_kernel<true, true>), grid, block, e->lds_obs, e->stream, e->d, e->pool_tokens);
+    else hipLaunchKernelGGL((mgx_obs_kernel<false, true>), grid, block, e->lds_obs, e->stream, e->d, e->pool_tokens);
+  } else {
+    if (with_rewards) hipLaunchKernelGGL((mgx_obs_kernel<true, false>), grid, block, e->lds_obs, e->stream, e->d, e->pool_tokens);
+    else hipLaunchKernelGGL((mgx_obs_kernel<false, false>), grid, block, e->lds_obs, e->stream, e->d, e->pool_tokens);
+  }
   HIP_TRY(hipGetLastError());
   return MGX_OK;
 }
@@ -140,6 +146,43 @@ int mgx_create(const int32_t* program, size_t program_words, const uint16_t* cla
   for (int c = 0; c < P[MGX_H_NUM_CLASSES]; c++)
     if (P[d.sec[MGX_SEC_CLASSES] + c * MGX_C_WORDS + MGX_C_ON_TICK] >= 0) d.any_on_tick = 1;
 
+  // ---- extended (rung 4) features: capacities come from a host scan of the class maps ----
+  d.n_events = P[MGX_H_NUM_EVENTS]; d.n_schedule = P[MGX_H_NUM_SCHEDULE]; d.n_matq = P[MGX_H_NUM_MATQ];
+  d.NT = P[MGX_H_NUM_TERRITORIES]; d.game_on_tick = P[MGX_H_GAME_ON_TICK]; d.NL = P[MGX_H_NUM_INDEXED_TAGS];
+  d.aoe_mask_feat = P[MGX_H_FEAT_BASE + MGX_F_AOE_MASK];
+  d.QD = std::max(1, (int)P[MGX_H_QUERY_DEPTH]) + 1;
+  d.QB = 3 + 2 * (d.QD + 1);
+  d.AW = (d.A + 31) / 32;
+  d.SW = (d.S + 31) / 32;
+  {
+    const int nc = P[MGX_H_NUM_CLASSES];
+    std::vector<int> cf(nc), cm(nc), ct(nc);
+    bool any_aoe = false;
+    for (int c = 0; c < nc; c++) {
+      const int32_t* C = P + d.sec[MGX_SEC_CLASSES] + c * MGX_C_WORDS;
+      for (int i = 0; i < C[MGX_C_AOE_COUNT]; i++) {
+        bool st = P[d.sec[MGX_SEC_AOES] + (C[MGX_C_AOE_START] + i) * MGX_AO_WORDS + MGX_AO_STATIC] != 0;
+        (st ? cf[c] : cm[c])++;
+        any_aoe = true;
+      }
+      ct[c] = C[MGX_C_TERR_COUNT];
+    }
+    int nf = 0, nm = 0, nts = 0;
+    const size_t hw = (size_t)d.H * d.W;
+    if (any_aoe || d.NT > 0)
+      for (int env = 0; env < num_envs; env++) {
+        int f = 0, m = 0, t = 0;
+        const uint16_t* cmap = class_maps + (size_t)env * hw;
+        for (size_t i = 0; i < hw; i++) {
+          int k = cmap[i];
+          if (k > 0 && k <= nc) { f += cf[k - 1]; m += cm[k - 1]; t += ct[k - 1]; }
+        }
+        nf = std::max(nf, f); nm = std::max(nm, m); nts = std::max(nts, t);
+      }
+    d.NF = nf; d.NM = nm; d.NTS = nts;
+    d.X = (any_aoe || d.NT > 0 || d.n_schedule > 0 || d.n_matq > 0 || d.game_on_tick >= 0 || P[MGX_H_DYNAMIC_TAGS] ||
+           mgx_sec_cnt(P, MGX_SEC_QUERIES) > 0) ? 1 : 0;
+  }
   const size_t E = d.E, HW = (size_t)d.H * d.W, S = d.S, A = d.A, rows = E * A;
   int rc = MGX_OK;
   int32_t* dprog = nullptr;
@@ -183,6 +226,20 @@ int mgx_create(const int32_t* program, size_t program_words, const uint16_t* cla
   A_(e->alloc(&e->own_rew, rows));
   A_(e->alloc(&e->own_act, rows));
   A_(e->alloc(&e->own_vact, rows));
+  if (d.X) {
+    if (P[MGX_H_DYNAMIC_TAGS]) A_(e->alloc(&d.obj_tags, E * S * MGX_TAG_WORDS));
+    if (d.NL) { A_(e->alloc(&d.tl_items, E * d.NL * S)); A_(e->alloc(&d.tl_count, E * d.NL)); }
+    if (d.NF) { A_(e->alloc(&d.fx_obj, E * d.NF)); A_(e->alloc(&d.fx_aoe, E * d.NF)); A_(e->alloc(&d.fx_rc, E * d.NF));
+                A_(e->alloc(&d.fx_inside, E * d.NF * d.AW)); A_(e->alloc(&d.fx_count, E)); }
+    if (d.NM) { A_(e->alloc(&d.mb_obj, E * d.NM)); A_(e->alloc(&d.mb_aoe, E * d.NM));
+                A_(e->alloc(&d.mb_inside, E * d.NM * d.AW)); A_(e->alloc(&d.mb_count, E)); }
+    if (d.NTS) { A_(e->alloc(&d.ts_obj, E * d.NTS)); A_(e->alloc(&d.ts_ctrl, E * d.NTS)); A_(e->alloc(&d.ts_rc, E * d.NTS));
+                 A_(e->alloc(&d.ts_count, E)); }
+    A_(e->alloc(&d.terr_prev, rows * std::max(1, d.NT)));
+    A_(e->alloc(&d.next_event, E));
+    A_(e->alloc(&d.qws, E * d.QB * S));
+    A_(e->alloc(&d.qvis, E * (d.QD + 1) * d.SW));
+  }
   A_(e->alloc(&dmaps, E * HW));
   A_(e->alloc(&dseeds, E));
 #undef A_
@@ -191,7 +248,7 @@ int mgx_create(const int32_t* program, size_t program_words, const uint16_t* cla
   d.obs = e->own_obs; d.terminals = e->own_term; d.truncations = e->own_trunc; d.rewards = e->own_rew;
   d.actions = e->own_act; d.vibe_actions = e->own_vact;
 
-  e->lds_world = (size_t)((d.A * MGX_WAVE + 15) & ~15);
+  e->lds_world = (size_t)mgx_world_lds_fixed(d.A, d.X != 0);
   e->prog_in_lds = program_words * 4 + e->lds_world <= 36 * 1024;  // 4 workgroups per CU keep their copy resident
   if (e->prog_in_lds) e->lds_world += program_words * 4;
   {  // LDS token pool: every object of an env caches its (feature, value) list once per step.  Upper bound per
@@ -236,13 +293,15 @@ int mgx_create(const int32_t* program, size_t program_words, const uint16_t* cla
     d.cls_tokinfo = dinfo;
     d.cls_tok = dtoks;
   }
-  e->lds_obs = (size_t)mgx_obs_lds_layout((int)HW, d.NOFF, (int)S, (int)A, d.T, e->pool_tokens).total;
+  e->lds_obs = (size_t)mgx_obs_lds_layout((int)HW, d.NOFF, (int)S, (int)A, d.T, e->pool_tokens, d.X != 0, d.n_obs_values).total;
   if (e->lds_obs > 160 * 1024 || e->lds_world > 64 * 1024) {
     mgx_destroy(e);
     return fail(MGX_ERR_PROGRAM, "mgx_create: map/object count too large for the LDS staging of the observation kernel");
   }
-  hipError_t he = hipFuncSetAttribute((const void*)mgx_obs_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_obs);
-  if (he == hipSuccess) he = hipFuncSetAttribute((const void*)mgx_obs_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_obs);
+  hipError_t he = hipFuncSetAttribute((const void*)mgx_obs_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_obs);
+  if (he == hipSuccess) he = hipFuncSetAttribute((const void*)mgx_obs_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_obs);
+  if (he == hipSuccess) he = hipFuncSetAttribute((const void*)mgx_obs_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_obs);
+  if (he == hipSuccess) he = hipFuncSetAttribute((const void*)mgx_obs_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_obs);
   if (he == hipSuccess) he = hipMemcpyAsync(dprog, program, program_words * 4, hipMemcpyHostToDevice, e->stream);
   if (he == hipSuccess) he = hipMemcpyAsync(dmaps, class_maps, E * HW * 2, hipMemcpyHostToDevice, e->stream);
   if (he == hipSuccess) he = hipMemcpyAsync(dseeds, seeds, E * 4, hipMemcpyHostToDevice, e->stream);
@@ -321,8 +380,13 @@ int mgx_step(mgx_engine* e) {
   {
     dim3 grid((d.E + MGX_WAVE - 1) / MGX_WAVE), block(MGX_WAVE);
     int pw = (int)e->prog.size();
-    if (e->prog_in_lds) hipLaunchKernelGGL(mgx_world_kernel<true>, grid, block, e->lds_world, e->stream, e->d, pw);
-    else hipLaunchKernelGGL(mgx_world_kernel<false>, grid, block, e->lds_world, e->stream, e->d, pw);
+    if (d.X) {
+      if (e->prog_in_lds) hipLaunchKernelGGL((mgx_world_kernel<true, true>), grid, block, e->lds_world, e->stream, e->d, pw);
+      else hipLaunchKernelGGL((mgx_world_kernel<false, true>), grid, block, e->lds_world, e->stream, e->d, pw);
+    } else {
+      if (e->prog_in_lds) hipLaunchKernelGGL((mgx_world_kernel<true, false>), grid, block, e->lds_world, e->stream, e->d, pw);
+      else hipLaunchKernelGGL((mgx_world_kernel<false, false>), grid, block, e->lds_world, e->stream, e->d, pw);
+    }
   }
   HIP_TRY(hipGetLastError());
   if (e->profiling) HIP_TRY(hipEventRecord(e->ev[1], e->stream));
@@ -409,6 +473,7 @@ int mgx_get_objects(mgx_engine* e, int32_t env, int32_t* out, int32_t* n_objects
   std::vector<uint16_t> cls(S), rc(S), inv(S * d.R);
   std::vector<uint8_t> vibe(S), agent(S);
   std::vector<unsigned long long> ord(S);
+  std::vector<uint32_t> tags(d.obj_tags ? S * MGX_TAG_WORDS : 0);
   uint32_t n = 0;
   int r = d2h(e, &n, d.num_objs + env, 4);
   if (!r) r = d2h(e, cls.data(), d.obj_cls + env * S, S * 2);
@@ -417,6 +482,7 @@ int mgx_get_objects(mgx_engine* e, int32_t env, int32_t* out, int32_t* n_objects
   if (!r) r = d2h(e, agent.data(), d.obj_agent + env * S, S);
   if (!r) r = d2h(e, inv.data(), d.obj_inv + env * S * d.R, S * d.R * 2);
   if (!r) r = d2h(e, ord.data(), d.obj_order + env * S, S * 8);
+  if (!r && d.obj_tags) r = d2h(e, tags.data(), d.obj_tags + env * S * MGX_TAG_WORDS, S * MGX_TAG_WORDS * 4);
   if (r) return r;
   for (uint32_t s = 0; s < n; s++) {
     int32_t* w = out + (size_t)s * MGX_OBJ_RECORD_WORDS;
@@ -431,6 +497,9 @@ int mgx_get_objects(mgx_engine* e, int32_t env, int32_t* out, int32_t* n_objects
     }
     w[7] = cnt;
     for (int k = 0; k < MGX_MAX_RESOURCES; k++) w[8 + MGX_MAX_RESOURCES + k] = k < d.R ? inv[s * d.R + k] : 0;
+    for (int k = 0; k < MGX_TAG_WORDS; k++)
+      w[8 + 2 * MGX_MAX_RESOURCES + k] = d.obj_tags ? (int32_t)tags[s * MGX_TAG_WORDS + k]
+                                                    : (cls[s] != MGX_DEAD_CLASS ? e->prog[d.sec[MGX_SEC_CLASSES] + cls[s] * MGX_C_WORDS + MGX_C_TAGS + k] : 0);
   }
   *n_objects = (int32_t)n;
   return MGX_OK;

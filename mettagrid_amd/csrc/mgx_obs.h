@@ -52,7 +52,8 @@ struct MgxObjTok {
   __device__ __forceinline__ void put(uint8_t f, uint8_t v) { pool[pos++] = (uint16_t)(f | (v << 8)); }
 };
 
-__device__ int mgx_object_dyn_token_count(const MgxDev& d, const MgxEnv& e, int slot, uint32_t cinfo) {
+template <class ENV>
+__device__ int mgx_object_dyn_token_count(const MgxDev& d, const ENV& e, int slot, uint32_t cinfo) {
   int n = 0;
   if (d.obj_vibe[e.so(slot)] != 0) n++;
   unsigned long long ord = d.obj_order[e.so(slot)];
@@ -65,7 +66,8 @@ __device__ int mgx_object_dyn_token_count(const MgxDev& d, const MgxEnv& e, int 
   return n;
 }
 
-__device__ void mgx_object_dyn_tokens_build(const MgxDev& d, const MgxEnv& e, int slot, uint32_t cinfo, MgxObjTok w) {
+template <class ENV>
+__device__ void mgx_object_dyn_tokens_build(const MgxDev& d, const ENV& e, int slot, uint32_t cinfo, MgxObjTok w) {
   uint8_t vibe = d.obj_vibe[e.so(slot)];
   if (vibe != 0) w.put((uint8_t)d.feat[MGX_F_VIBE], vibe);
   unsigned long long ord = d.obj_order[e.so(slot)];
@@ -96,8 +98,10 @@ __device__ void mgx_object_dyn_tokens_build(const MgxDev& d, const MgxEnv& e, in
 __host__ __device__ inline int mgx_align16(int x) { return (x + 15) & ~15; }
 struct MgxObsLds {
   int grid, offs, minobs, visited, tokinfo, agents, aginfo, spawn, vstat, written, misc, pool, rows, row_words, total;
+  int owner, obsval, tscore;  // X only: per-cell territory owner u16[HW], obs values u32[A][NOV], scores i64[8][256]
 };
-__host__ __device__ inline MgxObsLds mgx_obs_lds_layout(int HW, int NOFF, int S, int A, int T, int pool_tokens) {
+__host__ __device__ inline MgxObsLds mgx_obs_lds_layout(int HW, int NOFF, int S, int A, int T, int pool_tokens,
+                                                        bool X = false, int NOV = 0) {
   MgxObsLds l;
   int o = 0;
   l.grid = o; o += mgx_align16(HW * 2);
@@ -114,17 +118,23 @@ __host__ __device__ inline MgxObsLds mgx_obs_lds_layout(int HW, int NOFF, int S,
   l.pool = o; o += mgx_align16(pool_tokens * 2);
   l.row_words = (T + 3) & ~3;
   l.rows = o; o += MGX_OBS_WAVES * l.row_words * 4;
+  l.owner = l.obsval = l.tscore = 0;
+  if (X) {
+    l.owner = o; o += mgx_align16(HW * 2);
+    l.obsval = o; o += mgx_align16((A * NOV + 1) * 4);
+    l.tscore = o; o += 8 * MGX_OBS_THREADS * 8;
+  }
   l.total = o;
   return l;
 }
 
-template <bool WITH_REWARDS>
+template <bool WITH_REWARDS, bool X>
 __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int pool_tokens) {
   extern __shared__ __align__(16) uint8_t smem[];
   const int env = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & (MGX_WAVE - 1), wave = tid / MGX_WAVE;
   const int HW = d.H * d.W, A = d.A, S = d.S, T = d.T, NOFF = d.NOFF;
-  const MgxObsLds L = mgx_obs_lds_layout(HW, NOFF, S, A, T, pool_tokens);
+  const MgxObsLds L = mgx_obs_lds_layout(HW, NOFF, S, A, T, pool_tokens, X, d.n_obs_values);
   uint16_t* s_grid = (uint16_t*)(smem + L.grid);
   char2* s_offs = (char2*)(smem + L.offs);
   uint32_t* s_minobs = (uint32_t*)(smem + L.minobs);
@@ -139,10 +149,19 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
   uint16_t* s_pool = (uint16_t*)(smem + L.pool);
   uint32_t* s_row = (uint32_t*)(smem + L.rows) + wave * L.row_words;  // one u32 per token: loc | f << 8 | v << 16
 
-  MgxEnv e(d, d.P, env);
+  typedef MgxEnvT<MgxGlobalProg, X> Env;
+  Env e(d, d.P, env);
   e.step = d.step[env];
   const uint32_t step = e.step;
   const int sid_visited = mgx_wk(d, MGX_S_CELL_VISITED);
+  uint16_t* s_owner = (uint16_t*)(smem + L.owner);
+  uint32_t* s_obsval = (uint32_t*)(smem + L.obsval);
+  const bool want_mask = X && d.aoe_mask_feat != 0 && d.NT > 0;
+  if (X) {
+    e.xl.terr_score = (long long*)(smem + L.tscore);
+    e.xl.lane = tid;
+    e.xl.stride = MGX_OBS_THREADS;
+  }
 
   // ---- phase 0: stage the env (coalesced) and build the per-object token cache ----
   {
@@ -170,13 +189,26 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
     uint16_t cls = d.obj_cls[e.so(s)];
     if (cls != MGX_DEAD_CLASS) {
       const uint32_t cinfo = d.cls_tokinfo[cls];  // start(16) | group(8) | ntags(6) | agent(1) | static(1)
-      const int ntags = (cinfo >> 24) & 0x3F;
+      int ntags = (cinfo >> 24) & 0x3F;
       const bool is_static = (cinfo >> 31) != 0;
+      const bool dyn_tags = X && d.obj_tags != nullptr;
+      if (dyn_tags) {
+        ntags = 0;
+        for (int w = 0; w < MGX_TAG_WORDS; w++) ntags += __popc(d.obj_tags[e.so(s) * MGX_TAG_WORDS + w]);
+      }
       int n = ntags + (is_static ? 0 : mgx_object_dyn_token_count(d, e, s, cinfo));
       uint32_t start = atomicAdd(&s_misc[0], (uint32_t)n);
       if ((int)(start + n) <= pool_tokens) {
-        const uint16_t* src = d.cls_tok + (cinfo & 0xFFFF);
-        for (int k = 0; k < ntags; k++) s_pool[start + k] = src[k];
+        if (dyn_tags) {
+          int k = 0;
+          for (int w = 0; w < MGX_TAG_WORDS; w++) {
+            uint32_t m = d.obj_tags[e.so(s) * MGX_TAG_WORDS + w];
+            while (m) { int b = __ffs(m) - 1; m &= m - 1; s_pool[start + k++] = (uint16_t)(d.feat[MGX_F_TAG] | ((w * 32 + b) << 8)); }
+          }
+        } else {
+          const uint16_t* src = d.cls_tok + (cinfo & 0xFFFF);
+          for (int k = 0; k < ntags; k++) s_pool[start + k] = src[k];
+        }
         if (!is_static) mgx_object_dyn_tokens_build(d, e, s, cinfo, MgxObjTok{s_pool, (int)start + ntags});
         info = start | ((uint32_t)n << 16);
       } else {
@@ -185,6 +217,25 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
       s_visited[s] = d.obj_visited[e.so(s)];
     }
     s_tokinfo[s] = info;
+  }
+  if constexpr (X) {
+    if (want_mask) {  // TerritoryTracker::compute_observability_at (:254-273): first territory with an owner decides
+      for (int cellidx = tid; cellidx < HW; cellidx += MGX_OBS_THREADS) {
+        int owner = -1;
+        for (int ti = 0; ti < d.NT && owner < 0; ti++) owner = e.cell_owner(cellidx / d.W, cellidx % d.W, ti);
+        s_owner[cellidx] = owner < 0 ? 0xFFFF : (uint16_t)owner;
+      }
+    }
+    if (tid == 0) {  // query-backed obs values share the env's query workspace -> evaluated serially here
+      for (int a = 0; a < A; a++)
+        for (int i = 0; i < d.n_obs_values; i++) {
+          const int32_t* V = d.P + d.sec[MGX_SEC_OBS_VALUES] + i * MGX_OV_WORDS;
+          int slot = s_agents[a] & 0xFFFF;
+          MgxCtx vc = mgx_ctx(slot, slot);
+          s_obsval[a * d.n_obs_values + i] =
+              (uint32_t)e.template eval_code<Env::TOPQ>(V[MGX_OV_GV_START], V[MGX_OV_GV_COUNT], slot, vc, 0);
+        }
+    }
   }
   __syncthreads();
 
@@ -245,8 +296,13 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
       }
       for (int i = 0; i < d.n_obs_values; i++) {  // _emit_obs_value_tokens :1207-1238
         const int32_t* V = d.P + d.sec[MGX_SEC_OBS_VALUES] + i * MGX_OV_WORDS;
-        float raw = e.eval_code(V[MGX_OV_GV_START], V[MGX_OV_GV_COUNT], my_slot);
-        uint32_t rem = (uint32_t)raw;
+        uint32_t rem;
+        if constexpr (X) {
+          rem = s_obsval[a * d.n_obs_values + i];
+        } else {
+          MgxCtx vc = mgx_ctx(my_slot, my_slot);
+          rem = (uint32_t)e.template eval_code<0>(V[MGX_OV_GV_START], V[MGX_OV_GV_COUNT], my_slot, vc, 0);
+        }
         int f = V[MGX_OV_FEATURE];
         put(f, rem % (uint32_t)d.base);
         rem /= (uint32_t)d.base;
@@ -262,7 +318,7 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
     bool visited_any = false;
     for (int p = 0; p < NPASS; p++) {
       int n[2] = {0, 0}, start[2] = {0, 0};
-      uint32_t loc[2] = {0, 0};
+      uint32_t loc[2] = {0, 0}, mask[2] = {0, 0};
       float stale[2] = {0.f, 0.f};
       bool first[2] = {false, false};
 #pragma unroll
@@ -273,11 +329,17 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
           int r = r0 + o.x, c = c0 + o.y;
           if ((unsigned)r < (unsigned)d.H && (unsigned)c < (unsigned)d.W) {
             int slot = (int)s_grid[r * d.W + c] - 1;
+            loc[h] = (uint32_t)(((o.x + hr) << 4) | (o.y + wr));
+            if constexpr (X) {
+              if (want_mask) {  // _emit_tile_observability_tokens (:337-362): before the cell's object tokens
+                uint16_t ow = s_owner[r * d.W + c];
+                if (ow != 0xFFFF) { mask[h] = e.has_tag(my_slot, ow) ? 1u : 2u; n[h] = 1; }
+              }
+            }
             if (slot >= 0) {
-              loc[h] = (uint32_t)(((o.x + hr) << 4) | (o.y + wr));
               uint32_t info = s_tokinfo[slot];
               start[h] = info & 0xFFFF;
-              n[h] = info >> 16;
+              n[h] += info >> 16;
               if (step > 0 && s_minobs[slot] == (uint32_t)a) {
                 uint32_t pv = s_visited[slot];
                 if (pv < step) { first[h] = true; stale[h] = (float)(step - pv); }
@@ -293,6 +355,10 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
       const int excl = incl - packed;
       int pos0 = base_pos + (excl & 0xFFFF);
       int pos1 = base_pos + (tot & 0xFFFF) + (excl >> 16);
+      if constexpr (X) {
+        if (mask[0]) { if (pos0 < T) s_row[pos0] = loc[0] | ((uint32_t)d.aoe_mask_feat << 8) | (mask[0] << 16); pos0++; n[0]--; }
+        if (mask[1]) { if (pos1 < T) s_row[pos1] = loc[1] | ((uint32_t)d.aoe_mask_feat << 8) | (mask[1] << 16); pos1++; n[1]--; }
+      }
       for (int k = 0; k < n[0]; k++)
         if (pos0 + k < T) s_row[pos0 + k] = loc[0] | ((uint32_t)s_pool[start[0] + k] << 8);
       for (int k = 0; k < n[1]; k++)
@@ -353,13 +419,16 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
     if (overflow) d.err[env] |= 1u;
   }
   if (WITH_REWARDS) {
-    for (int a = tid; a < A; a += MGX_OBS_THREADS) {  // RewardHelper::compute_entries, systems/reward.hpp:56-77
+    if constexpr (X) __syncthreads();  // cell.visited stats of all waves are in before value expressions read them
+    // X: query-backed values share one workspace per env -> one thread walks the agents in order
+    for (int a = X ? (tid == 0 ? 0 : A) : tid; a < A; a += X ? 1 : MGX_OBS_THREADS) {  // RewardHelper::compute_entries (reward.hpp:56-77)
       const int slot = s_agents[a] & 0xFFFF;
       const int32_t* C = e.cls_of(slot);
       const int32_t* rw = d.P + d.sec[MGX_SEC_REWARDS] + C[MGX_C_REWARD_START] * MGX_RW_WORDS;
       float total = 0.f;
       for (int k = 0; k < C[MGX_C_REWARD_COUNT]; k++, rw += MGX_RW_WORDS) {
-        float val = e.eval_code(rw[MGX_RW_GV_START], rw[MGX_RW_GV_COUNT], slot);
+        MgxCtx vc = mgx_ctx(slot, slot);
+        float val = e.template eval_code<Env::TOPQ>(rw[MGX_RW_GV_START], rw[MGX_RW_GV_COUNT], slot, vc, 0);
         float* prev = &d.ag_rprev[e.ao(a) * d.NRW + k];
         if (rw[MGX_RW_ACCUMULATE]) total = __fadd_rn(total, val);
         else total = __fadd_rn(total, __fsub_rn(val, *prev));

@@ -2,39 +2,69 @@
 //
 // Covers phases 1-11 of MettaGrid::_step (/root/reference/cpp/bindings/mettagrid_c.cpp:921-1056): snapshot of
 // previous locations, step counter, the per-step agent shuffle, action dispatch by priority and stream
-// (noop / move with the handler-chain line scan / change_vibe), per-agent on_tick handlers and coverage tracking.
+// (noop / move with the handler-chain line scan / change_vibe), timestep events, per-agent on_tick handlers, fixed and
+// mobile AoE, territory effects, the game-level on_tick handler and coverage tracking.
 // The order of agents inside one env is a true sequential dependence (collisions, first-come resources), so an env
 // is executed serially by ONE lane; 64 envs advance in lock-step per wavefront and every lane runs the same
 // compiled program, which bounds divergence.  Observations, rewards and termination are mgx_obs.h.
+//
+// Two instantiations exist: X = false (rungs 1-3: static tags, no queries/events/AoE/territory — the benchmarked
+// configuration) and X = true (everything).  The X-only code is compiled out of the fast variant.
 #ifndef MGX_WORLD_H_
 #define MGX_WORLD_H_
 
 #include "mgx_device.h"
 
 struct MgxCtx {  // handler/handler_context.hpp:38-112 (the fields the supported filters/mutations read)
-  int actor, target;  // object slots, -1 = null
+  int actor, target, source;  // object slots, MGX_SLOT_NONE (-1) or MGX_SLOT_PROXY (-2)
+  int proxy_tag;              // tag carried by the territory proxy cell
   int target_r, target_c;
   int move_direction;
   bool mutation_failed;
+  bool skip_trigger;          // skip_on_update_trigger
+  bool deferred;              // AOETracker::apply_fixed: ResourceDelta on the target is accumulated
 };
+__device__ __forceinline__ MgxCtx mgx_ctx(int actor, int target) {
+  MgxCtx c;
+  c.actor = actor; c.target = target; c.source = MGX_SLOT_NONE; c.proxy_tag = -1;
+  c.target_r = c.target_c = 0; c.move_direction = 0;
+  c.mutation_failed = false; c.skip_trigger = false; c.deferred = false;
+  return c;
+}
 
 // Program pointer types: the world kernel keeps the whole program in LDS when it fits (address space 3 pointer ->
 // ds_read, no vector-memory traffic for table lookups); everything else reads it from global memory.
 typedef const int32_t* MgxGlobalProg;
 typedef const __attribute__((address_space(3))) int32_t* MgxLdsProg;
 
-template <class PP>
+// Per-lane LDS scratch of the extended world kernel ([k][lane] layouts, bank-conflict free per wavefront).
+struct MgxXLds {
+  int* def_delta;            // [28][stride] deferred target resource deltas (core/aoe_tracker.cpp:283-289)
+  long long* terr_score;     // [8][stride]  per-prefix-tag influence sums (core/territory_tracker.cpp:223-236)
+  int lane, stride;
+};
+
+__device__ __forceinline__ unsigned long long mgx_floor_sqrt(unsigned long long v) {  // == floor_sqrt_u64 (:17-33), v < 2^53
+  unsigned long long r = (unsigned long long)__dsqrt_rn((double)v);
+  while (r * r > v) r--;
+  while ((r + 1) * (r + 1) <= v) r++;
+  return r;
+}
+
+template <class PP, bool X>
 struct MgxEnvT {  // per-lane view of one env
   const MgxDev& d;
   PP P;
   int env;
   uint32_t step;
-  __device__ MgxEnvT(const MgxDev& dd, PP prog, int e) : d(dd), P(prog), env(e), step(0) {}
+  MgxXLds xl;
+  __device__ MgxEnvT(const MgxDev& dd, PP prog, int e) : d(dd), P(prog), env(e), step(0) { xl.def_delta = nullptr; xl.terr_score = nullptr; xl.lane = 0; xl.stride = MGX_WAVE; }
   __device__ __forceinline__ PP cls(int c) const { return P + d.sec[MGX_SEC_CLASSES] + c * MGX_C_WORDS; }
 
   __device__ __forceinline__ size_t so(int slot) const { return (size_t)env * d.S + slot; }
   __device__ __forceinline__ size_t ao(int agent) const { return (size_t)env * d.A + agent; }
   __device__ __forceinline__ uint16_t& inv(int slot, int item) const { return d.obj_inv[so(slot) * d.R + item]; }
+  __device__ __forceinline__ int inv_of(int slot, int item) const { return slot >= 0 ? (int)inv(slot, item) : 0; }
   __device__ __forceinline__ PP cls_of(int slot) const { return cls(d.obj_cls[so(slot)]); }
   __device__ __forceinline__ int agent_of(int slot) const {
     if (slot < 0) return -1;
@@ -50,6 +80,11 @@ struct MgxEnvT {  // per-lane view of one env
   __device__ void astat_add(int agent, int id, float v) const {
     if (id < 0) return;
     d.ag_stats[ao(agent) * d.NS + id] += v;
+  }
+  __device__ void astat_add_touch(int agent, int id, float v) const {  // for deltas that may be zero or negative
+    if (id < 0) return;
+    d.ag_stats[ao(agent) * d.NS + id] += v;
+    astat_touch(agent, id);
   }
   __device__ void astat_set(int agent, int id, float v) const {
     if (id < 0) return;
@@ -90,7 +125,7 @@ struct MgxEnvT {  // per-lane view of one env
   }
   __device__ PP limit_of(PP C, int item) const {
     int li = C[MGX_C_RES_LIMIT + item];
-    return li < 0 ? (PP)nullptr : P + d.sec[MGX_SEC_LIMITS] + li * MGX_L_WORDS;
+    return li < 0 ? (PP) nullptr : P + d.sec[MGX_SEC_LIMITS] + li * MGX_L_WORDS;
   }
   __device__ void on_inventory_change(int slot, int item, int delta, int amount) const {  // objects/agent.cpp:106-121
     int a = agent_of(slot);
@@ -173,8 +208,188 @@ struct MgxEnvT {  // per-lane view of one env
     return amount;
   }
 
+  // ---- tags ----
+  __device__ __forceinline__ uint32_t tagword(int slot, int w, const MgxCtx& c) const {
+    if (slot >= 0) {
+      if constexpr (X) { if (d.obj_tags) return d.obj_tags[so(slot) * MGX_TAG_WORDS + w]; }
+      return (uint32_t)cls_of(slot)[MGX_C_TAGS + w];
+    }
+    if (slot == MGX_SLOT_PROXY && c.proxy_tag >= 0 && (c.proxy_tag >> 5) == w) return 1u << (c.proxy_tag & 31);
+    return 0u;
+  }
+  __device__ __forceinline__ bool has_tag(int slot, int t) const {
+    if (slot < 0) return false;
+    if constexpr (X) { if (d.obj_tags) return (d.obj_tags[so(slot) * MGX_TAG_WORDS + (t >> 5)] >> (t & 31)) & 1u; }
+    return ((uint32_t)cls_of(slot)[MGX_C_TAGS + (t >> 5)] >> (t & 31)) & 1u;
+  }
+  __device__ __forceinline__ int tag_list(int tag) const { return P[d.sec[MGX_SEC_TAG_LISTS] + tag]; }
+  __device__ __forceinline__ uint16_t* tl_items(int li) const { return d.tl_items + ((size_t)env * d.NL + li) * d.S; }
+  __device__ __forceinline__ uint16_t& tl_count(int li) const { return d.tl_count[(size_t)env * d.NL + li]; }
+  template <int DEPTH>
+  __device__ void fire_tag_handlers(int o, int tag, int start_field, const MgxCtx& c) const {  // grid_object.cpp:83-123
+    PP C = cls_of(o);
+    PP th = P + d.sec[MGX_SEC_TAG_HANDLERS] + C[start_field] * MGX_TH_WORDS;
+    for (int i = 0; i < C[start_field + 1]; i++, th += MGX_TH_WORDS) {
+      if (th[MGX_TH_TAG] != tag) continue;
+      if constexpr (DEPTH > 0) {
+        MgxCtx h = c;
+        h.actor = h.target = o;
+        h.skip_trigger = false;
+        apply_handler<DEPTH - 1>(th[MGX_TH_HANDLER], h);
+      } else {
+        flag(4u);
+      }
+    }
+  }
+  template <int DEPTH>
+  __device__ void add_tag(int o, int tag, const MgxCtx& c) const {
+    if (o < 0 || tag < 0 || tag >= 256 || !d.obj_tags || has_tag(o, tag)) return;
+    d.obj_tags[so(o) * MGX_TAG_WORDS + (tag >> 5)] |= 1u << (tag & 31);
+    int li = tag_list(tag);
+    if (li >= 0) { uint16_t n = tl_count(li); if (n < d.S) { tl_items(li)[n] = (uint16_t)o; tl_count(li) = n + 1; } }
+    if (!c.skip_trigger) fire_tag_handlers<DEPTH>(o, tag, MGX_C_TAG_ADD_START, c);
+  }
+  template <int DEPTH>
+  __device__ void remove_tag(int o, int tag, const MgxCtx& c) const {
+    if (o < 0 || tag < 0 || tag >= 256 || !d.obj_tags || !has_tag(o, tag)) return;
+    d.obj_tags[so(o) * MGX_TAG_WORDS + (tag >> 5)] &= ~(1u << (tag & 31));
+    int li = tag_list(tag);
+    if (li >= 0) {  // stable erase (core/tag_index.cpp:37-43)
+      uint16_t* it = tl_items(li);
+      int n = tl_count(li), k = 0;
+      for (int i = 0; i < n; i++) { uint16_t v = it[i]; if (v != (uint16_t)o) it[k++] = v; }
+      tl_count(li) = (uint16_t)k;
+    }
+    if (!c.skip_trigger) fire_tag_handlers<DEPTH>(o, tag, MGX_C_TAG_REMOVE_START, c);
+  }
+
+  // ---- query workspace ----
+  __device__ __forceinline__ uint16_t* qbuf(int idx) const { return d.qws + ((size_t)env * d.QB + idx) * d.S; }
+  __device__ __forceinline__ uint32_t* qvis(int depth) const { return d.qvis + ((size_t)env * (d.QD + 1) + depth) * d.SW; }
+  enum { QB_EVENT = 0, QB_LOST = 1, QB_KEEP = 2, QB_BASE = 3 };  // then two buffers per nesting level
+
+  // ---- queries (core/query_system.cpp:28-89, 178-330).  Results land in qbuf(QB_BASE + 2*depth); QD bounds the
+  // query -> filter -> query template recursion, `depth` selects the workspace level at run time. ----
+  template <int QD>
+  __device__ bool matches(int pc, MgxCtx c, int obj, int depth) const {
+    c.target = obj;
+    return pc == MGX_PC_PASS || check_filters<QD>(pc, c, depth);
+  }
+  template <int QD>
+  __device__ int apply_limits(uint16_t* res, int n, PP Q, const MgxCtx& c, int depth) const {  // :74-89
+    if (Q[MGX_Q_ORDER] & 1) {  // std::shuffle with the env's mt19937 (bits/stl_algo.h:3729-3795)
+      if (n >= 2) {
+        uint32_t i = 1;
+        if ((n & 1) == 0) { uint32_t j = rng_below(2); uint16_t t = res[1]; res[1] = res[j]; res[j] = t; i = 2; }
+        while (i < (uint32_t)n) {
+          uint32_t s = i + 1, x = rng_below(s * (s + 1));
+          uint32_t j0 = x / (s + 1), j1 = x % (s + 1);
+          uint16_t t = res[i]; res[i] = res[j0]; res[j0] = t;
+          t = res[i + 1]; res[i + 1] = res[j1]; res[j1] = t;
+          i += 2;
+        }
+      }
+    }
+    int mx = Q[MGX_Q_MAX_ITEMS] >= 0 ? (int)eval_value<QD - 1>(Q[MGX_Q_MAX_ITEMS], c.actor, c, depth + 1) : -1;
+    return (mx >= 0 && n > mx) ? mx : n;
+  }
+  template <int QD>
+  __device__ int eval_query(int qi, const MgxCtx& c, int depth) const {
+    if constexpr (!X || QD == 0) {
+      flag(4u);
+      return 0;
+    } else {
+      if (depth > d.QD) { flag(4u); return 0; }
+      PP Q = P + d.sec[MGX_SEC_QUERIES] + qi * MGX_Q_WORDS;
+      uint16_t* out = qbuf(QB_BASE + 2 * depth);
+      uint16_t* tmp = qbuf(QB_BASE + 2 * depth + 1);
+      int n = 0;
+      const int kind = Q[MGX_Q_KIND], a0 = Q[MGX_Q_A0], a1 = Q[MGX_Q_A1], a2 = Q[MGX_Q_A2], a3 = Q[MGX_Q_A3];
+      if (kind == MGX_QK_TAG) {
+        int li = tag_list(a0);
+        if (li >= 0) {
+          const uint16_t* it = tl_items(li);
+          int cnt = tl_count(li);
+          for (int i = 0; i < cnt; i++) { int o = it[i]; if (matches<QD - 1>(a1, c, o, depth + 1)) out[n++] = (uint16_t)o; }
+        }
+      } else if (kind == MGX_QK_FILTERED) {
+        int m = eval_query<QD - 1>(a0, c, depth + 1);
+        const uint16_t* src = qbuf(QB_BASE + 2 * (depth + 1));
+        for (int i = 0; i < m; i++) tmp[i] = src[i];
+        for (int i = 0; i < m; i++) { int o = tmp[i]; if (matches<QD - 1>(a1, c, o, depth + 1)) out[n++] = (uint16_t)o; }
+      } else if (kind == MGX_QK_CLOSURE) {
+        uint32_t* vis = qvis(depth);
+        for (int w = 0; w < d.SW; w++) vis[w] = 0;
+        int nr = eval_query<QD - 1>(a0, c, depth + 1);
+        const uint16_t* src = qbuf(QB_BASE + 2 * (depth + 1));
+        if (a1 < 0) {
+          for (int i = 0; i < nr; i++) out[i] = src[i];
+          return apply_limits<QD>(out, nr, Q, c, depth);
+        }
+        for (int i = 0; i < nr; i++) {
+          int o = src[i];
+          if (!((vis[o >> 5] >> (o & 31)) & 1u)) { vis[o >> 5] |= 1u << (o & 31); out[n++] = (uint16_t)o; }
+        }
+        int np = eval_query<QD - 1>(a1, c, depth + 1);
+        for (int i = 0; i < np; i++) tmp[i] = src[i];
+        for (int head = 0; head < n; head++) {  // BFS: the result list is the queue
+          int cur = out[head];
+          for (int i = 0; i < np; i++) {
+            int cand = tmp[i];
+            if ((vis[cand >> 5] >> (cand & 31)) & 1u) continue;
+            if (a2 != MGX_PC_PASS) {
+              MgxCtx e = c;
+              e.source = cur; e.target = cand;
+              if (!check_filters<QD - 1>(a2, e, depth + 1)) continue;
+            }
+            vis[cand >> 5] |= 1u << (cand & 31);
+            out[n++] = (uint16_t)cand;
+          }
+        }
+        if (a3 != MGX_PC_PASS) {
+          int k = 0;
+          for (int i = 0; i < n; i++) { int o = out[i]; if (matches<QD - 1>(a3, c, o, depth + 1)) out[k++] = (uint16_t)o; }
+          n = k;
+        }
+      } else if (kind == MGX_QK_RAYCAST) {
+        uint32_t* seen = qvis(depth);
+        for (int w = 0; w < d.SW; w++) seen[w] = 0;
+        int ns = eval_query<QD - 1>(a0, c, depth + 1);
+        const uint16_t* src = qbuf(QB_BASE + 2 * (depth + 1));
+        for (int i = 0; i < ns; i++) tmp[i] = src[i];
+        PP dirs = P + d.sec[MGX_SEC_WORDLIST] + a2;
+        const int blocker_pc = Q[MGX_Q_A4];
+        for (int i = 0; i < ns; i++) {
+          int s = tmp[i];
+          MgxCtx sc = c;
+          sc.actor = sc.target = s;
+          int range = (int)eval_value<QD - 1>(a1, s, sc, depth + 1);
+          if (range <= 0) continue;
+          uint16_t rc = d.obj_rc[so(s)];
+          for (int k = 0; k < a3; k++)
+            for (int dist = 1; dist <= range; dist++) {
+              int r = (rc >> 8) + dirs[k * 2] * dist, cc = (rc & 0xFF) + dirs[k * 2 + 1] * dist;
+              if (r < 0 || cc < 0 || r >= d.H || cc >= d.W) break;
+              int o = (int)cell(r, cc) - 1;
+              if (o < 0) continue;
+              bool blocker = false;
+              if (blocker_pc != MGX_PC_FAIL) { MgxCtx b = c; b.target = o; blocker = check_filters<QD - 1>(blocker_pc, b, depth + 1); }
+              bool was = (seen[o >> 5] >> (o & 31)) & 1u;
+              if (blocker) {
+                if ((Q[MGX_Q_ORDER] & 0x100) && !was) { seen[o >> 5] |= 1u << (o & 31); out[n++] = (uint16_t)o; }
+                break;
+              }
+              if (!was) { seen[o >> 5] |= 1u << (o & 31); out[n++] = (uint16_t)o; }
+            }
+        }
+      }
+      return apply_limits<QD>(out, n, Q, c, depth);
+    }
+  }
+
   // ---- game values (cpp/src/mettagrid/core/game_value.cpp:14-148): postfix code on a small f32 stack ----
-  __device__ float eval_code(int start, int count, int entity) const {
+  template <int QD>
+  __device__ float eval_code(int start, int count, int entity, const MgxCtx& outer, int depth) const {
     float st[8];
     int sp = 0;
     PP code = P + d.sec[MGX_SEC_GV_CODE] + start * MGX_GV_WORDS;
@@ -201,63 +416,154 @@ struct MgxEnvT {  // per-lane view of one env
         case MGX_GOP_RATIO: { float den = st[--sp & 7], num = st[--sp & 7]; st[sp++ & 7] = den > 0.f ? __fdiv_rn(num, den) : num; break; }
         case MGX_GOP_MAX2: { float v = st[--sp & 7], b = st[--sp & 7]; st[sp++ & 7] = (b < v) ? v : b; break; }
         case MGX_GOP_MIN2: { float v = st[--sp & 7], b = st[--sp & 7]; st[sp++ & 7] = (v < b) ? v : b; break; }
+        case MGX_GOP_QUERY_INVENTORY: {  // game_value.cpp:45-57 (captured ctx: actor = the value's entity)
+          float total = 0.f;
+          if constexpr (X && QD > 0) {
+            MgxCtx q = outer;
+            q.actor = entity;
+            int n = eval_query<QD>(a1, q, depth);
+            const uint16_t* res = qbuf(QB_BASE + 2 * depth);
+            for (int k = 0; k < n; k++) total = __fadd_rn(total, (float)inv(res[k], a0));
+          } else {
+            flag(4u);
+          }
+          st[sp++ & 7] = total;
+          break;
+        }
+        case MGX_GOP_QUERY_COUNT: {
+          float cnt = 0.f;
+          if constexpr (X && QD > 0) {
+            MgxCtx q = outer;
+            q.actor = entity;
+            cnt = (float)eval_query<QD>(a0, q, depth);
+          } else {
+            flag(4u);
+          }
+          st[sp++ & 7] = cnt;
+          break;
+        }
       }
     }
     return sp > 0 ? st[(sp - 1) & 7] : 0.f;
   }
-  __device__ float eval_value(int rec, int entity) const {
+  template <int QD>
+  __device__ float eval_value(int rec, int entity, const MgxCtx& c, int depth) const {
     PP V = P + d.sec[MGX_SEC_OBS_VALUES] + rec * MGX_OV_WORDS;
-    return eval_code(V[MGX_OV_GV_START], V[MGX_OV_GV_COUNT], entity);
+    return eval_code<QD>(V[MGX_OV_GV_START], V[MGX_OV_GV_COUNT], entity, c, depth);
   }
 
   // ---- filters (handler/filters/*.hpp) as short-circuit code ----
   __device__ __forceinline__ int resolve(const MgxCtx& c, int ent) const { return ent == MGX_ENT_ACTOR ? c.actor : c.target; }
-  __device__ bool atom(PP a, const MgxCtx& c) const {
+  template <int QD>
+  __device__ bool atom(PP a, const MgxCtx& c, int depth) const {
     int a0 = a[MGX_AT_A0], a1 = a[MGX_AT_A1], a2 = a[MGX_AT_A2];
     switch (a[MGX_AT_OP]) {
-      case MGX_FOP_VIBE: { int e = resolve(c, a0); return e >= 0 && d.obj_vibe[so(e)] == a1; }
-      case MGX_FOP_RESOURCE: { int e = resolve(c, a0); return e >= 0 && (int)inv(e, a1) >= a2; }
+      case MGX_FOP_VIBE: { int e = resolve(c, a0); return e != MGX_SLOT_NONE && (e >= 0 ? (int)d.obj_vibe[so(e)] : 0) == a1; }
+      case MGX_FOP_RESOURCE: { int e = resolve(c, a0); return e != MGX_SLOT_NONE && inv_of(e, a1) >= a2; }
       case MGX_FOP_SHARED_TAG: {
-        if (c.actor < 0 || c.target < 0) return false;
         PP mask = P + d.sec[MGX_SEC_WORDLIST] + a0;
-        PP x = cls_of(c.actor) + MGX_C_TAGS; PP y = cls_of(c.target) + MGX_C_TAGS;
         uint32_t any = 0;
-        for (int w = 0; w < MGX_TAG_WORDS; w++) any |= (uint32_t)x[w] & (uint32_t)y[w] & (uint32_t)mask[w];
+        for (int w = 0; w < MGX_TAG_WORDS; w++) any |= tagword(c.actor, w, c) & tagword(c.target, w, c) & (uint32_t)mask[w];
         return any != 0;
       }
       case MGX_FOP_TAG: {
         int e = resolve(c, a0);
-        if (e < 0) return false;
+        if (e == MGX_SLOT_NONE) return false;
         PP mask = P + d.sec[MGX_SEC_WORDLIST] + a1;
-        PP x = cls_of(e) + MGX_C_TAGS;
         uint32_t any = 0;
-        for (int w = 0; w < MGX_TAG_WORDS; w++) any |= (uint32_t)x[w] & (uint32_t)mask[w];
+        for (int w = 0; w < MGX_TAG_WORDS; w++) any |= tagword(e, w, c) & (uint32_t)mask[w];
         return any != 0;
       }
-      case MGX_FOP_TARGET_LOC_EMPTY: return c.target < 0;
-      case MGX_FOP_TARGET_IS_USABLE: return c.target >= 0;
+      case MGX_FOP_TARGET_LOC_EMPTY: return c.target == MGX_SLOT_NONE;
+      case MGX_FOP_TARGET_IS_USABLE: return c.target != MGX_SLOT_NONE;
       case MGX_FOP_PERIODIC: return step >= (uint32_t)a1 && ((step - (uint32_t)a1) % (uint32_t)a0) == 0;
       case MGX_FOP_GAME_VALUE: {
         int e = resolve(c, a0);
-        float v = eval_value(a1, e);
-        float t = eval_value(a2, e);
+        float v = eval_value<QD>(a1, e, c, depth);
+        float t = eval_value<QD>(a2, e, c, depth);
         return v >= t;
+      }
+      case MGX_FOP_MAX_DISTANCE: {  // filters/max_distance_filter.hpp:27-67
+        int e = resolve(c, a0);
+        if (e < 0) return false;
+        uint16_t erc = d.obj_rc[so(e)];
+        long long r = a1;
+        if (a2 < 0) {
+          int ref = c.source >= 0 ? c.source : c.actor;
+          if (ref < 0) return false;
+          if (a1 == 0) return true;
+          uint16_t rrc = d.obj_rc[so(ref)];
+          long long dr = (int)(erc >> 8) - (int)(rrc >> 8), dc = (int)(erc & 0xFF) - (int)(rrc & 0xFF);
+          return dr * dr + dc * dc <= r * r;
+        }
+        if constexpr (X && QD > 0) {
+          int n = eval_query<QD>(a2, c, depth);
+          if (a1 == 0) return n > 0;
+          const uint16_t* res = qbuf(QB_BASE + 2 * depth);
+          for (int i = 0; i < n; i++) {
+            uint16_t src = d.obj_rc[so(res[i])];
+            long long dr = (int)(erc >> 8) - (int)(src >> 8), dc = (int)(erc & 0xFF) - (int)(src & 0xFF);
+            if (dr * dr + dc * dc <= r * r) return true;
+          }
+        } else {
+          flag(4u);
+        }
+        return false;
+      }
+      case MGX_FOP_QUERY_RESOURCE: {  // filters/query_resource_filter.hpp:26-41
+        if constexpr (X && QD > 0) {
+          int n = eval_query<QD>(a0, c, depth);
+          const uint16_t* res = qbuf(QB_BASE + 2 * depth);
+          PP req = P + d.sec[MGX_SEC_WORDLIST] + a1;
+          for (int i = 0; i < a2; i++) {
+            uint32_t total = 0, need = (uint32_t)req[i * 2 + 1];
+            for (int k = 0; k < n; k++) { total += inv(res[k], req[i * 2]); if (total >= need) break; }
+            if (total < need) return false;
+          }
+          return true;
+        } else {
+          flag(4u);
+          return false;
+        }
       }
       case MGX_FOP_TRUE: return true;
       default: return false;
     }
   }
-  __device__ bool check_filters(int pc, const MgxCtx& c) const {  // handler/handler.cpp:95-103
+  template <int QD>
+  __device__ bool check_filters(int pc, const MgxCtx& c, int depth) const {  // handler/handler.cpp:95-103
     PP atoms = P + d.sec[MGX_SEC_ATOMS];
     while (pc >= 0) {
       PP a = atoms + pc * MGX_AT_WORDS;
-      pc = atom(a, c) ? a[MGX_AT_ON_TRUE] : a[MGX_AT_ON_FALSE];
+      pc = atom<QD>(a, c, depth) ? a[MGX_AT_ON_TRUE] : a[MGX_AT_ON_FALSE];
     }
     return pc == MGX_PC_PASS;
   }
+  static constexpr int TOPQ = X ? 3 : 0;  // query nesting available to top-level filter/value evaluation
 
   // ---- grid (core/grid.hpp:75-113) ----
   __device__ __forceinline__ uint16_t& cell(int r, int c) const { return d.grid[(size_t)env * d.H * d.W + r * d.W + c]; }
+  __device__ void territory_moved(int slot) const {  // TerritoryTracker::notify_source_moved (:187-199)
+    if constexpr (X) {
+      if (d.NTS == 0) return;
+      uint16_t* to = d.ts_obj + (size_t)env * d.NTS;
+      uint16_t* tc = d.ts_ctrl + (size_t)env * d.NTS;
+      uint16_t* tr = d.ts_rc + (size_t)env * d.NTS;
+      int n = d.ts_count[env];
+      // entries of the moved object are re-registered at the END, keeping their relative order
+      int mine = 0;
+      for (int i = 0; i < n; i++) mine += to[i] == (uint16_t)slot;
+      if (!mine) return;
+      uint16_t rc = d.obj_rc[so(slot)];
+      for (int pass = 0; pass < mine; pass++) {
+        int i = 0;
+        while (to[i] != (uint16_t)slot) i++;  // originals of this object always precede the entries already moved
+        uint16_t ctrl = tc[i];
+        for (int k = i; k + 1 < n; k++) { to[k] = to[k + 1]; tc[k] = tc[k + 1]; tr[k] = tr[k + 1]; }
+        to[n - 1] = (uint16_t)slot; tc[n - 1] = ctrl; tr[n - 1] = rc;
+      }
+    }
+  }
   __device__ bool move_object(int slot, int r, int c) const {
     if (r < 0 || c < 0 || r >= d.H || c >= d.W) return false;
     if (cell(r, c) != 0) return false;
@@ -265,6 +571,7 @@ struct MgxEnvT {  // per-lane view of one env
     cell(r, c) = (uint16_t)(slot + 1);
     cell(rc >> 8, rc & 0xFF) = 0;
     d.obj_rc[so(slot)] = (uint16_t)((r << 8) | c);
+    territory_moved(slot);
     return true;
   }
 
@@ -273,7 +580,22 @@ struct MgxEnvT {  // per-lane view of one env
   __device__ void mutate(PP m, MgxCtx& c) const {
     int a0 = m[MGX_MU_A0], a1 = m[MGX_MU_A1], a2 = m[MGX_MU_A2], a3 = m[MGX_MU_A3];
     switch (m[MGX_MU_OP]) {
-      case MGX_MOP_RESOURCE_DELTA: { int e = resolve(c, a0); if (e >= 0) inv_update<1>(e, a1, a2); break; }
+      case MGX_MOP_RESOURCE_DELTA: {  // resource_mutation.hpp:25-47
+        if constexpr (X) {
+          if (c.deferred && a0 == MGX_ENT_TARGET && c.target >= 0 && !(cls_of(c.target)[MGX_C_MODIFIER_MASK] & (1 << a1))) {
+            int* dd = xl.def_delta + a1 * xl.stride + xl.lane;
+            int* meta = xl.def_delta + 13 * xl.stride + xl.lane;       // seen mask
+            int* cnt = xl.def_delta + 14 * xl.stride + xl.lane;        // number of first-seen entries
+            if (!((*meta >> a1) & 1)) { *meta |= 1 << a1; xl.def_delta[(15 + *cnt) * xl.stride + xl.lane] = a1; *cnt += 1; *dd = 0; }
+            *dd += a2;
+            break;
+          }
+        }
+        int e = resolve(c, a0);
+        if (e >= 0) inv_update<1>(e, a1, a2);
+        else if (e == MGX_SLOT_PROXY) flag(32u);
+        break;
+      }
       case MGX_MOP_RESOURCE_TRANSFER: {  // resource_mutation.hpp:60-98
         int s = resolve(c, a0), t = resolve(c, a1);
         if (s < 0 || t < 0) break;
@@ -308,7 +630,7 @@ struct MgxEnvT {  // per-lane view of one env
       }
       case MGX_MOP_STATS: {  // stats_mutation.hpp:21-41
         int e = resolve(c, a1);
-        float v = eval_value(a3, e);
+        float v = eval_value<TOPQ>(a3, e, c, 0);
         if (a0 == 0) gstat_set(a2, v);
         else { int a = agent_of(e); if (a >= 0) astat_set(a, a2, v); }
         break;
@@ -323,6 +645,8 @@ struct MgxEnvT {  // per-lane view of one env
         cell(ry >> 8, ry & 0xFF) = (uint16_t)(c.actor + 1);
         d.obj_rc[so(c.actor)] = ry;
         d.obj_rc[so(c.target)] = rx;
+        territory_moved(c.actor);  // on_object_moved twice (core/grid.hpp:100-103)
+        territory_moved(c.target);
         astat_add(xa, mgx_wk(d, MGX_S_SWAP), 1.f);
         break;
       }
@@ -340,6 +664,100 @@ struct MgxEnvT {  // per-lane view of one env
         if constexpr (DEPTH > 0) { if (after >= 0) apply_handler<DEPTH - 1>(after, c); }
         break;
       }
+      default:
+        if constexpr (X) mutate_ext<DEPTH>(m, c);
+        else flag(4u);
+        break;
+    }
+  }
+  template <int DEPTH>
+  __device__ void mutate_ext(PP m, MgxCtx& c) const {
+    int a0 = m[MGX_MU_A0], a1 = m[MGX_MU_A1], a2 = m[MGX_MU_A2], a3 = m[MGX_MU_A3];
+    switch (m[MGX_MU_OP]) {
+      case MGX_MOP_ADD_TAG: add_tag<DEPTH>(resolve(c, a0), a1, c); break;        // tag_mutation.hpp:16-30
+      case MGX_MOP_REMOVE_TAG: remove_tag<DEPTH>(resolve(c, a0), a1, c); break;  // :32-45
+      case MGX_MOP_REMOVE_TAGS_PREFIX: {                                         // :47-67
+        int e = resolve(c, a0);
+        PP ids = P + d.sec[MGX_SEC_WORDLIST] + a1;
+        for (int i = 0; i < a2; i++) remove_tag<DEPTH>(e, ids[i], c);
+        break;
+      }
+      case MGX_MOP_GAME_VALUE: {  // game_value_mutation.hpp:21-27 (a0 target entity, a1 value, a2 source)
+        int e = resolve(c, a0);
+        float delta = eval_value<TOPQ>(a2, e, c, 0);
+        PP V = P + d.sec[MGX_SEC_OBS_VALUES] + a1 * MGX_OV_WORDS;
+        PP code = P + d.sec[MGX_SEC_GV_CODE] + V[MGX_OV_GV_START] * MGX_GV_WORDS;
+        if (code[MGX_GV_OP] == MGX_GOP_INVENTORY) {
+          if (e >= 0) inv_update<1>(e, code[MGX_GV_A0], (int)delta);
+        } else if (code[MGX_GV_OP] == MGX_GOP_STAT) {
+          if (code[MGX_GV_A0] == 1) gstat_add(code[MGX_GV_A1], delta);
+          else { int a = agent_of(e); if (a >= 0) astat_add_touch(a, code[MGX_GV_A1], delta); }
+        }
+        break;
+      }
+      case MGX_MOP_RECOMPUTE_QUERY: recompute_query<DEPTH>(a0, c); break;
+      case MGX_MOP_QUERY_INVENTORY: {  // query_inventory_mutation.hpp:26-52
+        int n = eval_query<TOPQ>(a0, c, 0);
+        const uint16_t* res = qbuf(QB_BASE);
+        PP dl = P + d.sec[MGX_SEC_WORDLIST] + a1;
+        PP sn = P + d.sec[MGX_SEC_WORDLIST] + m[MGX_MU_A4];
+        int nsn = m[MGX_MU_PAD0];
+        if (a3 >= 0) {
+          int srcobj = resolve(c, a3);
+          if (srcobj < 0) break;
+          for (int k = 0; k < n; k++)
+            for (int i = 0; i < a2; i++) {
+              int o = res[k], item = dl[i * 2], delta = dl[i * 2 + 1], actual = 0;
+              if (delta > 0) actual = transfer(srcobj, o, item, delta);
+              else if (delta < 0) actual = transfer(o, srcobj, item, -delta);
+              if (actual != 0)
+                for (int q = nsn - 1; q >= 0; q--)
+                  if (sn[q * 2] == item) { gstat_add(sn[q * 2 + 1], (float)actual); break; }
+            }
+        } else {
+          for (int k = 0; k < n; k++)
+            for (int i = 0; i < a2; i++) inv_update<1>(res[k], dl[i * 2], dl[i * 2 + 1]);
+        }
+        break;
+      }
+      default: flag(4u); break;
+    }
+  }
+  template <int DEPTH>
+  __device__ void recompute_query(int tag, const MgxCtx& c) const {  // query_system.cpp:119-175
+    MgxCtx t = c;
+    t.skip_trigger = true;
+    uint16_t* lost = qbuf(QB_LOST);
+    uint16_t* keep = qbuf(QB_KEEP);
+    int nl = 0, nk = 0;
+    PP mq = P + d.sec[MGX_SEC_MATQ];
+    for (int i = 0; i < d.n_matq; i++, mq += MGX_MQ_WORDS) {
+      if (mq[MGX_MQ_TAG] != tag) continue;
+      int li = tag_list(tag);
+      if (li >= 0) { nl = tl_count(li); const uint16_t* it = tl_items(li); for (int k = 0; k < nl; k++) lost[k] = it[k]; }
+      for (int k = 0; k < nl; k++) { t.actor = t.target = lost[k]; remove_tag<DEPTH>(lost[k], tag, t); }
+      int n = eval_query<TOPQ>(mq[MGX_MQ_QUERY], c, 0);
+      const uint16_t* res = qbuf(QB_BASE);
+      for (int k = 0; k < n; k++) {
+        int o = res[k];
+        bool dup = false;
+        for (int q = 0; q < nk; q++) dup |= keep[q] == (uint16_t)o;
+        if (!dup) keep[nk++] = (uint16_t)o;
+        t.actor = t.target = o;
+        add_tag<DEPTH>(o, tag, t);
+      }
+      break;
+    }
+    t.skip_trigger = false;
+    for (int k = 0; k < nl; k++) {
+      bool kept = false;
+      for (int q = 0; q < nk; q++) kept |= keep[q] == lost[k];
+      if (!kept) { t.actor = t.target = lost[k]; fire_tag_handlers<DEPTH>(lost[k], tag, MGX_C_TAG_REMOVE_START, t); }
+    }
+    for (int q = 0; q < nk; q++) {
+      bool had = false;
+      for (int k = 0; k < nl; k++) had |= lost[k] == keep[q];
+      if (!had) { t.actor = t.target = keep[q]; fire_tag_handlers<DEPTH>(keep[q], tag, MGX_C_TAG_ADD_START, t); }
     }
   }
 
@@ -349,7 +767,7 @@ struct MgxEnvT {  // per-lane view of one env
   __device__ bool apply_handler(int h, MgxCtx& c) const {
     PP hd = P + d.sec[MGX_SEC_HANDLERS] + h * MGX_HD_WORDS;
     if (hd[MGX_HD_KIND] == MGX_HK_LEAF) {
-      if (!check_filters(hd[MGX_HD_FILTER_PC], c)) return false;
+      if (!check_filters<TOPQ>(hd[MGX_HD_FILTER_PC], c, 0)) return false;
       c.mutation_failed = false;
       PP m = P + d.sec[MGX_SEC_MUTS] + hd[MGX_HD_MUT_START] * MGX_MU_WORDS;
       for (int i = 0; i < hd[MGX_HD_MUT_COUNT]; i++, m += MGX_MU_WORDS) {
@@ -373,6 +791,216 @@ struct MgxEnvT {  // per-lane view of one env
     }
     return any;
   }
+  // Filters + every mutation, no stop on mutation_failed (events, AoE sources, territory handlers:
+  // handler/event.cpp:86-92, core/aoe_tracker.cpp:99-113, core/territory_tracker.cpp:62-66).
+  __device__ bool apply_all(int filter_pc, int mut_start, int mut_count, MgxCtx& c) const {
+    if (!check_filters<TOPQ>(filter_pc, c, 0)) return false;
+    PP m = P + d.sec[MGX_SEC_MUTS] + mut_start * MGX_MU_WORDS;
+    for (int i = 0; i < mut_count; i++, m += MGX_MU_WORDS) mutate<2>(m, c);
+    return true;
+  }
+
+  // ---- events (handler/event.cpp:34-101, handler/event_scheduler.cpp:36-53) ----
+  __device__ int execute_event(int ev) const {
+    for (int hop = 0; hop < 8; hop++) {  // fallback chain
+      PP E = P + d.sec[MGX_SEC_EVENTS] + ev * MGX_EV_WORDS;
+      MgxCtx g = mgx_ctx(MGX_SLOT_NONE, MGX_SLOT_NONE);
+      int n = eval_query<TOPQ>(E[MGX_EV_QUERY], g, 0);
+      uint16_t* targets = qbuf(QB_EVENT);
+      const uint16_t* res = qbuf(QB_BASE);
+      for (int i = 0; i < n; i++) targets[i] = res[i];
+      int mt = E[MGX_EV_MAX_TARGETS];
+      if (mt >= 0 && n > mt && n >= 2) {  // std::shuffle
+        uint32_t i = 1;
+        if ((n & 1) == 0) { uint32_t j = rng_below(2); uint16_t t = targets[1]; targets[1] = targets[j]; targets[j] = t; i = 2; }
+        while (i < (uint32_t)n) {
+          uint32_t s = i + 1, x = rng_below(s * (s + 1));
+          uint32_t j0 = x / (s + 1), j1 = x % (s + 1);
+          uint16_t t = targets[i]; targets[i] = targets[j0]; targets[j0] = t;
+          t = targets[i + 1]; targets[i + 1] = targets[j1]; targets[j1] = t;
+          i += 2;
+        }
+      }
+      int applied = 0;
+      for (int i = 0; i < n; i++) {
+        if (mt >= 0 && applied >= mt) break;
+        int t = targets[i];
+        MgxCtx c = mgx_ctx(t, t);
+        uint16_t rc = d.obj_rc[so(t)];
+        c.target_r = rc >> 8; c.target_c = rc & 0xFF;
+        if (apply_all(E[MGX_EV_FILTER_PC], E[MGX_EV_MUT_START], E[MGX_EV_MUT_COUNT], c)) applied++;
+      }
+      if (applied != 0 || E[MGX_EV_FALLBACK] < 0) return applied;
+      ev = E[MGX_EV_FALLBACK];
+    }
+    flag(4u);
+    return 0;
+  }
+  __device__ void process_events() const {
+    PP sc = P + d.sec[MGX_SEC_SCHEDULE];
+    uint32_t k = d.next_event[env];
+    while (k < (uint32_t)d.n_schedule && (uint32_t)sc[k * MGX_SC_WORDS + MGX_SC_TIMESTEP] <= step) {
+      execute_event(sc[k * MGX_SC_WORDS + MGX_SC_EVENT]);
+      k++;
+    }
+    d.next_event[env] = k;
+  }
+
+  // ---- AoE (core/aoe_tracker.cpp) ----
+  __device__ __forceinline__ PP aoe(int a) const { return P + d.sec[MGX_SEC_AOES] + a * MGX_AO_WORDS; }
+  __device__ bool fixed_covers(PP a, uint16_t src_rc, int r, int c) const {  // register_fixed :166-200
+    long long range = a[MGX_AO_RADIUS], dr = r - (int)(src_rc >> 8), dc = c - (int)(src_rc & 0xFF);
+    if (dr < -range || dr > range || dc < -range || dc > range) return false;
+    long long d2 = dr * dr + dc * dc;
+    if (d2 > range * range) return false;
+    bool territory_style = a[MGX_AO_MUT_COUNT] == 0 && a[MGX_AO_PRES_COUNT] == 0 && range > 0;
+    if (territory_style && range >= 2 && d2 == range * range && (dr == 0 || dc == 0)) return false;
+    return true;
+  }
+  __device__ void presence(PP a, int target, int mult) const {  // apply_presence_deltas :122-126
+    PP pr = P + d.sec[MGX_SEC_PRESENCE] + a[MGX_AO_PRES_START] * MGX_PR_WORDS;
+    for (int i = 0; i < a[MGX_AO_PRES_COUNT]; i++, pr += MGX_PR_WORDS) inv_update<1>(target, pr[MGX_PR_RESOURCE], pr[MGX_PR_DELTA] * mult);
+  }
+  __device__ void apply_fixed(int ai) const {  // :278-362
+    const int nf = d.fx_count[env];
+    if (nf == 0) return;
+    const int tgt = d.ag_obj[ao(ai)];
+    const uint16_t rc = d.obj_rc[so(tgt)];
+    const int r = rc >> 8, c = rc & 0xFF;
+    const size_t fb = (size_t)env * d.NF;
+    xl.def_delta[13 * xl.stride + xl.lane] = 0;  // seen mask
+    xl.def_delta[14 * xl.stride + xl.lane] = 0;  // count
+    // exits first.  The reference walks an unordered_set<AOESource*> here (address order); registration order is used.
+    for (int f = 0; f < nf; f++) {
+      uint32_t& w = d.fx_inside[(fb + f) * d.AW + (ai >> 5)];
+      if (!((w >> (ai & 31)) & 1u)) continue;
+      PP a = aoe(d.fx_aoe[fb + f]);
+      if (!fixed_covers(a, d.fx_rc[fb + f], r, c)) { w &= ~(1u << (ai & 31)); presence(a, tgt, -1); }
+    }
+    for (int f = 0; f < nf; f++) {
+      PP a = aoe(d.fx_aoe[fb + f]);
+      if (!fixed_covers(a, d.fx_rc[fb + f], r, c)) continue;
+      if (a[MGX_AO_MUT_COUNT] == 0 && a[MGX_AO_PRES_COUNT] == 0) continue;
+      const int src = d.fx_obj[fb + f];
+      bool skip_self = !a[MGX_AO_EFFECT_SELF] && src == tgt;
+      MgxCtx fc = mgx_ctx(src, tgt);
+      fc.deferred = true;
+      bool passes = !skip_self && check_filters<TOPQ>(a[MGX_AO_FILTER_PC], fc, 0);
+      uint32_t& w = d.fx_inside[(fb + f) * d.AW + (ai >> 5)];
+      bool was = (w >> (ai & 31)) & 1u;
+      if (passes && !was) { w |= 1u << (ai & 31); presence(a, tgt, +1); }
+      else if (!passes && was) { w &= ~(1u << (ai & 31)); presence(a, tgt, -1); }
+      if (passes && a[MGX_AO_MUT_COUNT] > 0) {
+        MgxCtx ac = mgx_ctx(src, tgt);
+        ac.deferred = true;
+        apply_all(a[MGX_AO_FILTER_PC], a[MGX_AO_MUT_START], a[MGX_AO_MUT_COUNT], ac);
+      }
+    }
+    const int cnt = xl.def_delta[14 * xl.stride + xl.lane];
+    for (int k = 0; k < cnt; k++) {  // net delta per resource, first-seen order (:347-361)
+      int res = xl.def_delta[(15 + k) * xl.stride + xl.lane];
+      int dl = xl.def_delta[res * xl.stride + xl.lane];
+      if (dl != 0) inv_update<1>(tgt, res, dl);
+    }
+  }
+  __device__ void apply_mobile() const {  // :364-415
+    const int nm = d.mb_count[env];
+    const size_t mb = (size_t)env * d.NM;
+    for (int m = 0; m < nm; m++) {
+      PP a = aoe(d.mb_aoe[mb + m]);
+      const int src = d.mb_obj[mb + m];
+      const long long range = a[MGX_AO_RADIUS];
+      for (int ai = 0; ai < d.A; ai++) {
+        const int tgt = d.ag_obj[ao(ai)];
+        if (!a[MGX_AO_EFFECT_SELF] && src == tgt) continue;
+        uint32_t& w = d.mb_inside[(mb + m) * d.AW + (ai >> 5)];
+        bool was = (w >> (ai & 31)) & 1u;
+        uint16_t s = d.obj_rc[so(src)], t = d.obj_rc[so(tgt)];
+        long long dr = (int)(s >> 8) - (int)(t >> 8), dc = (int)(s & 0xFF) - (int)(t & 0xFF);
+        if (dr * dr + dc * dc > range * range) {
+          if (was) { w &= ~(1u << (ai & 31)); presence(a, tgt, -1); }
+          continue;
+        }
+        MgxCtx c = mgx_ctx(src, tgt);
+        if (check_filters<TOPQ>(a[MGX_AO_FILTER_PC], c, 0)) {
+          if (!was) { w |= 1u << (ai & 31); presence(a, tgt, +1); }
+          if (a[MGX_AO_MUT_COUNT] > 0) { MgxCtx ac = mgx_ctx(src, tgt); apply_all(a[MGX_AO_FILTER_PC], a[MGX_AO_MUT_START], a[MGX_AO_MUT_COUNT], ac); }
+        } else if (was) {
+          w &= ~(1u << (ai & 31));
+          presence(a, tgt, -1);
+        }
+      }
+    }
+  }
+
+  // ---- territory (core/territory_tracker.cpp) ----
+  __device__ int cell_owner(int r, int c, int ti) const {  // compute_cell_ownership :215-252 -> winning tag or -1
+    PP TE = P + d.sec[MGX_SEC_TERRITORIES] + ti * MGX_TE_WORDS;
+    PP prefix = P + d.sec[MGX_SEC_WORDLIST] + TE[MGX_TE_TAGS_START];
+    const int np = min(TE[MGX_TE_TAGS_COUNT], 8);
+    if (TE[MGX_TE_TAGS_COUNT] > 8) flag(4u);
+    long long* score = xl.terr_score + xl.lane;
+    for (int k = 0; k < np; k++) score[k * xl.stride] = 0;
+    const size_t tb = (size_t)env * d.NTS;
+    const int n = d.ts_count[env];
+    for (int i = 0; i < n; i++) {
+      PP tc = P + d.sec[MGX_SEC_TERR_CONTROLS] + d.ts_ctrl[tb + i] * MGX_TC_WORDS;
+      if (tc[MGX_TC_TERRITORY] != ti) continue;
+      const int strength = tc[MGX_TC_STRENGTH], decay = tc[MGX_TC_DECAY];
+      const long long range = decay > 0 ? strength / decay : strength;
+      const uint16_t reg = d.ts_rc[tb + i];
+      long long dr = r - (int)(reg >> 8), dc = c - (int)(reg & 0xFF);
+      if (dr < -range || dr > range || dc < -range || dc > range || dr * dr + dc * dc > range * range) continue;
+      const int src = d.ts_obj[tb + i];
+      int k = 0;
+      while (k < np && !has_tag(src, prefix[k])) k++;
+      if (k >= np) continue;
+      const uint16_t cur = d.obj_rc[so(src)];  // the score uses the source's CURRENT location (:230-231)
+      long long sr = (int)(cur >> 8) - r, sc = (int)(cur & 0xFF) - c;
+      unsigned long long d2 = (unsigned long long)(sr * sr + sc * sc);
+      long long s = (long long)strength * 1024 - (long long)decay * (long long)mgx_floor_sqrt(d2 << 20);
+      if (s > 0) score[k * xl.stride] += s;
+    }
+    // unique maximum wins, any tie at the maximum -> none.  Tags are visited in ascending id like the oracle; the
+    // reference's unordered_map order does not matter for this rule.
+    int win = -1;
+    long long best = 0;
+    bool tied = false;
+    for (int t = 0; t < 256; t++) {
+      int k = 0;
+      while (k < np && prefix[k] != t) k++;
+      if (k >= np) continue;
+      long long s = score[k * xl.stride];
+      if (s <= 0) continue;
+      if (s > best) { win = t; best = s; tied = false; }
+      else if (s == best && win >= 0) tied = true;
+    }
+    return tied ? -1 : win;
+  }
+  __device__ void run_territory_handlers(int start, int count, int tag, int tgt) const {
+    for (int i = 0; i < count; i++) {
+      PP hd = P + d.sec[MGX_SEC_HANDLERS] + (start + i) * MGX_HD_WORDS;
+      MgxCtx c = mgx_ctx(MGX_SLOT_PROXY, tgt);
+      c.proxy_tag = tag;
+      uint16_t rc = d.obj_rc[so(tgt)];
+      c.target_r = rc >> 8; c.target_c = rc & 0xFF;
+      apply_all(hd[MGX_HD_FILTER_PC], hd[MGX_HD_MUT_START], hd[MGX_HD_MUT_COUNT], c);
+    }
+  }
+  __device__ void apply_territory(int ai) const {  // apply_effects :275-346
+    const int tgt = d.ag_obj[ao(ai)];
+    for (int ti = 0; ti < d.NT; ti++) {
+      PP TE = P + d.sec[MGX_SEC_TERRITORIES] + ti * MGX_TE_WORDS;
+      uint16_t rc = d.obj_rc[so(tgt)];
+      int cur = cell_owner(rc >> 8, rc & 0xFF, ti);
+      int16_t& pv = d.terr_prev[ao(ai) * d.NT + ti];
+      int prev = pv;
+      if (prev != cur && prev >= 0) run_territory_handlers(TE[MGX_TE_EXIT_START], TE[MGX_TE_EXIT_COUNT], prev, tgt);
+      if (prev != cur && cur >= 0) run_territory_handlers(TE[MGX_TE_ENTER_START], TE[MGX_TE_ENTER_COUNT], cur, tgt);
+      pv = (int16_t)cur;
+      if (cur >= 0) run_territory_handlers(TE[MGX_TE_PRES_START], TE[MGX_TE_PRES_COUNT], cur, tgt);
+    }
+  }
 
   // ---- actions ----
   __device__ bool do_move(int slot, int orient) const {  // actions/move.hpp:81-115, orientation.hpp:28-48
@@ -386,9 +1014,8 @@ struct MgxEnvT {  // per-lane view of one env
         if (r < 0 || c < 0 || r >= d.H || c >= d.W) break;
         int t = (int)cell(r, c) - 1;
         if (t < 0 && !mh[MGX_MH_ACCEPTS_EMPTY]) continue;
-        MgxCtx ctx;
-        ctx.actor = slot; ctx.target = t; ctx.target_r = r; ctx.target_c = c; ctx.move_direction = orient;
-        ctx.mutation_failed = false;
+        MgxCtx ctx = mgx_ctx(slot, t);
+        ctx.target_r = r; ctx.target_c = c; ctx.move_direction = orient;
         if (apply_handler<3>(mh[MGX_MH_HANDLER], ctx)) return true;
         break;
       }
@@ -466,7 +1093,8 @@ struct MgxEnvT {  // per-lane view of one env
   }
 };
 
-typedef MgxEnvT<MgxGlobalProg> MgxEnv;
+typedef MgxEnvT<MgxGlobalProg, false> MgxEnv;
+typedef MgxEnvT<MgxGlobalProg, true> MgxEnvX;
 
 // order: LDS, [k][lane] bytes (k-major so that a wavefront access is bank-conflict free)
 __device__ __forceinline__ void mgx_swap(uint8_t* order, int lane, int i, int j) {
@@ -475,9 +1103,10 @@ __device__ __forceinline__ void mgx_swap(uint8_t* order, int lane, int i, int j)
   order[j * MGX_WAVE + lane] = a;
 }
 
-template <class PP>
-__device__ __forceinline__ void mgx_world_body(const MgxDev& d, PP P, uint8_t* order, int lane, int env) {
-  MgxEnvT<PP> e(d, P, env);
+template <class PP, bool X>
+__device__ __forceinline__ void mgx_world_body(const MgxDev& d, PP P, uint8_t* order, MgxXLds xl, int lane, int env) {
+  MgxEnvT<PP, X> e(d, P, env);
+  e.xl = xl;
   const int A = d.A;
   e.step = ++d.step[env];
 
@@ -531,39 +1160,72 @@ __device__ __forceinline__ void mgx_world_body(const MgxDev& d, PP P, uint8_t* o
       }
     }
   }
+  if constexpr (X) {
+    if (d.n_schedule > 0) e.process_events();  // mettagrid_c.cpp:1009-1011
+  }
   if (d.any_on_tick) {
     for (int i = 0; i < A; i++) {  // per-agent on_tick (mettagrid_c.cpp:1019-1024)
       int slot = d.ag_obj[e.ao(i)];
       int h = e.cls_of(slot)[MGX_C_ON_TICK];
       if (h >= 0) {
-        MgxCtx c;
-        c.actor = c.target = slot; c.target_r = c.target_c = 0; c.move_direction = 0; c.mutation_failed = false;
+        MgxCtx c = mgx_ctx(slot, slot);
         e.template apply_handler<3>(h, c);
       }
+    }
+  }
+  if constexpr (X) {
+    if (d.NF > 0 || d.NT > 0)
+      for (int i = 0; i < A; i++) {  // mettagrid_c.cpp:1032-1035
+        if (d.NF > 0) e.apply_fixed(i);
+        if (d.NT > 0) e.apply_territory(i);
+      }
+    if (d.NM > 0) e.apply_mobile();  // :1038
+    if (d.game_on_tick >= 0) {       // :1050-1052
+      MgxCtx c = mgx_ctx(MGX_SLOT_NONE, MGX_SLOT_NONE);
+      e.template apply_handler<3>(d.game_on_tick, c);
     }
   }
   for (int i = 0; i < A; i++) e.track_coverage(i);  // mettagrid_c.cpp:1054-1056
 }
 
 // PROG_LDS: the program blob is first copied into LDS (16-byte coalesced loads) and every table lookup of the
-// handler VM becomes a ds_read.  Dynamic LDS: order u8[A][64] | program i32[prog_words].
-template <bool PROG_LDS>
+// handler VM becomes a ds_read.  Dynamic LDS: order u8[A][64] | [X: deferred i32[28][64] | territory i64[8][64]] |
+// program i32[prog_words].
+__host__ __device__ inline int mgx_world_lds_fixed(int A, bool X) {
+  int o = (A * MGX_WAVE + 15) & ~15;
+  if (X) o += 28 * MGX_WAVE * 4 + 8 * MGX_WAVE * 8;
+  return o;
+}
+template <bool PROG_LDS, bool X>
 __global__ void __launch_bounds__(MGX_WAVE) mgx_world_kernel(MgxDev d, int prog_words) {
   extern __shared__ __align__(16) uint8_t wsmem[];
   uint8_t* order = wsmem;
   const int lane = threadIdx.x;
   const int env = blockIdx.x * MGX_WAVE + lane;
+  MgxXLds xl;
+  xl.lane = lane;
+  xl.stride = MGX_WAVE;
+  int off = (d.A * MGX_WAVE + 15) & ~15;
+  if (X) {
+    xl.def_delta = (int*)(wsmem + off);
+    off += 28 * MGX_WAVE * 4;
+    xl.terr_score = (long long*)(wsmem + off);
+    off += 8 * MGX_WAVE * 8;
+  } else {
+    xl.def_delta = nullptr;
+    xl.terr_score = nullptr;
+  }
   if (PROG_LDS) {
-    int32_t* lprog = (int32_t*)(wsmem + ((d.A * MGX_WAVE + 15) & ~15));
+    int32_t* lprog = (int32_t*)(wsmem + off);
     const int4* src = (const int4*)d.P;
     int4* dst = (int4*)lprog;
     for (int i = lane; i < prog_words / 4; i += MGX_WAVE) dst[i] = src[i];
     __syncthreads();
     if (env >= d.E) return;
-    mgx_world_body<MgxLdsProg>(d, (MgxLdsProg)lprog, order, lane, env);
+    mgx_world_body<MgxLdsProg, X>(d, (MgxLdsProg)lprog, order, xl, lane, env);
   } else {
     if (env >= d.E) return;
-    mgx_world_body<MgxGlobalProg>(d, d.P, order, lane, env);
+    mgx_world_body<MgxGlobalProg, X>(d, d.P, order, xl, lane, env);
   }
 }
 
@@ -572,7 +1234,7 @@ __global__ void __launch_bounds__(MGX_WAVE) mgx_world_kernel(MgxDev d, int prog_
 __global__ void __launch_bounds__(MGX_WAVE) mgx_init_kernel(MgxDev d, const uint16_t* class_maps, const uint32_t* seeds) {
   const int env = blockIdx.x * MGX_WAVE + threadIdx.x;
   if (env >= d.E) return;
-  MgxEnv e(d, d.P, env);
+  MgxEnvX e(d, d.P, env);
   const size_t E = (size_t)d.E;
   uint32_t x = seeds[env];  // std::mt19937(seed): bits/random.tcc seed()
   d.mt[env] = x;
@@ -588,7 +1250,7 @@ __global__ void __launch_bounds__(MGX_WAVE) mgx_init_kernel(MgxDev d, const uint
   e.gstat_touch(mgx_wk(d, MGX_S_GAME_TOKENS_FREE));
   const int HW = d.H * d.W;
   const uint16_t* cm = class_maps + (size_t)env * HW;
-  int nobj = 0, nag = 0;
+  int nobj = 0, nag = 0, nf = 0, nm = 0, nts = 0;
   for (int cellidx = 0; cellidx < HW; cellidx++) {
     int k = cm[cellidx];
     if (!k) continue;
@@ -597,15 +1259,15 @@ __global__ void __launch_bounds__(MGX_WAVE) mgx_init_kernel(MgxDev d, const uint
     int cls = k - 1;
     const int32_t* C = mgx_cls(d, cls);
     int r = cellidx / d.W, c = cellidx % d.W;
+    const uint16_t rc = (uint16_t)((r << 8) | c);
     d.grid[(size_t)env * HW + cellidx] = (uint16_t)(slot + 1);
     d.obj_cls[e.so(slot)] = (uint16_t)cls;
-    d.obj_rc[e.so(slot)] = (uint16_t)((r << 8) | c);
+    d.obj_rc[e.so(slot)] = rc;
     d.obj_vibe[e.so(slot)] = (uint8_t)C[MGX_C_INITIAL_VIBE];
     int ai = -1;
     if (C[MGX_C_KIND] == MGX_KIND_AGENT && nag < d.A) {
       ai = nag++;
       d.ag_obj[e.ao(ai)] = (uint16_t)slot;
-      uint16_t rc = (uint16_t)((r << 8) | c);
       d.ag_prev[e.ao(ai)] = rc;
       d.ag_spawn[e.ao(ai)] = rc;
       d.ag_stepprev[e.ao(ai)] = rc;
@@ -619,8 +1281,55 @@ __global__ void __launch_bounds__(MGX_WAVE) mgx_init_kernel(MgxDev d, const uint
       if (ai >= 0) e.astat_set(ai, mgx_wk(d, MGX_S_RES_AMOUNT_BASE) + ii[MGX_II_ITEM], (float)ii[MGX_II_AMOUNT]);
     }
     e.gstat_add(C[MGX_C_OBJECTS_STAT], 1.f);
+    if (d.X) {
+      if (d.obj_tags)
+        for (int w = 0; w < MGX_TAG_WORDS; w++) d.obj_tags[e.so(slot) * MGX_TAG_WORDS + w] = (uint32_t)C[MGX_C_TAGS + w];
+      for (int t = 0; t < 256 && d.NL > 0; t++) {  // TagIndex::register_object (core/tag_index.cpp:9-19)
+        if (!(((uint32_t)C[MGX_C_TAGS + (t >> 5)] >> (t & 31)) & 1u)) continue;
+        int li = e.tag_list(t);
+        if (li >= 0) { uint16_t n = e.tl_count(li); e.tl_items(li)[n] = (uint16_t)slot; e.tl_count(li) = n + 1; }
+      }
+      for (int i = 0; i < C[MGX_C_AOE_COUNT]; i++) {  // AOETracker::register_source (mettagrid_c.cpp:249-252)
+        int a = C[MGX_C_AOE_START] + i;
+        const int32_t* AO = d.P + d.sec[MGX_SEC_AOES] + a * MGX_AO_WORDS;
+        if (AO[MGX_AO_STATIC]) {
+          if (nf < d.NF) { size_t q = (size_t)env * d.NF + nf; d.fx_obj[q] = (uint16_t)slot; d.fx_aoe[q] = (uint16_t)a; d.fx_rc[q] = rc; nf++; }
+        } else if (nm < d.NM) {
+          size_t q = (size_t)env * d.NM + nm; d.mb_obj[q] = (uint16_t)slot; d.mb_aoe[q] = (uint16_t)a; nm++;
+        }
+      }
+      for (int i = 0; i < C[MGX_C_TERR_COUNT]; i++)  // TerritoryTracker::register_source (:254-257)
+        if (nts < d.NTS) { size_t q = (size_t)env * d.NTS + nts; d.ts_obj[q] = (uint16_t)slot; d.ts_ctrl[q] = (uint16_t)(C[MGX_C_TERR_START] + i); d.ts_rc[q] = rc; nts++; }
+    }
   }
   d.num_objs[env] = (uint32_t)nobj;
+  if (d.X) {
+    if (d.NF) d.fx_count[env] = (uint16_t)nf;
+    if (d.NM) d.mb_count[env] = (uint16_t)nm;
+    if (d.NTS) d.ts_count[env] = (uint16_t)nts;
+    for (int i = 0; i < d.A * d.NT; i++) d.terr_prev[(size_t)env * d.A * d.NT + i] = -1;
+    d.next_event[env] = 0;
+    // QuerySystem::compute_all (query_system.cpp:91-117, mettagrid_c.cpp:162-163)
+    const int32_t* mq = d.P + d.sec[MGX_SEC_MATQ];
+    for (int i = 0; i < d.n_matq; i++, mq += MGX_MQ_WORDS) {
+      MgxCtx t = mgx_ctx(MGX_SLOT_NONE, MGX_SLOT_NONE);
+      t.skip_trigger = true;
+      int tag = mq[MGX_MQ_TAG];
+      int li = e.tag_list(tag);
+      if (li >= 0) {
+        uint16_t* lost = e.qbuf(MgxEnvX::QB_LOST);
+        int nl = e.tl_count(li);
+        for (int k = 0; k < nl; k++) lost[k] = e.tl_items(li)[k];
+        for (int k = 0; k < nl; k++) e.remove_tag<0>(lost[k], tag, t);
+      }
+      MgxCtx g = mgx_ctx(MGX_SLOT_NONE, MGX_SLOT_NONE);
+      int n = e.eval_query<3>(mq[MGX_MQ_QUERY], g, 0);
+      uint16_t* keep = e.qbuf(MgxEnvX::QB_KEEP);
+      const uint16_t* res = e.qbuf(MgxEnvX::QB_BASE);
+      for (int k = 0; k < n; k++) keep[k] = res[k];
+      for (int k = 0; k < n; k++) e.add_tag<0>(keep[k], tag, t);
+    }
+  }
   for (int ai = 0; ai < nag; ai++) {
     e.track_coverage(ai);  // Agent::init -> reset_coverage_tracking (agent.cpp:25-28,41-47)
     const int32_t* C = e.cls_of(d.ag_obj[e.ao(ai)]);

@@ -31,6 +31,7 @@ def test_bad_program_is_rejected_without_touching_the_gpu():
 
 def test_header_constants_parse():
     from mettagrid_amd.fmt import K
-    assert K.MAGIC == 0x3158474D and K.C_WORDS == K.C_RES_LIMIT + K.MAX_RESOURCES
+    assert K.MAGIC == 0x3158474D and K.C_WORDS % 4 == 0 and K.C_WORDS > K.C_TERR_COUNT
     assert K.H_SECTION_BASE + 2 * K.SEC_COUNT <= K.H_WORDS
-    assert K.H_STAT_BASE + K.S_GAME_TOKENS_FREE < K.H_SECTION_BASE
+    assert K.H_STAT_BASE + K.S_GAME_TOKENS_FREE < K.H_SECTION_BASE and K.H_QUERY_DEPTH < K.H_FEAT_BASE
+    assert K.AT_WORDS == K.MU_WORDS == K.HD_WORDS == K.Q_WORDS == 8
