@@ -18,7 +18,7 @@
 #include <stdint.h>
 
 #define MGX_MAGIC 0x3158474d /* "MGX1" little-endian */
-#define MGX_VERSION 5
+#define MGX_VERSION 6
 
 #define MGX_MAX_RESOURCES 13 /* inventory order list = 4-bit ids in one u64, 0xF terminator; see DESIGN.md */
 #define MGX_TAG_WORDS 8      /* 256 tags = 8 x u32 (reference kMaxTags, core/types.hpp:62) */
@@ -61,6 +61,7 @@ enum {
   MGX_H_DYNAMIC_TAGS,    /* 1: objects carry their own tag bitset (tag mutations / materialized queries / territories) */
   MGX_H_NUM_INDEXED_TAGS,/* tags that own a TagIndex list (referenced by a TagQuery) */
   MGX_H_QUERY_DEPTH,     /* max nesting of queries */
+  MGX_H_SPAWNS,          /* 1: the program can create objects at run time (Spawn / RaycastSpawn) */
   MGX_H_FEAT_BASE = 40, /* MGX_F_* feature ids follow */
   MGX_H_STAT_BASE = 56, /* MGX_S_* well-known stat ids follow */
   MGX_H_SECTION_BASE = 104, /* section s: offset at BASE+2s, record count at BASE+2s+1 */
@@ -179,6 +180,9 @@ enum {
   MGX_MOP_ADD_TAG, MGX_MOP_REMOVE_TAG, /* a0 entity, a1 tag                    tag_mutation.hpp:16-45 */
   MGX_MOP_REMOVE_TAGS_PREFIX, /* a0 entity, a1 WORDLIST start, a2 count         tag_mutation.hpp:47-67 */
   MGX_MOP_RECOMPUTE_QUERY,    /* a0 tag                                         recompute_materialized_query_mutation.hpp */
+  MGX_MOP_PUSH_OBJECT,        /*                                                push_object_mutation.hpp:29-71 */
+  MGX_MOP_SPAWN_OBJECT,       /* a0 class                                       spawn_object_mutation.cpp:10-64 */
+  MGX_MOP_RAYCAST_SPAWN,      /* a0 class, a1 WORDLIST (dr, dc) pairs, a2 count, a3 max_range value, a4 blocker pc  raycast_spawn_mutation.cpp:15-92 */
   MGX_MOP_QUERY_INVENTORY     /* a0 query, a1 WORDLIST (res, delta) pairs, a2 count, a3 source entity or -1,
                                  a4 WORDLIST (res, game stat id) pairs, PAD0 = their count   query_inventory_mutation.hpp:22-75 */
 };

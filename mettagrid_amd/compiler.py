@@ -150,6 +150,9 @@ class _Compiler:
         self.header = [0] * K.H_WORDS
         self.atom_labels: list = []  # (word index in atoms section, label)
         self.indexed_tags: set = set()
+        self.spawns = False
+        self.removals = False
+        self.pending_class_refs: list = []
         self.query_depth = 0
         self._qdepth = 0          # nesting level of the query currently being emitted (filters/values inherit it)
         self.dynamic_tags = False
@@ -221,7 +224,7 @@ class _Compiler:
     # ---- emit helpers ----------------------------------------------------------------------------------------
     def emit(self, sec: int, rec: list[int]) -> int:
         idx = self.counts[sec]
-        self.sections[sec].extend(int(x) for x in rec)
+        self.sections[sec].extend(x if isinstance(x, tuple) else int(x) for x in rec)
         self.counts[sec] += 1
         return idx
 
@@ -417,9 +420,9 @@ class _Compiler:
             return [K.MOP_RESOURCE_DELTA, self.ent(m.entity), self.res_id[m.resource], m.delta, 0, 0]
         if isinstance(m, S.ResourceTransfer):
             if m.remove_source_when_empty:
-                raise UnsupportedFeature("ResourceTransfer.remove_source_when_empty is not supported yet")
+                self.removals = True
             return [K.MOP_RESOURCE_TRANSFER, self.ent(m.source), self.ent(m.destination), self.res_id[m.resource],
-                    m.amount, 0]
+                    m.amount, 1 if m.remove_source_when_empty else 0]
         if isinstance(m, S.ClearInventory):
             ids = [self.res_id[r] for r in m.resources]
             off = self.emit_words(ids) if ids else 0
@@ -453,6 +456,18 @@ class _Compiler:
             return [K.MOP_QUERY_INVENTORY, self.query(m.query), self.emit_words(pairs) if pairs else 0, len(pairs) // 2,
                     -1 if m.source is None else self.ent(m.source), self.emit_words(stats) if stats else 0,
                     len(stats) // 2]
+        if isinstance(m, S.PushObject):
+            return [K.MOP_PUSH_OBJECT, 0, 0, 0, 0, 0]
+        if isinstance(m, (S.SpawnObject, S.RaycastSpawn)):
+            self.spawns = True
+            self.dynamic_tags = True      # spawned objects register with the tag index at run time
+            self.pending_class_refs.append(m.object_type)
+            if isinstance(m, S.SpawnObject):
+                return [K.MOP_SPAWN_OBJECT, ("class", m.object_type), 0, 0, 0, 0]
+            dirs = [x for d in m.directions for x in d]
+            blocker = self.filters_emit([S.OrFilter(list(m.blocker))]) if m.blocker else K.PC_FAIL
+            return [K.MOP_RAYCAST_SPAWN, ("class", m.object_type), self.emit_words(dirs) if dirs else 0,
+                    len(m.directions), self.value_ref(m.max_range), blocker]
         if isinstance(m, S.Relocate):
             return [K.MOP_RELOCATE, 0, 0, 0, 0, 0]
         if isinstance(m, S.Swap):
@@ -679,7 +694,11 @@ class _Compiler:
             if not isinstance(h, S.Handler):
                 raise TypeError("move handlers must be plain Handler objects")
             accepts_empty = any(isinstance(f, S.TargetLocEmptyFilter) for f in h.filters)
-            move_handlers.append((self.handler(h), 1, accepts_empty))  # max_range: no MaxDistance filter yet
+            max_range = 1
+            for f in h.filters:  # actions/move.hpp:31-40: the last MaxDistance filter sets the scan range
+                if isinstance(f, S.MaxDistanceFilter):
+                    max_range = f.radius if f.radius > 0 else 1
+            move_handlers.append((self.handler(h), max_range, accepts_empty))
         move_handlers.append((self.handler(S.Handler([S.TargetLocEmptyFilter()], [S.Relocate()], "move")), 1, True))
         move_handlers.append((self.handler(S.Handler([S.TargetIsUsableFilter()], [S.UseTarget()], "use_target")),
                               1, False))
@@ -903,6 +922,19 @@ class _Compiler:
         h[K.H_NUM_GAME_STATS] = len(self.game_stats)
         if len(self.agent_stats) > 1024 or len(self.game_stats) > 1024:
             raise RuntimeError("Exceeded maximum number of stats (MAX_STATS)")  # stats_tracker.hpp:57-67
+
+        # ---- resolve symbolic class references (spawn mutations may name classes emitted later) ----
+        for sec_words in self.sections.values():
+            for i, x in enumerate(sec_words):
+                if isinstance(x, tuple):
+                    if x[1] not in cell_to_class:
+                        raise ValueError(f"spawn references unknown object '{x[1]}'")
+                    sec_words[i] = cell_to_class[x[1]]
+        h[K.H_SPAWNS] = 1 if self.spawns else 0
+        if self.spawns or self.removals:
+            cw = self.sections[K.SEC_CLASSES]
+            for c in range(self.counts[K.SEC_CLASSES]):
+                cw[c * K.C_WORDS + K.C_STATIC] = 0
 
         # ---- resolve atom labels, lay out sections ----
         atoms = self.sections[K.SEC_ATOMS]

@@ -90,6 +90,9 @@ struct MgxDev {
   uint16_t* ts_count;     // [E]
   int16_t* terr_prev;     // [E][A][NT] previous owner tag or -1
   uint32_t* next_event;   // [E]
+  uint8_t* obj_flags;     // [E][S] bit0 removed from the grid, bit1 created at run time (no inventory tokens)
+  uint16_t* def_aoe;      // [E][S] objects spawned this tick whose AoEs register at flush_deferred
+  uint16_t* def_count;    // [E]
   uint16_t* qws;          // [E][QB][S] query workspace
   uint32_t* qvis;         // [E][QD+1][SW] visited bitmaps
   // ---- env-minor RNG ----

@@ -179,6 +179,12 @@ int mgx_create(const int32_t* program, size_t program_words, const uint16_t* cla
         }
         nf = std::max(nf, f); nm = std::max(nm, m); nts = std::max(nts, t);
       }
+    if (P[MGX_H_SPAWNS]) {  // spawned objects may bring AoEs: leave room for one set per object slot
+      int per_f = 0, per_m = 0;
+      for (int c = 0; c < nc; c++) { per_f = std::max(per_f, cf[c]); per_m = std::max(per_m, cm[c]); }
+      nf += per_f ? std::min<int>(d.S * per_f, 4096) : 0;
+      nm += per_m ? std::min<int>(d.S * per_m, 4096) : 0;
+    }
     d.NF = nf; d.NM = nm; d.NTS = nts;
     d.X = (any_aoe || d.NT > 0 || d.n_schedule > 0 || d.n_matq > 0 || d.game_on_tick >= 0 || P[MGX_H_DYNAMIC_TAGS] ||
            mgx_sec_cnt(P, MGX_SEC_QUERIES) > 0) ? 1 : 0;
@@ -237,6 +243,8 @@ int mgx_create(const int32_t* program, size_t program_words, const uint16_t* cla
                  A_(e->alloc(&d.ts_count, E)); }
     A_(e->alloc(&d.terr_prev, rows * std::max(1, d.NT)));
     A_(e->alloc(&d.next_event, E));
+    A_(e->alloc(&d.obj_flags, E * S));
+    if (P[MGX_H_SPAWNS]) { A_(e->alloc(&d.def_aoe, E * S)); A_(e->alloc(&d.def_count, E)); }
     A_(e->alloc(&d.qws, E * d.QB * S));
     A_(e->alloc(&d.qvis, E * (d.QD + 1) * d.SW));
   }
@@ -471,7 +479,7 @@ int mgx_get_objects(mgx_engine* e, int32_t env, int32_t* out, int32_t* n_objects
   const MgxDev& d = e->d;
   const size_t S = d.S;
   std::vector<uint16_t> cls(S), rc(S), inv(S * d.R);
-  std::vector<uint8_t> vibe(S), agent(S);
+  std::vector<uint8_t> vibe(S), agent(S), oflags(S, 0);
   std::vector<unsigned long long> ord(S);
   std::vector<uint32_t> tags(d.obj_tags ? S * MGX_TAG_WORDS : 0);
   uint32_t n = 0;
@@ -482,12 +490,13 @@ int mgx_get_objects(mgx_engine* e, int32_t env, int32_t* out, int32_t* n_objects
   if (!r) r = d2h(e, agent.data(), d.obj_agent + env * S, S);
   if (!r) r = d2h(e, inv.data(), d.obj_inv + env * S * d.R, S * d.R * 2);
   if (!r) r = d2h(e, ord.data(), d.obj_order + env * S, S * 8);
+  if (!r && d.obj_flags) r = d2h(e, oflags.data(), d.obj_flags + env * S, S);
   if (!r && d.obj_tags) r = d2h(e, tags.data(), d.obj_tags + env * S * MGX_TAG_WORDS, S * MGX_TAG_WORDS * 4);
   if (r) return r;
   for (uint32_t s = 0; s < n; s++) {
     int32_t* w = out + (size_t)s * MGX_OBJ_RECORD_WORDS;
     w[0] = (int)s + 1; w[1] = cls[s]; w[2] = rc[s] >> 8; w[3] = rc[s] & 0xFF; w[4] = vibe[s];
-    w[5] = cls[s] != MGX_DEAD_CLASS; w[6] = agent[s] == MGX_NO_AGENT ? -1 : agent[s];
+    w[5] = cls[s] != MGX_DEAD_CLASS && !(oflags[s] & 1); w[6] = agent[s] == MGX_NO_AGENT ? -1 : agent[s];
     int cnt = 0;
     for (int k = 0; k < MGX_MAX_RESOURCES; k++) {
       int item = (int)((ord[s] >> (4 * k)) & 0xF);

@@ -57,6 +57,7 @@ __device__ int mgx_object_dyn_token_count(const MgxDev& d, const ENV& e, int slo
   int n = 0;
   if (d.obj_vibe[e.so(slot)] != 0) n++;
   unsigned long long ord = d.obj_order[e.so(slot)];
+  if (d.obj_flags && (d.obj_flags[e.so(slot)] & 2)) ord = ~0ull;  // created without an ObservationEncoder
   for (int k = 0; k < 16; k++) {
     int item = (int)((ord >> (4 * k)) & 0xF);
     if (item == 0xF) break;
@@ -71,6 +72,7 @@ __device__ void mgx_object_dyn_tokens_build(const MgxDev& d, const ENV& e, int s
   uint8_t vibe = d.obj_vibe[e.so(slot)];
   if (vibe != 0) w.put((uint8_t)d.feat[MGX_F_VIBE], vibe);
   unsigned long long ord = d.obj_order[e.so(slot)];
+  if (d.obj_flags && (d.obj_flags[e.so(slot)] & 2)) ord = ~0ull;
   for (int k = 0; k < 16; k++) {  // observation_encoder.hpp:198-225: base digit, then :pK digits while remaining > 0
     int item = (int)((ord >> (4 * k)) & 0xF);
     if (item == 0xF) break;

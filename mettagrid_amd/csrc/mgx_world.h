@@ -575,6 +575,97 @@ struct MgxEnvT {  // per-lane view of one env
     return true;
   }
 
+  // ---- objects created / removed at run time ----
+  __device__ int spawn_object(int cls_id, int r, int c) const {  // create_object_from_config + Grid::add_object + TagIndex
+    if constexpr (!X) { flag(4u); return -1; } else {
+      PP C = cls(cls_id);
+      if (C[MGX_C_KIND] == MGX_KIND_AGENT) { flag(64u); return -1; }
+      uint32_t n = d.num_objs[env];
+      if ((int)n >= d.S) { flag(8u); return -1; }
+      d.num_objs[env] = n + 1;
+      const int slot = (int)n;
+      d.obj_cls[so(slot)] = (uint16_t)cls_id;
+      d.obj_rc[so(slot)] = (uint16_t)((r << 8) | c);
+      d.obj_vibe[so(slot)] = (uint8_t)C[MGX_C_INITIAL_VIBE];
+      d.obj_agent[so(slot)] = MGX_NO_AGENT;
+      d.obj_visited[so(slot)] = 0;
+      d.obj_order[so(slot)] = ~0ull;
+      for (int k = 0; k < d.R; k++) inv(slot, k) = 0;
+      d.obj_flags[so(slot)] = 2;  // no ObservationEncoder: inventory is not observable (grid_object.cpp:194)
+      cell(r, c) = (uint16_t)(slot + 1);
+      PP ii = P + d.sec[MGX_SEC_INIT_INV] + C[MGX_C_INIT_INV_START] * MGX_II_WORDS;
+      for (int i = 0; i < C[MGX_C_INIT_INV_COUNT]; i++, ii += MGX_II_WORDS) inv_update<0>(slot, ii[MGX_II_ITEM], ii[MGX_II_AMOUNT], true, true);
+      for (int w = 0; w < MGX_TAG_WORDS; w++) d.obj_tags[so(slot) * MGX_TAG_WORDS + w] = (uint32_t)C[MGX_C_TAGS + w];
+      for (int t = 0; t < 256 && d.NL > 0; t++) {
+        if (!(((uint32_t)C[MGX_C_TAGS + (t >> 5)] >> (t & 31)) & 1u)) continue;
+        int li = tag_list(t);
+        if (li >= 0) { uint16_t k = tl_count(li); if (k < d.S) { tl_items(li)[k] = (uint16_t)slot; tl_count(li) = k + 1; } }
+      }
+      if (C[MGX_C_AOE_COUNT] > 0) { uint16_t k = d.def_count[env]; d.def_aoe[(size_t)env * d.S + k] = (uint16_t)slot; d.def_count[env] = k + 1; }
+      return slot;
+    }
+  }
+  __device__ void register_aoes(int slot) const {  // AOETracker::register_source :128-134 (flush_deferred :154-159)
+    PP C = cls_of(slot);
+    for (int i = 0; i < C[MGX_C_AOE_COUNT]; i++) {
+      int a = C[MGX_C_AOE_START] + i;
+      if (aoe(a)[MGX_AO_STATIC]) {
+        uint16_t n = d.fx_count[env];
+        if (n >= d.NF) { flag(8u); continue; }
+        size_t q = (size_t)env * d.NF + n;
+        d.fx_obj[q] = (uint16_t)slot; d.fx_aoe[q] = (uint16_t)a; d.fx_rc[q] = d.obj_rc[so(slot)];
+        for (int w = 0; w < d.AW; w++) d.fx_inside[q * d.AW + w] = 0;
+        d.fx_count[env] = n + 1;
+      } else {
+        uint16_t n = d.mb_count[env];
+        if (n >= d.NM) { flag(8u); continue; }
+        size_t q = (size_t)env * d.NM + n;
+        d.mb_obj[q] = (uint16_t)slot; d.mb_aoe[q] = (uint16_t)a;
+        for (int w = 0; w < d.AW; w++) d.mb_inside[q * d.AW + w] = 0;
+        d.mb_count[env] = n + 1;
+      }
+    }
+  }
+  __device__ void remove_object(int slot) const {  // resource_mutation.hpp:88-97
+    if (agent_of(slot) >= 0) { flag(64u); return; }
+    if (d.NF) {
+      const size_t fb = (size_t)env * d.NF;
+      for (int f = 0; f < d.fx_count[env]; f++) {
+        if (d.fx_obj[fb + f] != (uint16_t)slot) continue;
+        PP a = aoe(d.fx_aoe[fb + f]);
+        for (int ai = 0; ai < d.A; ai++) {
+          uint32_t& w = d.fx_inside[(fb + f) * d.AW + (ai >> 5)];
+          if ((w >> (ai & 31)) & 1u) { w &= ~(1u << (ai & 31)); presence(a, d.ag_obj[ao(ai)], -1); }
+        }
+        d.fx_obj[fb + f] = 0xFFFF;  // unregistered
+      }
+    }
+    if (d.NM) {
+      const size_t mb = (size_t)env * d.NM;
+      for (int f = 0; f < d.mb_count[env]; f++) {
+        if (d.mb_obj[mb + f] != (uint16_t)slot) continue;
+        PP a = aoe(d.mb_aoe[mb + f]);
+        for (int ai = 0; ai < d.A; ai++) {
+          uint32_t& w = d.mb_inside[(mb + f) * d.AW + (ai >> 5)];
+          if ((w >> (ai & 31)) & 1u) { w &= ~(1u << (ai & 31)); presence(a, d.ag_obj[ao(ai)], -1); }
+        }
+        d.mb_obj[mb + f] = 0xFFFF;
+      }
+    }
+    uint16_t rc = d.obj_rc[so(slot)];
+    cell(rc >> 8, rc & 0xFF) = 0;
+    d.obj_flags[so(slot)] |= 1;
+    for (int t = 0; t < 256 && d.NL > 0; t++) {  // TagIndex::unregister_object (core/tag_index.cpp:21-31)
+      if (!has_tag(slot, t)) continue;
+      int li = tag_list(t);
+      if (li < 0) continue;
+      uint16_t* it = tl_items(li);
+      int n = tl_count(li), k = 0;
+      for (int i = 0; i < n; i++) { uint16_t v = it[i]; if (v != (uint16_t)slot) it[k++] = v; }
+      tl_count(li) = (uint16_t)k;
+    }
+  }
+
   // ---- mutations (handler/mutations/*.hpp) ----
   template <int DEPTH>
   __device__ void mutate(PP m, MgxCtx& c) const {
@@ -603,6 +694,9 @@ struct MgxEnvT {  // per-lane view of one env
         int moved = transfer(s, t, a2, amount);
         int sa = agent_of(s);
         if (moved > 0 && sa >= 0) astat_add(sa, mgx_wk(d, MGX_S_RES_DEPOSITED_BASE) + a2, (float)moved);
+        if constexpr (X) {
+          if (m[MGX_MU_A4] && (d.obj_order[so(s)] & 0xF) == 0xF) remove_object(s);  // resource_mutation.hpp:88-97
+        }
         break;
       }
       case MGX_MOP_CLEAR_INVENTORY: {  // resource_mutation.hpp:111-128
@@ -696,6 +790,45 @@ struct MgxEnvT {  // per-lane view of one env
         break;
       }
       case MGX_MOP_RECOMPUTE_QUERY: recompute_query<DEPTH>(a0, c); break;
+      case MGX_MOP_PUSH_OBJECT: {  // push_object_mutation.hpp:33-67
+        if (c.actor < 0 || c.target < 0) { c.mutation_failed = true; break; }
+        uint16_t arc = d.obj_rc[so(c.actor)], trc = d.obj_rc[so(c.target)];
+        int dr = min(max((int)(trc >> 8) - (int)(arc >> 8), -1), 1), dc = min(max((int)(trc & 0xFF) - (int)(arc & 0xFF), -1), 1);
+        int nr = (trc >> 8) + dr, nc = (trc & 0xFF) + dc;
+        if (nr < 0 || nc < 0 || nr >= d.H || nc >= d.W || cell(nr, nc) != 0 || !move_object(c.target, nr, nc)) c.mutation_failed = true;
+        break;
+      }
+      case MGX_MOP_SPAWN_OBJECT: {  // spawn_object_mutation.cpp:10-64
+        if (cell(c.target_r, c.target_c) != 0) { c.mutation_failed = true; break; }
+        int o = spawn_object(a0, c.target_r, c.target_c);
+        if (o < 0) { c.mutation_failed = true; break; }
+        c.target = o;
+        break;
+      }
+      case MGX_MOP_RAYCAST_SPAWN: {  // raycast_spawn_mutation.cpp:15-92
+        if (c.target < 0) { c.mutation_failed = true; break; }
+        uint16_t orc = d.obj_rc[so(c.target)];
+        MgxCtx tc = c;
+        tc.actor = c.target;
+        int range = (int)eval_value<TOPQ>(a3, c.target, tc, 0);
+        if (range <= 0) break;
+        PP dirs = P + d.sec[MGX_SEC_WORDLIST] + a1;
+        const int blocker_pc = m[MGX_MU_A4];
+        for (int k = 0; k < a2; k++)
+          for (int dist = 1; dist <= range; dist++) {
+            int r = (orc >> 8) + dirs[k * 2] * dist, cc = (orc & 0xFF) + dirs[k * 2 + 1] * dist;
+            if (r < 0 || cc < 0 || r >= d.H || cc >= d.W) break;
+            int ex = (int)cell(r, cc) - 1;
+            if (ex >= 0) {
+              bool blocker = false;
+              if (blocker_pc != MGX_PC_FAIL) { MgxCtx b = c; b.target = ex; blocker = check_filters<TOPQ>(blocker_pc, b, 0); }
+              if (blocker) break;
+              continue;
+            }
+            spawn_object(a0, r, cc);
+          }
+        break;
+      }
       case MGX_MOP_QUERY_INVENTORY: {  // query_inventory_mutation.hpp:26-52
         int n = eval_query<TOPQ>(a0, c, 0);
         const uint16_t* res = qbuf(QB_BASE);
@@ -862,7 +995,7 @@ struct MgxEnvT {  // per-lane view of one env
     for (int i = 0; i < a[MGX_AO_PRES_COUNT]; i++, pr += MGX_PR_WORDS) inv_update<1>(target, pr[MGX_PR_RESOURCE], pr[MGX_PR_DELTA] * mult);
   }
   __device__ void apply_fixed(int ai) const {  // :278-362
-    const int nf = d.fx_count[env];
+    const int nf = d.NF ? d.fx_count[env] : 0;
     if (nf == 0) return;
     const int tgt = d.ag_obj[ao(ai)];
     const uint16_t rc = d.obj_rc[so(tgt)];
@@ -872,12 +1005,14 @@ struct MgxEnvT {  // per-lane view of one env
     xl.def_delta[14 * xl.stride + xl.lane] = 0;  // count
     // exits first.  The reference walks an unordered_set<AOESource*> here (address order); registration order is used.
     for (int f = 0; f < nf; f++) {
+      if (d.fx_obj[fb + f] == 0xFFFF) continue;
       uint32_t& w = d.fx_inside[(fb + f) * d.AW + (ai >> 5)];
       if (!((w >> (ai & 31)) & 1u)) continue;
       PP a = aoe(d.fx_aoe[fb + f]);
       if (!fixed_covers(a, d.fx_rc[fb + f], r, c)) { w &= ~(1u << (ai & 31)); presence(a, tgt, -1); }
     }
     for (int f = 0; f < nf; f++) {
+      if (d.fx_obj[fb + f] == 0xFFFF) continue;
       PP a = aoe(d.fx_aoe[fb + f]);
       if (!fixed_covers(a, d.fx_rc[fb + f], r, c)) continue;
       if (a[MGX_AO_MUT_COUNT] == 0 && a[MGX_AO_PRES_COUNT] == 0) continue;
@@ -904,9 +1039,10 @@ struct MgxEnvT {  // per-lane view of one env
     }
   }
   __device__ void apply_mobile() const {  // :364-415
-    const int nm = d.mb_count[env];
+    const int nm = d.NM ? d.mb_count[env] : 0;
     const size_t mb = (size_t)env * d.NM;
     for (int m = 0; m < nm; m++) {
+      if (d.mb_obj[mb + m] == 0xFFFF) continue;
       PP a = aoe(d.mb_aoe[mb + m]);
       const int src = d.mb_obj[mb + m];
       const long long range = a[MGX_AO_RADIUS];
@@ -1180,6 +1316,11 @@ __device__ __forceinline__ void mgx_world_body(const MgxDev& d, PP P, uint8_t* o
         if (d.NT > 0) e.apply_territory(i);
       }
     if (d.NM > 0) e.apply_mobile();  // :1038
+    if (d.def_aoe) {                 // AOETracker::flush_deferred :1042
+      int n = d.def_count[env];
+      for (int k = 0; k < n; k++) e.register_aoes(d.def_aoe[(size_t)env * d.S + k]);
+      d.def_count[env] = 0;
+    }
     if (d.game_on_tick >= 0) {       // :1050-1052
       MgxCtx c = mgx_ctx(MGX_SLOT_NONE, MGX_SLOT_NONE);
       e.template apply_handler<3>(d.game_on_tick, c);

@@ -280,6 +280,24 @@ class QueryInventoryMutation:
 
 
 @dataclass
+class PushObject:
+    pass
+
+
+@dataclass
+class SpawnObject:
+    object_type: str    # map cell name of the class to create at ctx.target_location
+
+
+@dataclass
+class RaycastSpawn:
+    object_type: str
+    directions: list = field(default_factory=list)    # [(dr, dc)]
+    max_range: object = 2
+    blocker: list = field(default_factory=list)
+
+
+@dataclass
 class Relocate:
     pass
 

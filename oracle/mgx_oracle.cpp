@@ -100,6 +100,7 @@ struct Obj {
   uint8_t order[MGX_MAX_RESOURCES];  // inventory iteration order (front = begin())
   int norder = 0;
   uint32_t tags[MGX_TAG_WORDS] = {0};  // GridObject::tag_bits (core/grid_object.hpp:117)
+  bool no_inv_obs = false;             // spawned objects are created without an ObservationEncoder
 };
 
 struct Agent {
@@ -152,6 +153,7 @@ struct Engine {
   std::vector<TerrSrc> terr;         // TerritoryTracker sources in registration order
   std::vector<int> terr_prev;        // [A][num_territories] previous owner tag or -1
   size_t next_event = 0;
+  std::vector<int> deferred_aoe;     // AOETracker::_deferred_registrations (objects spawned this tick)
   std::vector<uint8_t> obs;
   std::vector<float> rewards, episode_rewards;
   std::vector<uint8_t> terminals, truncations, action_success;
@@ -527,6 +529,41 @@ struct Engine {
     return true;
   }
 
+  // ---- dynamic objects ----------------------------------------------------------------------------------------
+  int spawn_object(int cls_id, int r, int c) {  // create_object_from_config + Grid::add_object + TagIndex + deferred AoE
+    const int32_t* C = cls(cls_id);
+    if (C[MGX_C_KIND] == MGX_KIND_AGENT) { error |= 64; return -1; }  // spawning agents is not supported
+    Obj o;
+    o.cls = cls_id; o.r = r; o.c = c; o.vibe = C[MGX_C_INITIAL_VIBE];
+    o.no_inv_obs = true;
+    for (int w = 0; w < MGX_TAG_WORDS; w++) o.tags[w] = (uint32_t)C[MGX_C_TAGS + w];
+    int oi = (int)objs.size();
+    objs.push_back(o);
+    grid[r * W + c] = oi + 1;
+    const int32_t* ii = sec(MGX_SEC_INIT_INV) + C[MGX_C_INIT_INV_START] * MGX_II_WORDS;
+    for (int i = 0; i < C[MGX_C_INIT_INV_COUNT]; i++, ii += MGX_II_WORDS) inv_update(oi, ii[MGX_II_ITEM], ii[MGX_II_AMOUNT], true, true);
+    for (int t = 0; t < 256; t++) if (has_tag(oi, t)) tag_lists[t].push_back(oi);
+    if (C[MGX_C_AOE_COUNT] > 0) deferred_aoe.push_back(oi);
+    return oi;
+  }
+  void remove_object(int oi) {  // resource_mutation.hpp:88-97: aoe unregister, Grid::remove_from_grid, TagIndex unregister
+    if (is_agent(oi)) { error |= 64; return; }
+    for (auto& f : fixed)
+      if (f.alive && f.obj == oi) {
+        for (int ai = 0; ai < A; ai++) if (f.inside[ai]) { f.inside[ai] = 0; presence(f.aoe, agents[ai].obj, -1); }
+        f.alive = false;
+      }
+    for (auto& mo : mobile)
+      if (mo.alive && mo.obj == oi) {
+        for (int ai = 0; ai < A; ai++) if (mo.inside[ai]) { mo.inside[ai] = 0; presence(mo.aoe, agents[ai].obj, -1); }
+        mo.alive = false;
+      }
+    grid[objs[oi].r * W + objs[oi].c] = 0;
+    objs[oi].alive = false;
+    for (int t = 0; t < 256; t++)
+      if (has_tag(oi, t)) { auto& v = tag_lists[t]; v.erase(std::remove(v.begin(), v.end(), oi), v.end()); }
+  }
+
   // ---- mutations (cpp/include/mettagrid/handler/mutations/*.hpp) ----------------------------------------------
   void mutate(const int32_t* m, Ctx& c) {
     int a0 = m[MGX_MU_A0], a1 = m[MGX_MU_A1], a2 = m[MGX_MU_A2], a3 = m[MGX_MU_A3];
@@ -549,6 +586,7 @@ struct Engine {
         int amount = a3 < 0 ? (int)objs[s].inv[a2] : a3;
         int moved = transfer(s, d, a2, amount);
         if (moved > 0 && is_agent(s)) agents[objs[s].agent].stats.add(wk(MGX_S_RES_DEPOSITED_BASE) + a2, (float)moved);
+        if (m[MGX_MU_A4] && objs[s].norder == 0) remove_object(s);  // resource_mutation.hpp:88-97
         break;
       }
       case MGX_MOP_CLEAR_INVENTORY: {  // resource_mutation.hpp:111-128
@@ -624,6 +662,43 @@ struct Engine {
           for (int o : res)
             for (int i = 0; i < a2; i++) inv_update(o, dl[i * 2], dl[i * 2 + 1]);
         }
+        break;
+      }
+      case MGX_MOP_PUSH_OBJECT: {  // push_object_mutation.hpp:33-67
+        if (c.actor < 0 || c.target < 0) { c.mutation_failed = true; break; }
+        int dr = std::clamp(objs[c.target].r - objs[c.actor].r, -1, 1), dc = std::clamp(objs[c.target].c - objs[c.actor].c, -1, 1);
+        int nr = objs[c.target].r + dr, nc = objs[c.target].c + dc;
+        if (nr < 0 || nc < 0 || nr >= H || nc >= W || grid[nr * W + nc] != 0) { c.mutation_failed = true; break; }
+        int orr = objs[c.target].r, occ = objs[c.target].c;
+        if (!move_object(c.target, nr, nc)) { c.mutation_failed = true; break; }
+        territory_moved(c.target, orr, occ);
+        break;
+      }
+      case MGX_MOP_SPAWN_OBJECT: {  // spawn_object_mutation.cpp:10-64
+        if (grid[c.target_r * W + c.target_c] != 0) { c.mutation_failed = true; break; }
+        c.target = spawn_object(a0, c.target_r, c.target_c);
+        break;
+      }
+      case MGX_MOP_RAYCAST_SPAWN: {  // raycast_spawn_mutation.cpp:15-92
+        if (c.target < 0) { c.mutation_failed = true; break; }
+        int orr = objs[c.target].r, occ = objs[c.target].c;
+        Ctx tc = c; tc.actor = c.target;
+        int range = (int)eval_value(a3, c.target, tc);
+        if (range <= 0) break;
+        const int32_t* dirs = sec(MGX_SEC_WORDLIST) + a1;
+        for (int k = 0; k < a2; k++)
+          for (int dist = 1; dist <= range; dist++) {
+            int r = orr + dirs[k * 2] * dist, cc = occ + dirs[k * 2 + 1] * dist;
+            if (r < 0 || cc < 0 || r >= H || cc >= W) break;
+            int ex = grid[r * W + cc] - 1;
+            if (ex >= 0) {
+              bool blocker = false;
+              if (m[MGX_MU_A4] != MGX_PC_FAIL) { Ctx b = c; b.target = ex; blocker = check_filters(m[MGX_MU_A4], b); }
+              if (blocker) break;
+              continue;
+            }
+            spawn_object(a0, r, cc);
+          }
         break;
       }
       case MGX_MOP_RELOCATE:
@@ -919,7 +994,7 @@ struct Engine {
     for (int t = 0; t < 256; t++)
       if (o.tags[t >> 5] & (1u << (t & 31))) out[n++] = {(uint8_t)feat(MGX_F_TAG), (uint8_t)t};
     if (o.vibe != 0) out[n++] = {(uint8_t)feat(MGX_F_VIBE), (uint8_t)o.vibe};
-    for (int k = 0; k < o.norder; k++) {  // systems/observation_encoder.hpp:198-225, encoding_utils.hpp:39-62
+    for (int k = 0; k < (o.no_inv_obs ? 0 : o.norder); k++) {  // observation_encoder.hpp:198-225; grid_object.cpp:194 (obs_encoder null for spawned objects)
       int item = o.order[k];
       const int32_t* F = sec(MGX_SEC_INV_FEATURES) + item * MGX_IF_WORDS;
       uint32_t rem = o.inv[item];
@@ -1126,6 +1201,8 @@ struct Engine {
       apply_territory(ai);
     }
     apply_mobile();  // :1038
+    for (int oi : deferred_aoe) register_aoes(oi);  // AOETracker::flush_deferred :1042
+    deferred_aoe.clear();
     if (P[MGX_H_GAME_ON_TICK] >= 0) { Ctx c; apply_handler(P[MGX_H_GAME_ON_TICK], c); }  // :1050-1052
     for (auto& ag : agents) track_coverage(ag);
     compute_observations(executed);

@@ -241,6 +241,20 @@ class _Lower:
             c.transfer_stat_names = [(self.res[r], n) for r, n in mu.transfer_stat_names.items()]
             c.set_query(self.query(mu.query))
             hc.add_query_inventory_mutation(c)
+        elif isinstance(mu, S.PushObject):
+            hc.add_push_object_mutation(m.PushObjectMutationConfig())
+        elif isinstance(mu, S.SpawnObject):
+            c = m.SpawnObjectMutationConfig()
+            c.object_type = mu.object_type
+            hc.add_spawn_object_mutation(c)
+        elif isinstance(mu, S.RaycastSpawn):
+            c = m.RaycastSpawnMutationConfig()
+            c.object_type = mu.object_type
+            c.directions = [tuple(d) for d in mu.directions]
+            c.max_range = self.value(mu.max_range)
+            for f in mu.blocker:
+                self.add_filter(c, f, "blocker_")
+            hc.add_raycast_spawn_mutation(c)
         elif isinstance(mu, S.Relocate):
             hc.add_relocate_mutation(m.RelocateMutationConfig())
         elif isinstance(mu, S.Swap):

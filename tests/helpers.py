@@ -224,3 +224,51 @@ def rung4_map(seed: int) -> np.ndarray:
 
 SCENARIOS["rung4"] = (rung4_spec, rung4_map, 70, False)
 SCENARIOS["rung4_truncating"] = (lambda: rung4_spec(33), rung4_map, 36, True)
+
+
+def dynamic_spec() -> S.GameSpec:
+    """Objects created and removed at run time + move handlers with range: ranged beam (MaxDistance scan), push,
+    depletable extractors (remove_source_when_empty with a live AoE), event-driven smash-and-replace
+    (tests/test_spawn_in_event.py pattern), RaycastSpawn from a totem, spawned objects carrying AoEs and tags."""
+    A, T = S.ACTOR, S.TARGET
+    marker_aoe = S.AOESpec(radius=1, filters=[S.TagPrefixFilter(T, "type:agent")], mutations=[S.ResourceDelta(T, "hp", -1)])
+    well_aoe = S.AOESpec(radius=2, filters=[], mutations=[], presence_deltas={"mob": 2})
+    beam = S.Handler([S.VibeFilter(A, "a"), S.MaxDistanceFilter(T, 3), S.TagPrefixFilter(T, "type:agent")],
+                     [S.ResourceDelta(T, "mob", -1), S.ResourceDelta(A, "ore", -1)], "beam")
+    push = S.Handler([S.VibeFilter(A, "b"), S.TagPrefixFilter(T, "type:boulder")], [S.PushObject(), S.Relocate()], "push")
+    well_use = S.Handler([], [S.ResourceTransfer(T, A, "ore", 1, remove_source_when_empty=True)], "draw")
+    totem_use = S.Handler([S.ResourceFilter(A, "ore", 1)],
+                          [S.ResourceDelta(A, "ore", -1),
+                           S.RaycastSpawn("marker", [(-1, 0), (1, 0), (0, 1), (0, -1)], 2, [S.TagPrefixFilter(T, "type:wall")])], "totem")
+    events = {
+        "smash": S.EventSpec(S.TagQuery("type:crate", [S.ResourceFilter(T, "hp", 1)]), [3, 9, 20, 21], [],
+                             [S.ResourceDelta(T, "hp", -1), S.ResourceTransfer(T, A, "hp", 0, remove_source_when_empty=True),
+                              S.SpawnObject("marker")], max_targets=2),
+        "decay": S.EventSpec(S.TagQuery("spawned"), [15, 30], [], [S.AddTag(T, "old")]),
+    }
+    return S.GameSpec(
+        resource_names=["hp", "ore", "mob"],
+        agents=[S.AgentSpec(team_id=0, inventory=S.Inventory(initial={"hp": 30, "mob": 5, "ore": 2}, default_limit=50))
+                for _ in range(5)],
+        objects={
+            "wall": S.ObjectSpec("wall", kind="wall"),
+            "boulder": S.ObjectSpec("boulder"),
+            "crate": S.ObjectSpec("crate", inventory=S.Inventory(initial={"hp": 1}, limits=[S.Limit(["hp"], base=1, max=1)])),
+            "marker": S.ObjectSpec("marker", tags=["spawned"], vibe=1, aoes=[marker_aoe],
+                                   inventory=S.Inventory(initial={"ore": 4})),
+            "well": S.ObjectSpec("well", inventory=S.Inventory(initial={"ore": 3}), on_use=well_use, aoes=[well_aoe]),
+            "totem": S.ObjectSpec("totem", on_use=totem_use),
+        },
+        tags=["spawned", "old"],
+        vibe_names=["default", "a", "b"], change_vibe_enabled=True,
+        move_directions=["north", "south", "west", "east"],
+        move_handlers=[beam, push],
+        obs=S.ObsSpec(width=7, height=7, num_tokens=120, last_action_move=True),
+        events=events, max_steps=0)
+
+
+def dynamic_map(seed: int) -> np.ndarray:
+    return random_map(12, 12, {"wall": 6, "boulder": 6, "crate": 5, "well": 4, "totem": 3}, 5, seed)
+
+
+SCENARIOS["dynamic"] = (dynamic_spec, dynamic_map, 60, False)
