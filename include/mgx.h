@@ -61,6 +61,15 @@ int mgx_sync(mgx_engine* e);
 /* The engine's hipStream_t (as void*) so callers can order their own work / record events on it. */
 void* mgx_stream(mgx_engine* e);
 
+/* Episode restart for a subset of envs, on the device.  The reference restarts an episode by
+ * constructing a new MettaGrid (MettaGridPufferEnv._new_sim, python/src/mettagrid/envs/mettagrid_puffer_env.py:225-228,
+ * 299-302); here the selected envs are rebuilt in place by the same construction kernel mgx_create uses, their rows of
+ * the bound buffers are cleared and receive the initial observations (_init_buffers, mettagrid_c.cpp:294-319).
+ * env_mask:   u8 [E] host memory, non-zero = restart this env.
+ * class_maps: uint16 [E][H][W] host memory or NULL (= reuse each env's current map); only masked envs are read.
+ * seeds:      uint32 [E] host memory or NULL (= reuse each env's current seed); only masked envs are read. */
+int mgx_reset_envs(mgx_engine* e, const uint8_t* env_mask, const uint16_t* class_maps, const uint32_t* seeds);
+
 /* Pointers to the currently bound buffers (observations(), rewards(), ... accessors, mettagrid_py.cpp:291-299);
  * device or host according to mem_kind. */
 int mgx_get_buffers(mgx_engine* e, uint8_t** observations, uint8_t** terminals, uint8_t** truncations,

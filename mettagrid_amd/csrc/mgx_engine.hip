@@ -45,10 +45,21 @@ struct mgx_engine {
   size_t lds_world = 0, lds_obs = 0;
   int pool_tokens = 0;
   bool prog_in_lds = false;
+  uint16_t* dmaps = nullptr;
+  uint32_t* dseeds = nullptr;
+  uint8_t* dmask = nullptr;
+  struct Row { void* base; size_t row_bytes; int fill; };
+  std::vector<Row> rows_state;  // per-env state arrays (env-major) that an episode restart clears
   bool profiling = false;
   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
   float last_ms[2] = {0.f, 0.f};
 
+  template <class T>
+  int alloc_env(T** p, size_t per_env, int fill = 0) {  // env-major array: remembered for episode restarts
+    int rc = alloc(p, per_env * (size_t)d.E, fill);
+    if (rc == MGX_OK && per_env) rows_state.push_back({(void*)*p, per_env * sizeof(T), fill});
+    return rc;
+  }
   template <class T>
   int alloc(T** p, size_t count, int fill = 0) {
     void* q = nullptr;
@@ -65,14 +76,14 @@ struct mgx_engine {
   }
 };
 
-static int launch_obs(mgx_engine* e, bool with_rewards) {
+static int launch_obs(mgx_engine* e, bool with_rewards, const uint8_t* mask = nullptr) {
   dim3 grid(e->d.E), block(MGX_OBS_THREADS);
   if (e->d.X) {
-    if (with_rewards) hipLaunchKernelGGL((mgx_obs_kernel<true, true>), grid, block, e->lds_obs, e->stream, e->d, e->pool_tokens);
-    else hipLaunchKernelGGL((mgx_obs_kernel<false, true>), grid, block, e->lds_obs, e->stream, e->d, e->pool_tokens);
+    if (with_rewards) hipLaunchKernelGGL((mgx_obs_kernel<true, true>), grid, block, e->lds_obs, e->stream, e->d, e->pool_tokens, mask);
+    else hipLaunchKernelGGL((mgx_obs_kernel<false, true>), grid, block, e->lds_obs, e->stream, e->d, e->pool_tokens, mask);
   } else {
-    if (with_rewards) hipLaunchKernelGGL((mgx_obs_kernel<true, false>), grid, block, e->lds_obs, e->stream, e->d, e->pool_tokens);
-    else hipLaunchKernelGGL((mgx_obs_kernel<false, false>), grid, block, e->lds_obs, e->stream, e->d, e->pool_tokens);
+    if (with_rewards) hipLaunchKernelGGL((mgx_obs_kernel<true, false>), grid, block, e->lds_obs, e->stream, e->d, e->pool_tokens, mask);
+    else hipLaunchKernelGGL((mgx_obs_kernel<false, false>), grid, block, e->lds_obs, e->stream, e->d, e->pool_tokens, mask);
   }
   HIP_TRY(hipGetLastError());
   return MGX_OK;
@@ -196,34 +207,34 @@ int mgx_create(const int32_t* program, size_t program_words, const uint16_t* cla
   uint32_t* dseeds = nullptr;
 #define A_(call) if (rc == MGX_OK) rc = (call)
   A_(e->alloc(&dprog, program_words));
-  A_(e->alloc(&d.grid, E * HW));
-  A_(e->alloc(&d.obj_cls, E * S, 0xFF));
-  A_(e->alloc(&d.obj_rc, E * S));
-  A_(e->alloc(&d.obj_vibe, E * S));
-  A_(e->alloc(&d.obj_agent, E * S, 0xFF));
-  A_(e->alloc(&d.obj_visited, E * S));
-  A_(e->alloc(&d.obj_inv, E * S * d.R));
-  A_(e->alloc(&d.obj_order, E * S, 0xFF));
-  A_(e->alloc(&d.num_objs, E));
-  A_(e->alloc(&d.ag_obj, rows));
-  A_(e->alloc(&d.ag_prev, rows));
-  A_(e->alloc(&d.ag_spawn, rows));
-  A_(e->alloc(&d.ag_stepprev, rows));
-  A_(e->alloc(&d.ag_covrc, rows, 0xFF));
-  A_(e->alloc(&d.ag_swm, rows));
-  A_(e->alloc(&d.ag_maxdist, rows));
-  A_(e->alloc(&d.ag_unique, rows));
-  A_(e->alloc(&d.ag_seen, rows * d.SEENW));
-  A_(e->alloc(&d.ag_rprev, rows * d.NRW));
-  A_(e->alloc(&d.ag_stats, rows * d.NS));
-  A_(e->alloc(&d.ag_touched, rows * d.NSW));
-  A_(e->alloc(&d.game_stats, E * d.NG));
-  A_(e->alloc(&d.game_touched, E * d.NGW));
+  A_(e->alloc_env(&d.grid, HW));
+  A_(e->alloc_env(&d.obj_cls, S, 0xFF));
+  A_(e->alloc_env(&d.obj_rc, S));
+  A_(e->alloc_env(&d.obj_vibe, S));
+  A_(e->alloc_env(&d.obj_agent, S, 0xFF));
+  A_(e->alloc_env(&d.obj_visited, S));
+  A_(e->alloc_env(&d.obj_inv, S * d.R));
+  A_(e->alloc_env(&d.obj_order, S, 0xFF));
+  A_(e->alloc_env(&d.num_objs, 1));
+  A_(e->alloc_env(&d.ag_obj, A));
+  A_(e->alloc_env(&d.ag_prev, A));
+  A_(e->alloc_env(&d.ag_spawn, A));
+  A_(e->alloc_env(&d.ag_stepprev, A));
+  A_(e->alloc_env(&d.ag_covrc, A, 0xFF));
+  A_(e->alloc_env(&d.ag_swm, A));
+  A_(e->alloc_env(&d.ag_maxdist, A));
+  A_(e->alloc_env(&d.ag_unique, A));
+  A_(e->alloc_env(&d.ag_seen, A * d.SEENW));
+  A_(e->alloc_env(&d.ag_rprev, A * d.NRW));
+  A_(e->alloc_env(&d.ag_stats, A * d.NS));
+  A_(e->alloc_env(&d.ag_touched, A * d.NSW));
+  A_(e->alloc_env(&d.game_stats, (size_t)d.NG));
+  A_(e->alloc_env(&d.game_touched, (size_t)d.NGW));
   A_(e->alloc(&d.step, E));
   A_(e->alloc(&d.err, E));
-  A_(e->alloc(&d.executed, rows));
-  A_(e->alloc(&d.success, rows));
-  A_(e->alloc(&d.episode_rewards, rows));
+  A_(e->alloc_env(&d.executed, A));
+  A_(e->alloc_env(&d.success, A));
+  A_(e->alloc_env(&d.episode_rewards, A));
   A_(e->alloc(&d.mt, 624 * E));
   A_(e->alloc(&d.mt_idx, E));
   A_(e->alloc(&e->own_obs, rows * d.T * 3, 0xFF));
@@ -233,23 +244,24 @@ int mgx_create(const int32_t* program, size_t program_words, const uint16_t* cla
   A_(e->alloc(&e->own_act, rows));
   A_(e->alloc(&e->own_vact, rows));
   if (d.X) {
-    if (P[MGX_H_DYNAMIC_TAGS]) A_(e->alloc(&d.obj_tags, E * S * MGX_TAG_WORDS));
-    if (d.NL) { A_(e->alloc(&d.tl_items, E * d.NL * S)); A_(e->alloc(&d.tl_count, E * d.NL)); }
-    if (d.NF) { A_(e->alloc(&d.fx_obj, E * d.NF)); A_(e->alloc(&d.fx_aoe, E * d.NF)); A_(e->alloc(&d.fx_rc, E * d.NF));
-                A_(e->alloc(&d.fx_inside, E * d.NF * d.AW)); A_(e->alloc(&d.fx_count, E)); }
-    if (d.NM) { A_(e->alloc(&d.mb_obj, E * d.NM)); A_(e->alloc(&d.mb_aoe, E * d.NM));
-                A_(e->alloc(&d.mb_inside, E * d.NM * d.AW)); A_(e->alloc(&d.mb_count, E)); }
-    if (d.NTS) { A_(e->alloc(&d.ts_obj, E * d.NTS)); A_(e->alloc(&d.ts_ctrl, E * d.NTS)); A_(e->alloc(&d.ts_rc, E * d.NTS));
-                 A_(e->alloc(&d.ts_count, E)); }
-    A_(e->alloc(&d.terr_prev, rows * std::max(1, d.NT)));
-    A_(e->alloc(&d.next_event, E));
-    A_(e->alloc(&d.obj_flags, E * S));
-    if (P[MGX_H_SPAWNS]) { A_(e->alloc(&d.def_aoe, E * S)); A_(e->alloc(&d.def_count, E)); }
+    if (P[MGX_H_DYNAMIC_TAGS]) A_(e->alloc_env(&d.obj_tags, S * MGX_TAG_WORDS));
+    if (d.NL) { A_(e->alloc_env(&d.tl_items, d.NL * S)); A_(e->alloc_env(&d.tl_count, (size_t)d.NL)); }
+    if (d.NF) { A_(e->alloc_env(&d.fx_obj, (size_t)d.NF)); A_(e->alloc_env(&d.fx_aoe, (size_t)d.NF)); A_(e->alloc_env(&d.fx_rc, (size_t)d.NF));
+                A_(e->alloc_env(&d.fx_inside, (size_t)d.NF * d.AW)); A_(e->alloc_env(&d.fx_count, 1)); }
+    if (d.NM) { A_(e->alloc_env(&d.mb_obj, (size_t)d.NM)); A_(e->alloc_env(&d.mb_aoe, (size_t)d.NM));
+                A_(e->alloc_env(&d.mb_inside, (size_t)d.NM * d.AW)); A_(e->alloc_env(&d.mb_count, 1)); }
+    if (d.NTS) { A_(e->alloc_env(&d.ts_obj, (size_t)d.NTS)); A_(e->alloc_env(&d.ts_ctrl, (size_t)d.NTS)); A_(e->alloc_env(&d.ts_rc, (size_t)d.NTS));
+                 A_(e->alloc_env(&d.ts_count, 1)); }
+    A_(e->alloc_env(&d.terr_prev, A * std::max(1, d.NT)));
+    A_(e->alloc_env(&d.next_event, 1));
+    A_(e->alloc_env(&d.obj_flags, S));
+    if (P[MGX_H_SPAWNS]) { A_(e->alloc_env(&d.def_aoe, S)); A_(e->alloc_env(&d.def_count, 1)); }
     A_(e->alloc(&d.qws, E * d.QB * S));
     A_(e->alloc(&d.qvis, E * (d.QD + 1) * d.SW));
   }
   A_(e->alloc(&dmaps, E * HW));
   A_(e->alloc(&dseeds, E));
+  A_(e->alloc(&e->dmask, E));
 #undef A_
   if (rc != MGX_OK) { mgx_destroy(e); return rc; }
   d.P = dprog;
@@ -314,7 +326,10 @@ int mgx_create(const int32_t* program, size_t program_words, const uint16_t* cla
   if (he == hipSuccess) he = hipMemcpyAsync(dmaps, class_maps, E * HW * 2, hipMemcpyHostToDevice, e->stream);
   if (he == hipSuccess) he = hipMemcpyAsync(dseeds, seeds, E * 4, hipMemcpyHostToDevice, e->stream);
   if (he != hipSuccess) { mgx_destroy(e); return fail(MGX_ERR_HIP, std::string("mgx_create upload: ") + hipGetErrorString(he)); }
-  hipLaunchKernelGGL(mgx_init_kernel, dim3((d.E + MGX_WAVE - 1) / MGX_WAVE), dim3(MGX_WAVE), 0, e->stream, e->d, dmaps, dseeds);
+  e->dmaps = dmaps;
+  e->dseeds = dseeds;
+  hipLaunchKernelGGL(mgx_init_kernel, dim3((d.E + MGX_WAVE - 1) / MGX_WAVE), dim3(MGX_WAVE), 0, e->stream, e->d, dmaps, dseeds,
+                     (const uint8_t*)nullptr);
   he = hipGetLastError();
   if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
   if (he != hipSuccess) { mgx_destroy(e); return fail(MGX_ERR_HIP, std::string("mgx_init_kernel: ") + hipGetErrorString(he)); }
@@ -371,6 +386,49 @@ int mgx_set_buffers(mgx_engine* e, uint8_t* observations, uint8_t* terminals, ui
     return fail(MGX_ERR_BAD_ARG, "mgx_set_buffers: unknown mem_kind");
   }
   return init_buffers(e);
+}
+
+int mgx_reset_envs(mgx_engine* e, const uint8_t* env_mask, const uint16_t* class_maps, const uint32_t* seeds) {
+  if (!e || !env_mask) return fail(MGX_ERR_BAD_ARG, "mgx_reset_envs: null argument");
+  HIP_TRY(hipSetDevice(e->device));
+  const MgxDev& d = e->d;
+  const size_t E = d.E, HW = (size_t)d.H * d.W, A = d.A;
+  int first = -1, last = -1;
+  for (size_t i = 0; i < E; i++) if (env_mask[i]) { if (first < 0) first = (int)i; last = (int)i; }
+  if (first < 0) return MGX_OK;
+  HIP_TRY(hipMemcpyAsync(e->dmask, env_mask, E, hipMemcpyHostToDevice, e->stream));
+  for (int i = first; i <= last; i++) {
+    if (!env_mask[i]) continue;
+    if (class_maps) HIP_TRY(hipMemcpyAsync(e->dmaps + (size_t)i * HW, class_maps + (size_t)i * HW, HW * 2, hipMemcpyHostToDevice, e->stream));
+    if (seeds) HIP_TRY(hipMemcpyAsync(e->dseeds + i, seeds + i, 4, hipMemcpyHostToDevice, e->stream));
+  }
+  for (const auto& r : e->rows_state) {
+    int bx = (int)std::min<size_t>((r.row_bytes + 255) / 256, 64);
+    hipLaunchKernelGGL(mgx_fill_rows_kernel, dim3(bx, (unsigned)E), dim3(256), 0, e->stream, (uint8_t*)r.base, r.row_bytes, r.fill,
+                       (const uint8_t*)e->dmask, (int)E);
+  }
+  // caller-visible rows of the restarted envs: terminals / truncations / rewards cleared (_init_buffers)
+  hipLaunchKernelGGL(mgx_fill_rows_kernel, dim3(1, (unsigned)E), dim3(256), 0, e->stream, (uint8_t*)d.terminals, A, 0, (const uint8_t*)e->dmask, (int)E);
+  hipLaunchKernelGGL(mgx_fill_rows_kernel, dim3(1, (unsigned)E), dim3(256), 0, e->stream, (uint8_t*)d.truncations, A, 0, (const uint8_t*)e->dmask, (int)E);
+  hipLaunchKernelGGL(mgx_fill_rows_kernel, dim3(1, (unsigned)E), dim3(256), 0, e->stream, (uint8_t*)d.rewards, A * 4, 0, (const uint8_t*)e->dmask, (int)E);
+  HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(mgx_init_kernel, dim3((d.E + MGX_WAVE - 1) / MGX_WAVE), dim3(MGX_WAVE), 0, e->stream, e->d, e->dmaps, e->dseeds,
+                     (const uint8_t*)e->dmask);
+  HIP_TRY(hipGetLastError());
+  int rc = launch_obs(e, false, e->dmask);
+  if (rc) return rc;
+  if (e->mem_kind == MGX_MEM_HOST) {
+    for (int i = first; i <= last; i++) {
+      if (!env_mask[i]) continue;
+      size_t r0 = (size_t)i * A;
+      HIP_TRY(hipMemcpyAsync(e->h_obs + r0 * d.T * 3, d.obs + r0 * d.T * 3, A * d.T * 3, hipMemcpyDeviceToHost, e->stream));
+      HIP_TRY(hipMemcpyAsync(e->h_term + r0, d.terminals + r0, A, hipMemcpyDeviceToHost, e->stream));
+      HIP_TRY(hipMemcpyAsync(e->h_trunc + r0, d.truncations + r0, A, hipMemcpyDeviceToHost, e->stream));
+      HIP_TRY(hipMemcpyAsync(e->h_rew + r0, d.rewards + r0, A * 4, hipMemcpyDeviceToHost, e->stream));
+    }
+  }
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return MGX_OK;
 }
 
 int mgx_step(mgx_engine* e) {

@@ -131,9 +131,10 @@ __host__ __device__ inline MgxObsLds mgx_obs_lds_layout(int HW, int NOFF, int S,
 }
 
 template <bool WITH_REWARDS, bool X>
-__global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int pool_tokens) {
+__global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int pool_tokens, const uint8_t* env_mask) {
   extern __shared__ __align__(16) uint8_t smem[];
   const int env = blockIdx.x;
+  if (env_mask && !env_mask[env]) return;  // episode restart: only the restarted envs get initial observations
   const int tid = threadIdx.x, lane = tid & (MGX_WAVE - 1), wave = tid / MGX_WAVE;
   const int HW = d.H * d.W, A = d.A, S = d.S, T = d.T, NOFF = d.NOFF;
   const MgxObsLds L = mgx_obs_lds_layout(HW, NOFF, S, A, T, pool_tokens, X, d.n_obs_values);

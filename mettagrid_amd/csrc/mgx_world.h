@@ -1372,9 +1372,11 @@ __global__ void __launch_bounds__(MGX_WAVE) mgx_world_kernel(MgxDev d, int prog_
 
 // Construction: MettaGrid ctor + _init_grid (mettagrid_c.cpp:42-191, 200-269).  One lane per env scans the class
 // map in row-major order; object slot = reference object id - 1; agent index = order of appearance.
-__global__ void __launch_bounds__(MGX_WAVE) mgx_init_kernel(MgxDev d, const uint16_t* class_maps, const uint32_t* seeds) {
+__global__ void __launch_bounds__(MGX_WAVE) mgx_init_kernel(MgxDev d, const uint16_t* class_maps, const uint32_t* seeds,
+                                                            const uint8_t* env_mask) {
   const int env = blockIdx.x * MGX_WAVE + threadIdx.x;
   if (env >= d.E) return;
+  if (env_mask && !env_mask[env]) return;
   MgxEnvX e(d, d.P, env);
   const size_t E = (size_t)d.E;
   uint32_t x = seeds[env];  // std::mt19937(seed): bits/random.tcc seed()
@@ -1480,6 +1482,14 @@ __global__ void __launch_bounds__(MGX_WAVE) mgx_init_kernel(MgxDev d, const uint
       else if (rw[MGX_RW_TOUCH_SCOPE] == 1) e.gstat_touch(rw[MGX_RW_TOUCH_STAT]);
     }
   }
+}
+
+// Fills the rows of the masked envs of one state array (episode restart): row_bytes per env, byte value `fill`.
+__global__ void mgx_fill_rows_kernel(uint8_t* base, size_t row_bytes, int fill, const uint8_t* env_mask, int E) {
+  const int env = blockIdx.y;
+  if (env >= E || !env_mask[env]) return;
+  uint8_t* row = base + (size_t)env * row_bytes;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < row_bytes; i += (size_t)gridDim.x * blockDim.x) row[i] = (uint8_t)fill;
 }
 
 #endif  // MGX_WORLD_H_

@@ -53,6 +53,7 @@ def load_lib():
     L.mgx_destroy.restype = None
     L.mgx_set_buffers.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, i64, i32]
     L.mgx_step.argtypes = [vp]
+    L.mgx_reset_envs.argtypes = [vp, vp, vp, vp]
     L.mgx_sync.argtypes = [vp]
     L.mgx_stream.argtypes = [vp]
     L.mgx_stream.restype = vp
@@ -166,6 +167,23 @@ class BatchedMettaGrid:
 
     def sync(self) -> None:
         _check(self.L.mgx_sync(self.h))
+
+    def reset_envs(self, env_mask, class_maps=None, seeds=None) -> None:
+        """Restart the selected envs in place on the device (new episode): optional new maps / seeds for them.
+        Their buffer rows are cleared and receive the initial observations, exactly like a fresh reference
+        ``MettaGrid`` + ``set_buffers``."""
+        mask = np.ascontiguousarray(np.asarray(env_mask, dtype=np.uint8).reshape(self.E))
+        cm_ptr = sd_ptr = None
+        if class_maps is not None:
+            cm = np.ascontiguousarray(class_maps, dtype=np.uint16)
+            H, W = int(self.prog.words[K.H_HEIGHT]), int(self.prog.words[K.H_WIDTH])
+            if cm.shape != (self.E, H, W):
+                raise ValueError(f"class_maps must have shape {(self.E, H, W)} (only masked envs are read)")
+            cm_ptr = cm.ctypes.data
+        if seeds is not None:
+            sd = np.ascontiguousarray(np.broadcast_to(np.asarray(seeds, dtype=np.uint32), (self.E,)))
+            sd_ptr = sd.ctypes.data
+        _check(self.L.mgx_reset_envs(self.h, mask.ctypes.data, cm_ptr, sd_ptr))
 
     @property
     def stream(self) -> int:

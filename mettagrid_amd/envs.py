@@ -1,0 +1,188 @@
+"""Batched PufferEnv-shaped environment over the MI355X step engine.
+
+Mirrors the surface PufferLib drives on the reference's ``MettaGridPufferEnv``
+(/root/reference/python/src/mettagrid/envs/mettagrid_puffer_env.py): ``reset(seed) -> (obs, infos)``,
+``step(actions) -> (obs, rewards, terminals, truncations, infos)``, the same action encodings (1-D combined index or
+``[N, 2]`` primary/vibe columns, :305-394), the same dtypes (:59-63) and lazy auto-reset (an env whose agents are all
+terminal or all truncated is restarted at the START of the next ``step`` call, then stepped, :299-302) — for
+``num_agents = E * A`` agents at once, with every buffer resident in HBM.  pufferlib itself is not imported.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional
+
+import numpy as np
+
+from .compiler import Program
+from .engine import BatchedMettaGrid
+
+
+def split_action_names(action_names: list) -> tuple:
+    """PolicyEnvInterface._split_action_names (python/src/mettagrid/policy/policy_env_interface.py:110-119)."""
+    primary = [a for a in action_names if not a.startswith("change_vibe_")]
+    vibe = [a for a in action_names if a.startswith("change_vibe_")]
+    return primary, vibe
+
+
+def decode_actions(actions, num_primary: int, vibe_action_ids, xp=np):
+    """Action decoding rules of MettaGridPufferEnv.step (:305-381).  Returns (core_actions, vibe_actions or None).
+    ``xp`` is numpy or torch (the arrays stay on their device)."""
+    num_vibe = len(vibe_action_ids)
+    if num_primary <= 0:
+        raise ValueError("Environment must expose at least one non-vibe action")
+    a = actions
+    vibe = None
+    if a.ndim == 2:
+        if a.shape[1] == 1:
+            core = a[:, 0]
+        elif a.shape[1] == 2:
+            core = a[:, 0]
+            if num_vibe <= 0:
+                raise ValueError("Received 2D actions with vibe column, but environment has no configured vibe action space")
+            raw = a[:, 1].to(xp.int64) if xp is not np else a[:, 1].astype(np.int64)
+            if bool((raw < 0).any()):
+                raise ValueError(f"Vibe actions must be non-negative, got min={int(raw.min())}")
+            if bool((raw >= num_vibe).any()):
+                raise ValueError(f"Vibe action indices out of range [0,{num_vibe}), min={int(raw.min())} max={int(raw.max())}")
+            vibe = vibe_action_ids[raw]
+        else:
+            raise ValueError(f"Expected step actions shape [num_agents] or [num_agents,2], got {tuple(a.shape)}")
+    elif a.ndim == 1:
+        a64 = a.to(xp.int64) if xp is not np else a.astype(np.int64)
+        if bool((a64 < 0).any()):
+            raise ValueError(f"Actions must be non-negative, got min={int(a64.min())}")
+        core = a64
+        enc = a64 >= num_primary
+        if bool(enc.any()):
+            if num_vibe <= 0:
+                raise ValueError("Received encoded vibe actions, but environment has no configured vibe action space")
+            max_valid = num_primary + num_primary * num_vibe
+            if bool((a64 >= max_valid).any()):
+                raise ValueError(f"Action indices out of range [0, {max_valid}), min={int(a64.min())} max={int(a64.max())}")
+            off = a64 - num_primary
+            core = xp.where(enc, off // num_vibe, a64)
+            vibe = xp.where(enc, vibe_action_ids[(off % num_vibe) * enc], 0 * a64)
+    else:
+        raise ValueError(f"Expected step actions shape [num_agents] or [num_agents,2], got {tuple(a.shape)}")
+    c64 = core.to(xp.int64) if xp is not np else core.astype(np.int64)
+    if bool((c64 < 0).any()) or bool((c64 >= num_primary).any()):
+        raise ValueError(f"Core actions out of range [0,{num_primary}), min={int(c64.min())} max={int(c64.max())}")
+    return core, vibe
+
+
+class MettaGridBatchedEnv:
+    """E envs x A agents behind the PufferEnv call pattern.
+
+    ``map_fn(env_index, episode_index) -> uint16 class map [H, W]`` supplies the map of every new episode (maps are
+    built on the host once per episode, as in the reference: simulator.py:83); ``seed_fn`` likewise for engine seeds
+    (default: the seed given to ``reset`` plus the env index, constant across auto-resets like the reference's
+    ``_current_seed``).
+    """
+
+    def __init__(self, prog: Program, num_envs: int, map_fn: Callable[[int, int], np.ndarray],
+                 seed_fn: Optional[Callable[[int, int, int], int]] = None, device: int = 0, seed: int = 0,
+                 buffers: str = "device") -> None:
+        self.prog = prog
+        self.E = num_envs
+        self.map_fn = map_fn
+        self.seed_fn = seed_fn or (lambda base, env, episode: (base + env) & 0xFFFFFFFF)
+        self._seed = seed
+        self._device = device
+        self._kind = buffers
+        self.action_names, self.vibe_action_names = split_action_names(prog.action_names)
+        self.num_agents = num_envs * prog.num_agents
+        self.episode = np.zeros(num_envs, np.int64)
+        self._eng: Optional[BatchedMettaGrid] = None
+        self._vibe_ids = None
+
+    # spaces (shapes only; gymnasium is not a dependency)
+    @property
+    def single_observation_shape(self):
+        return (self.prog.num_tokens, 3)
+
+    @property
+    def single_action_n(self) -> int:
+        return len(self.action_names)
+
+    @property
+    def transport_action_n(self) -> int:
+        n, v = len(self.action_names), len(self.vibe_action_names)
+        return n * (v + 1) if v else n
+
+    def _maps(self, envs) -> np.ndarray:
+        H = int(self.prog.words[3]), int(self.prog.words[4])
+        out = np.zeros((self.E,) + H, np.uint16)
+        for e in envs:
+            out[e] = self.map_fn(int(e), int(self.episode[e]))
+        return out
+
+    def _seeds(self) -> np.ndarray:
+        return np.array([self.seed_fn(self._seed, e, int(self.episode[e])) for e in range(self.E)], dtype=np.uint32)
+
+    def reset(self, seed: Optional[int] = None):
+        if seed is not None:
+            self._seed = seed
+        if self._eng is not None:
+            self._eng.close()
+        self.episode[:] = 0
+        self._eng = BatchedMettaGrid(self.prog, self._maps(range(self.E)), self._seeds(), device=self._device,
+                                     buffers=self._kind)
+        ids = [self.prog.action_names.index(n) for n in self.vibe_action_names]
+        if self._kind == "device":
+            import torch
+            self._vibe_ids = torch.tensor(ids, dtype=torch.int64, device=self._eng.obs.device)
+        else:
+            self._vibe_ids = np.asarray(ids, dtype=np.int64)
+        return self._eng.obs, {}
+
+    @property
+    def engine(self) -> BatchedMettaGrid:
+        if self._eng is None:
+            raise RuntimeError("Simulation is closed")
+        return self._eng
+
+    def _done_envs(self) -> np.ndarray:
+        eng = self.engine
+        A = self.prog.num_agents
+        if self._kind == "device":
+            eng.sync()
+            term = eng.terminals.view(self.E, A).all(dim=1) | eng.truncations.view(self.E, A).all(dim=1)
+            return term.cpu().numpy()
+        return eng.terminals.reshape(self.E, A).all(1) | eng.truncations.reshape(self.E, A).all(1)
+
+    def step(self, actions):
+        eng = self.engine
+        done = self._done_envs()
+        if done.any():  # lazy auto-reset at the start of the next step (mettagrid_puffer_env.py:299-302)
+            idx = np.nonzero(done)[0]
+            self.episode[idx] += 1
+            eng.reset_envs(done, self._maps(idx), self._seeds())
+        if self._kind == "device":
+            import torch
+            a = actions if isinstance(actions, torch.Tensor) else torch.as_tensor(np.asarray(actions), device=eng.obs.device)
+            core, vibe = decode_actions(a, len(self.action_names), self._vibe_ids, xp=torch)
+            if tuple(core.shape) != tuple(eng.actions.shape):
+                raise ValueError(f"Expected {tuple(eng.actions.shape)} core actions, got {tuple(core.shape)}")
+            eng.actions.copy_(core.to(torch.int32))
+            if vibe is not None:
+                eng.vibe_actions.copy_(vibe.to(torch.int32))
+            else:
+                eng.vibe_actions.zero_()
+            torch.cuda.synchronize(eng.obs.device)
+        else:
+            a = np.asarray(actions)
+            core, vibe = decode_actions(a, len(self.action_names), self._vibe_ids, xp=np)
+            if core.shape != eng.actions.shape:
+                raise ValueError(f"Expected {eng.actions.shape} core actions, got {core.shape}")
+            np.copyto(eng.actions, core.astype(np.int32))
+            if vibe is not None:
+                np.copyto(eng.vibe_actions, vibe.astype(np.int32))
+            else:
+                eng.vibe_actions.fill(0)
+        eng.step()
+        return eng.obs, eng.rewards, eng.terminals, eng.truncations, {}
+
+    def close(self) -> None:
+        if self._eng is not None:
+            self._eng.close()
+            self._eng = None

@@ -1,0 +1,82 @@
+"""GPU: on-device episode restart and the batched PufferEnv surface."""
+import numpy as np
+import pytest
+
+import helpers as hp
+import oracle_py as op
+from mettagrid_amd import presets
+from mettagrid_amd.compiler import compile_spec
+from mettagrid_amd.engine import BatchedMettaGrid
+from mettagrid_amd.envs import MettaGridBatchedEnv
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", ["rung3", "rung4", "dynamic"])
+def test_reset_envs_equals_fresh_construction(name):
+    spec_f, map_f, steps, _ = hp.SCENARIOS[name]
+    spec = spec_f()
+    E, A = 4, None
+    maps = [map_f(s) for s in range(E)]
+    prog = compile_spec(spec, *maps[0].shape)
+    A = prog.num_agents
+    cms = np.stack([prog.class_map(m) for m in maps])
+    eng = BatchedMettaGrid(prog, cms, np.arange(E, dtype=np.uint32), buffers="host")
+    n = len(prog.action_names)
+    rng = np.random.RandomState(3)
+    for _ in range(20):
+        eng.actions[:] = rng.randint(0, n, E * A)
+        eng.vibe_actions[:] = rng.randint(0, n, E * A)
+        eng.step()
+    # restart envs 1 and 3 with new maps / seeds; 0 and 2 keep running
+    new_maps = cms.copy()
+    new_maps[1] = prog.class_map(map_f(11))
+    new_maps[3] = prog.class_map(map_f(13))
+    seeds = np.array([0, 77, 0, 99], np.uint32)
+    keep = {i: op.OracleSim(prog, cms[i], i) for i in (0, 2)}
+    acts_hist = None
+    eng.reset_envs([0, 1, 0, 1], new_maps, seeds)
+    fresh = {1: op.OracleSim(prog, new_maps[1], 77), 3: op.OracleSim(prog, new_maps[3], 99)}
+    for i, o in fresh.items():  # a restarted env == a fresh reference env after its (single) set_buffers
+        hp.compare_snapshots(o.snapshot(), {k: v[i * A:(i + 1) * A] for k, v in eng.snapshot().items()}, f"{name} env {i} after reset")
+    for t in range(15):
+        a = rng.randint(0, n, E * A).astype(np.int32)
+        v = rng.randint(0, n, E * A).astype(np.int32)
+        eng.actions[:] = a
+        eng.vibe_actions[:] = v
+        eng.step()
+        snap = eng.snapshot()
+        for i, o in fresh.items():
+            o.step(a[i * A:(i + 1) * A], v[i * A:(i + 1) * A])
+            hp.compare_snapshots(o.snapshot(), {k: x[i * A:(i + 1) * A] for k, x in snap.items()}, f"{name} env {i} step {t}")
+    assert eng.poll_errors()[0] == 0
+    assert eng.current_steps().tolist() == [35, 15, 35, 15]
+    del keep, acts_hist
+
+
+def test_batched_env_surface_and_auto_reset():
+    spec = presets.rung2_spec()
+    spec.max_steps = 5
+    spec.episode_truncates = True
+    prog = compile_spec(spec, 32, 32)
+    E, A = 3, prog.num_agents
+    env = MettaGridBatchedEnv(prog, E, map_fn=lambda e, ep: prog.class_map(presets.rung2_map(100 * ep + e)), seed=7, buffers="host")
+    obs, infos = env.reset()
+    assert obs.shape == (E * A, 200, 3) and obs.dtype == np.uint8 and infos == {}
+    assert env.single_action_n == 5 and env.transport_action_n == 5 * 5 and env.num_agents == E * A
+    move_n = env.action_names.index("move_north")
+    for t in range(5):
+        obs, rew, term, trunc, _ = env.step(np.full(E * A, move_n, np.int32))
+        assert rew.dtype == np.float32 and term.dtype == np.bool_ and trunc.dtype == np.bool_
+    assert trunc.all() and not term.any() and env.engine.current_steps().tolist() == [5, 5, 5]
+    first_obs = obs.copy()
+    # next step: lazy auto-reset (new maps: episode index 1), then the step itself
+    combined = np.full(E * A, 5 + 0 * 4 + 2, np.int64)  # primary 0 (noop) + vibe index 2
+    obs, rew, term, trunc, _ = env.step(combined)
+    assert not trunc.any() and env.engine.current_steps().tolist() == [1, 1, 1] and env.episode.tolist() == [1, 1, 1]
+    assert not np.array_equal(first_obs, obs)
+    vibe_feature = prog.feature_ids["vibe"]
+    assert ((obs[:, :, 1] == vibe_feature) & (obs[:, :, 2] == 2)).any()   # the vibe change of the combined action landed
+    with pytest.raises(ValueError, match="out of range"):
+        env.step(np.full(E * A, 999, np.int64))
+    env.close()
