@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -12,6 +13,11 @@
 #include "mgx_device.h"
 #include "mgx_obs.h"
 #include "mgx_world.h"
+
+template <bool PROG_LDS>
+__global__ void __launch_bounds__(MGX_WORLD_MAX_THREADS) mgx_world_kernel_ext(MgxDev d, int prog_words, int lpw) {
+  mgx_world_entry<PROG_LDS, true>(d, prog_words, lpw);
+}
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string& msg) {
@@ -45,6 +51,8 @@ struct mgx_engine {
   size_t lds_world = 0, lds_obs = 0;
   int pool_tokens = 0;
   bool prog_in_lds = false;
+  int world_lpw = MGX_WAVE;  // envs per wavefront of the world kernel (64, 32, 16 or 8)
+  int world_wpe = 0;         // 4: the 128-VGPR build of the non-extended world kernel
   uint16_t* dmaps = nullptr;
   uint32_t* dseeds = nullptr;
   uint8_t* dmask = nullptr;
@@ -143,6 +151,7 @@ int mgx_create(const int32_t* program, size_t program_words, const uint16_t* cla
   d.base = P[MGX_H_TOKEN_BASE];
   d.max_steps = P[MGX_H_MAX_STEPS]; d.truncates = P[MGX_H_EPISODE_TRUNCATES]; d.max_priority = P[MGX_H_MAX_PRIORITY];
   d.nact = P[MGX_H_NUM_ACTIONS]; d.flags = P[MGX_H_GLOBAL_FLAGS]; d.hp_res = P[MGX_H_HP_RESOURCE];
+  if (d.nact > 32000) { mgx_destroy(e); return fail(MGX_ERR_PROGRAM, "mgx_create: more than 32000 actions"); }
   d.n_obs_values = P[MGX_H_NUM_OBS_VALUES]; d.n_move_handlers = P[MGX_H_NUM_MOVE_HANDLERS];
   for (int i = 0; i < 14; i++) d.feat[i] = P[MGX_H_FEAT_BASE + i];
   d.feat[14] = P[MGX_H_OBS_HEIGHT] >> 1;
@@ -269,8 +278,16 @@ int mgx_create(const int32_t* program, size_t program_words, const uint16_t* cla
   d.actions = e->own_act; d.vibe_actions = e->own_vact;
 
   e->lds_world = (size_t)mgx_world_lds_fixed(d.A, d.X != 0);
-  e->prog_in_lds = program_words * 4 + e->lds_world <= 36 * 1024;  // 4 workgroups per CU keep their copy resident
+  e->prog_in_lds = program_words * 4 + e->lds_world <= 39 * 1024;  // 4 workgroups per CU (160 KB LDS) keep their copy
   if (e->prog_in_lds) e->lds_world += program_words * 4;
+  if (const char* v = getenv("MGX_WORLD_LPW")) {  // tuning knobs (bench sweeps); defaults are the measured best
+    int l = atoi(v);
+    if (l == 8 || l == 16 || l == 32 || l == 64) e->world_lpw = l;
+  }
+  if (const char* v = getenv("MGX_WORLD_WPE")) e->world_wpe = atoi(v);
+  if (getenv("MGX_VERBOSE"))
+    fprintf(stderr, "[mgx] E=%d A=%d S=%d program=%zu B world: X=%d prog_in_lds=%d lds=%zu B lpw=%d\n", d.E, d.A, d.S,
+            program_words * 4, d.X, (int)e->prog_in_lds, e->lds_world, e->world_lpw);
   {  // LDS token pool: every object of an env caches its (feature, value) list once per step.  Upper bound per
      // object from the program: tags + vibe + R * digits + 2; capped so that several workgroups fit one CU.
     int digits = 1;
@@ -444,14 +461,13 @@ int mgx_step(mgx_engine* e) {
   HIP_TRY(hipMemsetAsync(d.success, 0, rows, e->stream));
   if (e->profiling) HIP_TRY(hipEventRecord(e->ev[0], e->stream));
   {
-    dim3 grid((d.E + MGX_WAVE - 1) / MGX_WAVE), block(MGX_WAVE);
-    int pw = (int)e->prog.size();
+    const int pw = (int)e->prog.size(), lpw = e->world_lpw;
     if (d.X) {
-      if (e->prog_in_lds) hipLaunchKernelGGL((mgx_world_kernel<true, true>), grid, block, e->lds_world, e->stream, e->d, pw);
-      else hipLaunchKernelGGL((mgx_world_kernel<false, true>), grid, block, e->lds_world, e->stream, e->d, pw);
+      dim3 grid((d.E + MGX_WAVE - 1) / MGX_WAVE), block(MGX_WAVE * (MGX_WAVE / lpw));
+      if (e->prog_in_lds) hipLaunchKernelGGL((mgx_world_kernel_ext<true>), grid, block, e->lds_world, e->stream, e->d, pw, lpw);
+      else hipLaunchKernelGGL((mgx_world_kernel_ext<false>), grid, block, e->lds_world, e->stream, e->d, pw, lpw);
     } else {
-      if (e->prog_in_lds) hipLaunchKernelGGL((mgx_world_kernel<true, false>), grid, block, e->lds_world, e->stream, e->d, pw);
-      else hipLaunchKernelGGL((mgx_world_kernel<false, false>), grid, block, e->lds_world, e->stream, e->d, pw);
+      mgx_launch_world_fast(e->prog_in_lds, e->world_wpe, lpw, e->lds_world, e->stream, e->d, pw);
     }
   }
   HIP_TRY(hipGetLastError());
@@ -627,3 +643,11 @@ int32_t mgx_num_tokens(const mgx_engine* e) { return e ? e->d.T : 0; }
 int64_t mgx_state_bytes(const mgx_engine* e) { return e ? e->state_bytes : 0; }
 
 }  // extern "C"
+
+#ifdef MGX_WORLD_TIMING  // instrumented developer build only (scripts/world_timing.py); not part of the ABI
+extern "C" void mgx_debug_obs_cycles(unsigned long long* out, int reset) {
+  hipDeviceSynchronize();
+  hipMemcpyFromSymbol(out, HIP_SYMBOL(mgx_dbg_cycles), sizeof(unsigned long long) * 16);
+  if (reset) { unsigned long long z[16] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(mgx_dbg_cycles), z, sizeof z); }
+}
+#endif

@@ -166,6 +166,7 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
     e.xl.stride = MGX_OBS_THREADS;
   }
 
+  MGX_TICK0();
   // ---- phase 0: stage the env (coalesced) and build the per-object token cache ----
   {
     const uint4* src = (const uint4*)(d.grid + (size_t)env * HW);
@@ -186,6 +187,7 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
     if (tid == 0) s_misc[0] = 0;  // pool top
   }
   __syncthreads();
+  MGX_TICK(8);
   for (int s = tid; s < S; s += MGX_OBS_THREADS) {
     s_minobs[s] = 0xFFFFFFFFu;
     uint32_t info = 0;
@@ -241,6 +243,7 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
     }
   }
   __syncthreads();
+  MGX_TICK(9);
 
   const int hr = d.feat[14], wr = d.feat[15];  // obs_height >> 1, obs_width >> 1 (stored by the host)
   const int NPASS = (NOFF + 2 * MGX_WAVE - 1) / (2 * MGX_WAVE);  // two window cells per lane and pass
@@ -261,6 +264,7 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
     }
   }
   __syncthreads();
+  MGX_TICK(10);
 
   // ---- phase 2: encode ----
   for (int a = wave; a < A; a += MGX_OBS_WAVES) {
@@ -401,7 +405,9 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
   }
+  MGX_TICK(11);
   __syncthreads();
+  MGX_TICK(12);
 
   // ---- visited stamps, token statistics, rewards, termination ----
   if (step > 0)
@@ -421,6 +427,7 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
     gs[mgx_wk(d, MGX_S_GAME_TOKENS_FREE)] = tf;
     if (overflow) d.err[env] |= 1u;
   }
+  MGX_TICK(13);
   if (WITH_REWARDS) {
     if constexpr (X) __syncthreads();  // cell.visited stats of all waves are in before value expressions read them
     // X: query-backed values share one workspace per env -> one thread walks the agents in order
@@ -446,6 +453,7 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
       }
     }
   }
+  MGX_TICK(14);
 }
 
 #endif  // MGX_OBS_H_

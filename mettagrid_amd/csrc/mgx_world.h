@@ -44,6 +44,39 @@ struct MgxXLds {
   int lane, stride;
 };
 
+// Own-agent state of the world kernel, staged in LDS ([agent][lane]) at kernel start: slot, position, prev_location,
+// steps_without_motion and both action streams.  It is a read cache with write-through: every update also goes to HBM.
+struct MgxALds {
+  uint16_t* slot;
+  uint16_t* rc;
+  uint16_t* prev;
+  uint32_t* swm;
+  int16_t* act;   // [2][A][64] action ids, saturated to int16 (see mgx_sat16)
+  int lane, A;
+};
+// MGX_WORLD_TIMING (debug builds only): per-phase shader-clock totals of lane 0 of every wavefront.
+#ifdef MGX_WORLD_TIMING
+#ifndef MGX_DBG_LINKAGE
+#define MGX_DBG_LINKAGE static
+#endif
+MGX_DBG_LINKAGE __device__ unsigned long long mgx_dbg_cycles[16];
+#define MGX_TICK(k) do { unsigned long long _n = clock64(); if (threadIdx.x == 0) atomicAdd(&mgx_dbg_cycles[k], _n - _t); _t = _n; } while (0)
+#define MGX_TICK0() unsigned long long _t = clock64()
+#else
+#define MGX_TICK(k)
+#define MGX_TICK0()
+#endif
+
+// MGX_BIG: inlining policy of the large interpreter functions.  The benchmarked (non-extended) world kernel is built
+// in its own translation unit with MGX_BIG=__forceinline__ so the whole handler VM collapses into the kernel: MgxDev
+// stays in SGPRs and every state access is a global_load off an SGPR base.  The extended variant keeps real calls
+// (full inlining of its four nesting levels does not finish compiling in reasonable time).
+#ifndef MGX_BIG
+#define MGX_BIG
+#endif
+
+__host__ __device__ inline int mgx_world_alds_bytes(int A) { return A * MGX_WAVE * (2 + 2 + 2 + 4 + 4); }
+
 __device__ __forceinline__ unsigned long long mgx_floor_sqrt(unsigned long long v) {  // == floor_sqrt_u64 (:17-33), v < 2^53
   unsigned long long r = (unsigned long long)__dsqrt_rn((double)v);
   while (r * r > v) r--;
@@ -58,7 +91,11 @@ struct MgxEnvT {  // per-lane view of one env
   int env;
   uint32_t step;
   MgxXLds xl;
-  __device__ MgxEnvT(const MgxDev& dd, PP prog, int e) : d(dd), P(prog), env(e), step(0) { xl.def_delta = nullptr; xl.terr_score = nullptr; xl.lane = 0; xl.stride = MGX_WAVE; }
+  MgxALds al;
+  mutable int cur_agent, cur_slot;  // agent whose action is being executed (LDS write-through of its position)
+  __device__ MgxEnvT(const MgxDev& dd, PP prog, int e) : d(dd), P(prog), env(e), step(0), cur_agent(-1), cur_slot(-1) {
+    al.slot = nullptr; al.rc = nullptr; al.prev = nullptr; al.swm = nullptr; al.act = nullptr; al.lane = 0; al.A = 0;
+    xl.def_delta = nullptr; xl.terr_score = nullptr; xl.lane = 0; xl.stride = MGX_WAVE; }
   __device__ __forceinline__ PP cls(int c) const { return P + d.sec[MGX_SEC_CLASSES] + c * MGX_C_WORDS; }
 
   __device__ __forceinline__ size_t so(int slot) const { return (size_t)env * d.S + slot; }
@@ -74,38 +111,42 @@ struct MgxEnvT {  // per-lane view of one env
   __device__ __forceinline__ void flag(uint32_t bit) const { d.err[env] |= bit; }
 
   // ---- stats (systems/stats_tracker.hpp:69-90) ----
-  __device__ void astat_touch(int agent, int id) const { d.ag_touched[ao(agent) * d.NSW + (id >> 5)] |= 1u << (id & 31); }
+  __device__ __forceinline__ void astat_touch(int agent, int id) const { d.ag_touched[ao(agent) * d.NSW + (id >> 5)] |= 1u << (id & 31); }
   // add(): every caller adds a strictly positive amount to a key that only ever grows, so "value != 0" already
   // says the key exists; the host ORs that into the touched flags (mgx_get_stats) and the bit RMW is skipped here.
-  __device__ void astat_add(int agent, int id, float v) const {
+  // Plain read-modify-write on purpose: float atomics execute at the memory side on gfx950 (nothing stays in L2) and
+  // 64 lanes adding into 64 different rows is their slowest shape (MI355X_MICROARCH.md "Global float atomics").
+  __device__ __forceinline__ void astat_add(int agent, int id, float v) const {
     if (id < 0) return;
     d.ag_stats[ao(agent) * d.NS + id] += v;
   }
-  __device__ void astat_add_touch(int agent, int id, float v) const {  // for deltas that may be zero or negative
+  __device__ __forceinline__ void astat_add_touch(int agent, int id, float v) const {  // for deltas that may be zero or negative
     if (id < 0) return;
     d.ag_stats[ao(agent) * d.NS + id] += v;
     astat_touch(agent, id);
   }
-  __device__ void astat_set(int agent, int id, float v) const {
+  __device__ __forceinline__ void astat_set(int agent, int id, float v) const {
     if (id < 0) return;
     d.ag_stats[ao(agent) * d.NS + id] = v;
     astat_touch(agent, id);
   }
-  __device__ float astat_get(int agent, int id) const { return id < 0 ? 0.f : d.ag_stats[ao(agent) * d.NS + id]; }
-  __device__ void gstat_touch(int id) const { d.game_touched[(size_t)env * d.NGW + (id >> 5)] |= 1u << (id & 31); }
-  __device__ void gstat_set(int id, float v) const {
+  __device__ __forceinline__ float astat_get(int agent, int id) const {
+    return id < 0 ? 0.f : d.ag_stats[ao(agent) * d.NS + id];
+  }
+  __device__ __forceinline__ void gstat_touch(int id) const { d.game_touched[(size_t)env * d.NGW + (id >> 5)] |= 1u << (id & 31); }
+  __device__ __forceinline__ void gstat_set(int id, float v) const {
     if (id < 0) return;
     d.game_stats[(size_t)env * d.NG + id] = v;
     gstat_touch(id);
   }
-  __device__ void gstat_add(int id, float v) const {
+  __device__ __forceinline__ void gstat_add(int id, float v) const {
     if (id < 0) return;
     d.game_stats[(size_t)env * d.NG + id] += v;
     gstat_touch(id);
   }
 
   // ---- inventory (cpp/src/mettagrid/objects/inventory.cpp) ----
-  __device__ int effective_limit(int slot, PP L) const {  // objects/inventory.hpp:26-40
+  __device__ __forceinline__ int effective_limit(int slot, PP L) const {  // objects/inventory.hpp:26-40
     int sum = 0;
     PP mods = P + d.sec[MGX_SEC_MODS] + L[MGX_L_MOD_START] * MGX_MOD_WORDS;
     for (int i = 0; i < L[MGX_L_MOD_COUNT]; i++)
@@ -113,7 +154,7 @@ struct MgxEnvT {  // per-lane view of one env
     int eff = min(L[MGX_L_MAX], max(L[MGX_L_MIN], sum));
     return min(max(eff, 0), 65535);
   }
-  __device__ int group_amount(int slot, PP L) const {
+  __device__ __forceinline__ int group_amount(int slot, PP L) const {
     int s = 0;
     uint32_t mask = (uint32_t)L[MGX_L_RES_MASK];
     while (mask) {
@@ -123,11 +164,11 @@ struct MgxEnvT {  // per-lane view of one env
     }
     return s;
   }
-  __device__ PP limit_of(PP C, int item) const {
+  __device__ __forceinline__ PP limit_of(PP C, int item) const {
     int li = C[MGX_C_RES_LIMIT + item];
     return li < 0 ? (PP) nullptr : P + d.sec[MGX_SEC_LIMITS] + li * MGX_L_WORDS;
   }
-  __device__ void on_inventory_change(int slot, int item, int delta, int amount) const {  // objects/agent.cpp:106-121
+  __device__ MGX_BIG void on_inventory_change(int slot, int item, int delta, int amount) const {  // objects/agent.cpp:106-121
     int a = agent_of(slot);
     if (a < 0 || delta == 0) return;
     if (delta > 0) astat_add(a, mgx_wk(d, MGX_S_RES_GAINED_BASE) + item, (float)delta);
@@ -137,7 +178,7 @@ struct MgxEnvT {  // per-lane view of one env
   }
   // Inventory::update (inventory.cpp:38-86).  DEPTH bounds the update -> enforce_all_limits -> update recursion.
   template <int DEPTH>
-  __device__ int inv_update(int slot, int item, int delta, bool ignore_limits = false, bool notify = true) const {
+  __device__ MGX_BIG int inv_update(int slot, int item, int delta, bool ignore_limits = false, bool notify = true) const {
     PP C = cls_of(slot);
     int initial = inv(slot, item);
     int new_amount = initial + delta;
@@ -175,7 +216,7 @@ struct MgxEnvT {  // per-lane view of one env
     return dl;
   }
   template <int DEPTH>
-  __device__ void enforce_all_limits(int slot, PP C) const {  // inventory.cpp:141-173
+  __device__ MGX_BIG void enforce_all_limits(int slot, PP C) const {  // inventory.cpp:141-173
     for (int li = 0; li < C[MGX_C_LIMIT_COUNT]; li++) {
       PP L = P + d.sec[MGX_SEC_LIMITS] + (C[MGX_C_LIMIT_START] + li) * MGX_L_WORDS;
       if (L[MGX_L_DROP_COUNT] == 0) continue;
@@ -193,13 +234,13 @@ struct MgxEnvT {  // per-lane view of one env
       }
     }
   }
-  __device__ int free_space(int slot, int item) const {  // inventory.cpp:97-110
+  __device__ MGX_BIG int free_space(int slot, int item) const {  // inventory.cpp:97-110
     PP L = limit_of(cls_of(slot), item);
     if (!L) return 65535 - inv(slot, item);
     int used = group_amount(slot, L), eff = effective_limit(slot, L);
     return eff > used ? eff - used : 0;
   }
-  __device__ int transfer(int src, int dst, int item, int delta) const {  // objects/has_inventory.cpp:76-108
+  __device__ MGX_BIG int transfer(int src, int dst, int item, int delta) const {  // objects/has_inventory.cpp:76-108
     if (delta <= 0) return 0;
     int give = min((int)inv(src, item), delta);
     int amount = min(give, free_space(dst, item));
@@ -455,7 +496,7 @@ struct MgxEnvT {  // per-lane view of one env
   // ---- filters (handler/filters/*.hpp) as short-circuit code ----
   __device__ __forceinline__ int resolve(const MgxCtx& c, int ent) const { return ent == MGX_ENT_ACTOR ? c.actor : c.target; }
   template <int QD>
-  __device__ bool atom(PP a, const MgxCtx& c, int depth) const {
+  __device__ MGX_BIG bool atom(PP a, const MgxCtx& c, int depth) const {
     int a0 = a[MGX_AT_A0], a1 = a[MGX_AT_A1], a2 = a[MGX_AT_A2];
     switch (a[MGX_AT_OP]) {
       case MGX_FOP_VIBE: { int e = resolve(c, a0); return e != MGX_SLOT_NONE && (e >= 0 ? (int)d.obj_vibe[so(e)] : 0) == a1; }
@@ -531,7 +572,7 @@ struct MgxEnvT {  // per-lane view of one env
     }
   }
   template <int QD>
-  __device__ bool check_filters(int pc, const MgxCtx& c, int depth) const {  // handler/handler.cpp:95-103
+  __device__ MGX_BIG bool check_filters(int pc, const MgxCtx& c, int depth) const {  // handler/handler.cpp:95-103
     PP atoms = P + d.sec[MGX_SEC_ATOMS];
     while (pc >= 0) {
       PP a = atoms + pc * MGX_AT_WORDS;
@@ -564,13 +605,17 @@ struct MgxEnvT {  // per-lane view of one env
       }
     }
   }
-  __device__ bool move_object(int slot, int r, int c) const {
+  __device__ MGX_BIG bool move_object(int slot, int r, int c) const {
     if (r < 0 || c < 0 || r >= d.H || c >= d.W) return false;
     if (cell(r, c) != 0) return false;
     uint16_t rc = d.obj_rc[so(slot)];
     cell(r, c) = (uint16_t)(slot + 1);
     cell(rc >> 8, rc & 0xFF) = 0;
     d.obj_rc[so(slot)] = (uint16_t)((r << 8) | c);
+    if (al.rc) {
+      if (slot == cur_slot) al.rc[cur_agent * MGX_WAVE + al.lane] = (uint16_t)((r << 8) | c);
+      else { int a = agent_of(slot); if (a >= 0) al.rc[a * MGX_WAVE + al.lane] = (uint16_t)((r << 8) | c); }
+    }
     territory_moved(slot);
     return true;
   }
@@ -668,7 +713,7 @@ struct MgxEnvT {  // per-lane view of one env
 
   // ---- mutations (handler/mutations/*.hpp) ----
   template <int DEPTH>
-  __device__ void mutate(PP m, MgxCtx& c) const {
+  __device__ MGX_BIG void mutate(PP m, MgxCtx& c) const {
     int a0 = m[MGX_MU_A0], a1 = m[MGX_MU_A1], a2 = m[MGX_MU_A2], a3 = m[MGX_MU_A3];
     switch (m[MGX_MU_OP]) {
       case MGX_MOP_RESOURCE_DELTA: {  // resource_mutation.hpp:25-47
@@ -739,6 +784,7 @@ struct MgxEnvT {  // per-lane view of one env
         cell(ry >> 8, ry & 0xFF) = (uint16_t)(c.actor + 1);
         d.obj_rc[so(c.actor)] = ry;
         d.obj_rc[so(c.target)] = rx;
+        if (al.rc) { al.rc[xa * MGX_WAVE + al.lane] = ry; al.rc[ya * MGX_WAVE + al.lane] = rx; }
         territory_moved(c.actor);  // on_object_moved twice (core/grid.hpp:100-103)
         territory_moved(c.target);
         astat_add(xa, mgx_wk(d, MGX_S_SWAP), 1.f);
@@ -897,7 +943,7 @@ struct MgxEnvT {  // per-lane view of one env
   // Handler::try_apply (handler/handler.cpp:76-93) and MultiHandler::try_apply (multi_handler.cpp:8-21).
   // DEPTH bounds nesting (multi -> leaf -> use_target -> on_use multi -> leaf); exceeded depth raises MGX_ENV_DEPTH.
   template <int DEPTH>
-  __device__ bool apply_handler(int h, MgxCtx& c) const {
+  __device__ MGX_BIG bool apply_handler(int h, MgxCtx& c) const {
     PP hd = P + d.sec[MGX_SEC_HANDLERS] + h * MGX_HD_WORDS;
     if (hd[MGX_HD_KIND] == MGX_HK_LEAF) {
       if (!check_filters<TOPQ>(hd[MGX_HD_FILTER_PC], c, 0)) return false;
@@ -926,7 +972,7 @@ struct MgxEnvT {  // per-lane view of one env
   }
   // Filters + every mutation, no stop on mutation_failed (events, AoE sources, territory handlers:
   // handler/event.cpp:86-92, core/aoe_tracker.cpp:99-113, core/territory_tracker.cpp:62-66).
-  __device__ bool apply_all(int filter_pc, int mut_start, int mut_count, MgxCtx& c) const {
+  __device__ MGX_BIG bool apply_all(int filter_pc, int mut_start, int mut_count, MgxCtx& c) const {
     if (!check_filters<TOPQ>(filter_pc, c, 0)) return false;
     PP m = P + d.sec[MGX_SEC_MUTS] + mut_start * MGX_MU_WORDS;
     for (int i = 0; i < mut_count; i++, m += MGX_MU_WORDS) mutate<2>(m, c);
@@ -1139,12 +1185,12 @@ struct MgxEnvT {  // per-lane view of one env
   }
 
   // ---- actions ----
-  __device__ bool do_move(int slot, int orient) const {  // actions/move.hpp:81-115, orientation.hpp:28-48
+  __device__ MGX_BIG bool do_move(int slot, int orient) const {  // actions/move.hpp:81-115, orientation.hpp:28-48
     const int dx = (orient == 2 || orient == 4 || orient == 6) ? -1 : (orient == 3 || orient == 5 || orient == 7) ? 1 : 0;
     const int dy = (orient == 0 || orient == 4 || orient == 5) ? -1 : (orient == 1 || orient == 6 || orient == 7) ? 1 : 0;
     PP mh = P + d.sec[MGX_SEC_MOVE_HANDLERS];
     for (int k = 0; k < d.n_move_handlers; k++, mh += MGX_MH_WORDS) {
-      uint16_t rc = d.obj_rc[so(slot)];
+      uint16_t rc = (al.rc && slot == cur_slot) ? al.rc[cur_agent * MGX_WAVE + al.lane] : d.obj_rc[so(slot)];
       for (int i = 1; i <= mh[MGX_MH_MAX_RANGE]; i++) {
         int r = (rc >> 8) + dy * i, c = (rc & 0xFF) + dx * i;
         if (r < 0 || c < 0 || r >= d.H || c >= d.W) break;
@@ -1158,30 +1204,42 @@ struct MgxEnvT {  // per-lane view of one env
     }
     return false;
   }
-  __device__ bool handle_action(int ai, int action) const {  // actions/action_handler.hpp:78-105
+  __device__ MGX_BIG bool handle_action(int ai, int action) const {  // actions/action_handler.hpp:78-105
     PP ac = P + d.sec[MGX_SEC_ACTIONS] + action * MGX_AC_WORDS;
     int kind = ac[MGX_AC_KIND];
-    int slot = d.ag_obj[ao(ai)];
+    const int li = ai * MGX_WAVE + al.lane;
+    int slot = al.slot ? (int)al.slot[li] : (int)d.ag_obj[ao(ai)];
+    cur_agent = ai;
+    cur_slot = slot;
     bool ok = true;
+    MGX_TICK0();
     if (kind == MGX_AK_MOVE) ok = do_move(slot, ac[MGX_AC_ARG]);
     else if (kind == MGX_AK_VIBE) d.obj_vibe[so(slot)] = (uint8_t)ac[MGX_AC_ARG];  // actions/change_vibe.hpp:48-57
-    uint16_t rc = d.obj_rc[so(slot)];
-    if (rc == d.ag_prev[ao(ai)]) {
-      uint32_t swm = ++d.ag_swm[ao(ai)];
+    MGX_TICK(6);
+    uint16_t rc = al.rc ? al.rc[li] : d.obj_rc[so(slot)];
+    uint16_t prev = al.prev ? al.prev[li] : d.ag_prev[ao(ai)];
+    if (rc == prev) {
+      uint32_t swm = (al.swm ? al.swm[li] : d.ag_swm[ao(ai)]) + 1;
+      if (al.swm) al.swm[li] = swm;
+      d.ag_swm[ao(ai)] = swm;
       int sid = mgx_wk(d, MGX_S_MAX_STEPS_WITHOUT_MOTION);
       if ((float)swm > astat_get(ai, sid)) astat_set(ai, sid, (float)swm);
     } else {
+      if (al.swm) al.swm[li] = 0;
       d.ag_swm[ao(ai)] = 0;
+      if (al.prev) al.prev[li] = rc;
+      d.ag_prev[ao(ai)] = rc;
     }
-    d.ag_prev[ao(ai)] = rc;
+    cur_agent = cur_slot = -1;
     int s_ok = kind == MGX_AK_NOOP ? MGX_S_NOOP_SUCCESS : kind == MGX_AK_MOVE ? MGX_S_MOVE_SUCCESS : MGX_S_VIBE_SUCCESS;
     if (ok) astat_add(ai, mgx_wk(d, s_ok), 1.f);
     else { astat_add(ai, mgx_wk(d, s_ok + 1), 1.f); astat_add(ai, mgx_wk(d, MGX_S_ACTION_FAILED), 1.f); }
+    MGX_TICK(7);
     return ok;
   }
 
-  __device__ void track_coverage(int ai) const {  // objects/agent.cpp:49-57
-    uint16_t rc = d.obj_rc[so(d.ag_obj[ao(ai)])];
+  __device__ MGX_BIG void track_coverage(int ai) const {  // objects/agent.cpp:49-57
+    uint16_t rc = al.rc ? al.rc[ai * MGX_WAVE + al.lane] : d.obj_rc[so(d.ag_obj[ao(ai)])];
     // Unchanged position since the last call => the set is unchanged and both stats.set() calls would store the
     // values they already hold (keys exist since Agent::init): nothing to do.
     if (rc == d.ag_covrc[ao(ai)]) return;
@@ -1200,7 +1258,7 @@ struct MgxEnvT {  // per-lane view of one env
   }
 
   // ---- std::mt19937 + libstdc++ uniform_int_distribution / shuffle ----
-  __device__ uint32_t rng_next() const {  // incremental twist: identical stream to the batch _M_gen_rand
+  __device__ __forceinline__ uint32_t rng_next() const {  // incremental twist: identical stream to the batch _M_gen_rand
     uint32_t i = d.mt_idx[env];
     uint32_t i1 = i + 1 == 624 ? 0 : i + 1;
     uint32_t im = i + 397 >= 624 ? i + 397 - 624 : i + 397;
@@ -1215,7 +1273,7 @@ struct MgxEnvT {  // per-lane view of one env
     x ^= x >> 18;
     return x;
   }
-  __device__ uint32_t rng_below(uint32_t range) const {  // bits/uniform_int_dist.h:246-270 (Lemire, 64-bit product)
+  __device__ __forceinline__ uint32_t rng_below(uint32_t range) const {  // bits/uniform_int_dist.h:246-270 (Lemire, 64-bit product)
     unsigned long long p = (unsigned long long)rng_next() * range;
     uint32_t low = (uint32_t)p;
     if (low < range) {
@@ -1232,6 +1290,11 @@ struct MgxEnvT {  // per-lane view of one env
 typedef MgxEnvT<MgxGlobalProg, false> MgxEnv;
 typedef MgxEnvT<MgxGlobalProg, true> MgxEnvX;
 
+// Action ids are staged as int16.  Saturation keeps every distinction the dispatch makes: valid ids are < nact
+// (<= 32 000, checked at mgx_create), ids inside the +-16 invalid-index window keep their value, anything further out
+// stays further out.
+__device__ __forceinline__ int16_t mgx_sat16(int32_t a) { return (int16_t)max(-32768, min(32767, a)); }
+
 // order: LDS, [k][lane] bytes (k-major so that a wavefront access is bank-conflict free)
 __device__ __forceinline__ void mgx_swap(uint8_t* order, int lane, int i, int j) {
   uint8_t a = order[i * MGX_WAVE + lane], b = order[j * MGX_WAVE + lane];
@@ -1240,17 +1303,46 @@ __device__ __forceinline__ void mgx_swap(uint8_t* order, int lane, int i, int j)
 }
 
 template <class PP, bool X>
-__device__ __forceinline__ void mgx_world_body(const MgxDev& d, PP P, uint8_t* order, MgxXLds xl, int lane, int env) {
+__device__ __forceinline__ void mgx_world_body(const MgxDev& d, PP P, uint8_t* order, MgxXLds xl, MgxALds al, int lane, int env) {
   MgxEnvT<PP, X> e(d, P, env);
   e.xl = xl;
   const int A = d.A;
+  MGX_TICK0();
   e.step = ++d.step[env];
 
+  // ---- stage every agent's own state + both action streams in LDS.  The loads of one chunk are independent, so
+  // they are all in flight together instead of one HBM round trip per agent inside the serial loop below. ----
   const bool want_stepprev = (d.flags & MGX_G_LAST_ACTION_MOVE) != 0;
-  for (int i = 0; i < A; i++) {  // mettagrid_c.cpp:929-944 (executed/success are cleared by the host-side memset)
-    if (want_stepprev) d.ag_stepprev[e.ao(i)] = d.obj_rc[e.so(d.ag_obj[e.ao(i)])];
-    order[i * MGX_WAVE + lane] = (uint8_t)i;
+  for (int i0 = 0; i0 < A; i0 += 8) {
+    uint16_t slot8[8], prev8[8];
+    uint32_t swm8[8];
+    int32_t a8[8], v8[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      int i = min(i0 + q, A - 1);
+      slot8[q] = d.ag_obj[e.ao(i)];
+      prev8[q] = d.ag_prev[e.ao(i)];
+      swm8[q] = d.ag_swm[e.ao(i)];
+      a8[q] = d.actions[e.ao(i)];
+      v8[q] = d.vibe_actions[e.ao(i)];
+    }
+    uint16_t rc8[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) rc8[q] = d.obj_rc[e.so(slot8[q])];
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      int i = i0 + q;
+      if (i < A) {
+        int li = i * MGX_WAVE + lane;
+        al.slot[li] = slot8[q]; al.rc[li] = rc8[q]; al.prev[li] = prev8[q]; al.swm[li] = swm8[q];
+        al.act[li] = mgx_sat16(a8[q]); al.act[A * MGX_WAVE + li] = mgx_sat16(v8[q]);
+        if (want_stepprev) d.ag_stepprev[e.ao(i)] = rc8[q];  // mettagrid_c.cpp:929-931
+        order[li] = (uint8_t)i;
+      }
+    }
   }
+  e.al = al;
+  MGX_TICK(0);
   // std::shuffle (bits/stl_algo.h:3729-3795): one draw for an even n, then paired draws
   if (A >= 2) {
     uint32_t i = 1;
@@ -1273,11 +1365,11 @@ __device__ __forceinline__ void mgx_world_body(const MgxDev& d, PP P, uint8_t* o
   // stats added (max_priority + 1) times is equivalent — the stat keys involved are touched by nothing else.
   PP acts = P + d.sec[MGX_SEC_ACTIONS];
   const int repeats = d.max_priority + 1;
+  MGX_TICK(1);
   for (int stream = 0; stream < 2; stream++) {
-    const int32_t* src = stream == 0 ? d.actions : d.vibe_actions;
     for (int k = 0; k < A; k++) {
       int ai = order[k * MGX_WAVE + lane];
-      int a = src[e.ao(ai)];
+      int a = al.act[(stream * A + ai) * MGX_WAVE + lane];
       if (a < 0 || a >= d.nact) {  // _handle_invalid_action :914-919
         for (int rep = 0; rep < repeats; rep++) {
           e.astat_add(ai, mgx_wk(d, MGX_S_INVALID_INDEX), 1.f);
@@ -1295,6 +1387,7 @@ __device__ __forceinline__ void mgx_world_body(const MgxDev& d, PP P, uint8_t* o
         d.success[e.ao(ai)] = 1;
       }
     }
+    MGX_TICK(2 + stream);
   }
   if constexpr (X) {
     if (d.n_schedule > 0) e.process_events();  // mettagrid_c.cpp:1009-1011
@@ -1326,27 +1419,42 @@ __device__ __forceinline__ void mgx_world_body(const MgxDev& d, PP P, uint8_t* o
       e.template apply_handler<3>(d.game_on_tick, c);
     }
   }
+  MGX_TICK(4);
   for (int i = 0; i < A; i++) e.track_coverage(i);  // mettagrid_c.cpp:1054-1056
+  MGX_TICK(5);
 }
 
 // PROG_LDS: the program blob is first copied into LDS (16-byte coalesced loads) and every table lookup of the
 // handler VM becomes a ds_read.  Dynamic LDS: order u8[A][64] | [X: deferred i32[28][64] | territory i64[8][64]] |
 // program i32[prog_words].
 __host__ __device__ inline int mgx_world_lds_fixed(int A, bool X) {
-  int o = (A * MGX_WAVE + 15) & ~15;
+  int o = ((A * MGX_WAVE + 15) & ~15) + ((mgx_world_alds_bytes(A) + 15) & ~15);
   if (X) o += 28 * MGX_WAVE * 4 + 8 * MGX_WAVE * 8;
   return o;
 }
+// lpw = envs (active lanes) per wavefront.  The interpreter is a chain of dependent loads, so what bounds it is how
+// many wavefronts each SIMD can switch between, not lane utilisation: a workgroup always owns 64 envs, spread over
+// 64/lpw wavefronts that use their first lpw lanes.  LDS arrays stay [k][64] indexed by the env's index in the group.
 template <bool PROG_LDS, bool X>
-__global__ void __launch_bounds__(MGX_WAVE) mgx_world_kernel(MgxDev d, int prog_words) {
+__device__ __forceinline__ void mgx_world_entry(const MgxDev& d, int prog_words, int lpw) {
   extern __shared__ __align__(16) uint8_t wsmem[];
   uint8_t* order = wsmem;
-  const int lane = threadIdx.x;
+  const int wl = threadIdx.x & (MGX_WAVE - 1);
+  const int lane = (threadIdx.x >> 6) * lpw + wl;
+  const bool active = wl < lpw;
   const int env = blockIdx.x * MGX_WAVE + lane;
   MgxXLds xl;
   xl.lane = lane;
   xl.stride = MGX_WAVE;
   int off = (d.A * MGX_WAVE + 15) & ~15;
+  MgxALds al;
+  al.lane = lane; al.A = d.A;
+  al.swm = (uint32_t*)(wsmem + off);                 // u32 [A][64]
+  al.act = (int16_t*)(wsmem + off + d.A * MGX_WAVE * 4);   // i16 [2][A][64]
+  al.slot = (uint16_t*)(wsmem + off + d.A * MGX_WAVE * 8);
+  al.rc = al.slot + d.A * MGX_WAVE;
+  al.prev = al.rc + d.A * MGX_WAVE;
+  off += (mgx_world_alds_bytes(d.A) + 15) & ~15;
   if (X) {
     xl.def_delta = (int*)(wsmem + off);
     off += 28 * MGX_WAVE * 4;
@@ -1360,16 +1468,23 @@ __global__ void __launch_bounds__(MGX_WAVE) mgx_world_kernel(MgxDev d, int prog_
     int32_t* lprog = (int32_t*)(wsmem + off);
     const int4* src = (const int4*)d.P;
     int4* dst = (int4*)lprog;
-    for (int i = lane; i < prog_words / 4; i += MGX_WAVE) dst[i] = src[i];
+    for (int i = threadIdx.x; i < prog_words / 4; i += blockDim.x) dst[i] = src[i];
     __syncthreads();
-    if (env >= d.E) return;
-    mgx_world_body<MgxLdsProg, X>(d, (MgxLdsProg)lprog, order, xl, lane, env);
+    if (!active || env >= d.E) return;
+    mgx_world_body<MgxLdsProg, X>(d, (MgxLdsProg)lprog, order, xl, al, lane, env);
   } else {
-    if (env >= d.E) return;
-    mgx_world_body<MgxGlobalProg, X>(d, d.P, order, xl, lane, env);
+    if (!active || env >= d.E) return;
+    mgx_world_body<MgxGlobalProg, X>(d, d.P, order, xl, al, lane, env);
   }
 }
 
+#define MGX_WORLD_MAX_THREADS 512  // lpw >= 8
+
+// Host launcher of the non-extended world kernels (defined in mgx_world_fast.hip).  wpe = 0 or a waves-per-SIMD
+// occupancy target the kernel variant was compiled for (VGPR budget 512 / wpe).
+void mgx_launch_world_fast(bool prog_lds, int wpe, int lpw, size_t lds, hipStream_t stream, const MgxDev& d, int prog_words);
+
+#ifndef MGX_WORLD_FAST_TU
 // Construction: MettaGrid ctor + _init_grid (mettagrid_c.cpp:42-191, 200-269).  One lane per env scans the class
 // map in row-major order; object slot = reference object id - 1; agent index = order of appearance.
 __global__ void __launch_bounds__(MGX_WAVE) mgx_init_kernel(MgxDev d, const uint16_t* class_maps, const uint32_t* seeds,
@@ -1491,5 +1606,7 @@ __global__ void mgx_fill_rows_kernel(uint8_t* base, size_t row_bytes, int fill, 
   uint8_t* row = base + (size_t)env * row_bytes;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < row_bytes; i += (size_t)gridDim.x * blockDim.x) row[i] = (uint8_t)fill;
 }
+
+#endif  // !MGX_WORLD_FAST_TU
 
 #endif  // MGX_WORLD_H_

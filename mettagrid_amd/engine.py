@@ -22,7 +22,7 @@ from .fmt import K
 from .signature import objects_from_raw, stats_dicts
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmgx.so")
+LIB_PATH = os.environ.get("MGX_LIB") or os.path.join(_HERE, "libmgx.so")  # MGX_LIB: instrumented dev builds
 _lib = None
 OBJ_RECORD_WORDS = 42
 
