@@ -294,6 +294,12 @@ class _Compiler:
     def gv_emit(self, v) -> tuple[int, int]:
         code: list = []
         self.gv_code(v, code)
+        depth = peak = 0  # the device evaluates on an 8-entry register stack (MgxValueStack)
+        for ins in code:
+            depth += -1 if ins[0] in (K.GOP_ADD_TERM, K.GOP_RATIO, K.GOP_MAX2, K.GOP_MIN2) else 1
+            peak = max(peak, depth)
+        if peak > 8:
+            raise UnsupportedFeature("game value expression nests deeper than 8 stack entries")
         start = self.counts[K.SEC_GV_CODE]
         for ins in code:
             self.emit(K.SEC_GV_CODE, ins)

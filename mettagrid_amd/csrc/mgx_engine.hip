@@ -51,6 +51,8 @@ struct mgx_engine {
   size_t lds_world = 0, lds_obs = 0;
   int pool_tokens = 0;
   bool prog_in_lds = false;
+  int obs_blk_start = 0, obs_blk_words = 0;  // program block the observation kernel interprets
+  bool obs_blk_lds = false;
   int world_lpw = MGX_WAVE;  // envs per wavefront of the world kernel (64, 32, 16 or 8)
   int world_wpe = 0;         // 4: the 128-VGPR build of the non-extended world kernel
   uint16_t* dmaps = nullptr;
@@ -84,15 +86,21 @@ struct mgx_engine {
   }
 };
 
-static int launch_obs(mgx_engine* e, bool with_rewards, const uint8_t* mask = nullptr) {
+template <bool X, bool PL>
+static void launch_obs_t(mgx_engine* e, bool with_rewards, const uint8_t* mask) {
   dim3 grid(e->d.E), block(MGX_OBS_THREADS);
-  if (e->d.X) {
-    if (with_rewards) hipLaunchKernelGGL((mgx_obs_kernel<true, true>), grid, block, e->lds_obs, e->stream, e->d, e->pool_tokens, mask);
-    else hipLaunchKernelGGL((mgx_obs_kernel<false, true>), grid, block, e->lds_obs, e->stream, e->d, e->pool_tokens, mask);
-  } else {
-    if (with_rewards) hipLaunchKernelGGL((mgx_obs_kernel<true, false>), grid, block, e->lds_obs, e->stream, e->d, e->pool_tokens, mask);
-    else hipLaunchKernelGGL((mgx_obs_kernel<false, false>), grid, block, e->lds_obs, e->stream, e->d, e->pool_tokens, mask);
-  }
+  MgxDev dd = e->d;
+  if (PL)  // the interpreted sections are addressed relative to their LDS copy
+    for (int k = MGX_SEC_INV_FEATURES; k < MGX_SEC_WORDLIST; k++) dd.sec[k] -= e->obs_blk_start;
+  if (with_rewards)
+    hipLaunchKernelGGL((mgx_obs_kernel<true, X, PL>), grid, block, e->lds_obs, e->stream, dd, e->pool_tokens, mask, e->obs_blk_start, e->obs_blk_words);
+  else
+    hipLaunchKernelGGL((mgx_obs_kernel<false, X, PL>), grid, block, e->lds_obs, e->stream, dd, e->pool_tokens, mask, e->obs_blk_start, e->obs_blk_words);
+}
+static int launch_obs(mgx_engine* e, bool with_rewards, const uint8_t* mask = nullptr) {
+  if (e->d.X) launch_obs_t<true, false>(e, with_rewards, mask);
+  else if (e->obs_blk_lds) launch_obs_t<false, true>(e, with_rewards, mask);
+  else launch_obs_t<false, false>(e, with_rewards, mask);
   HIP_TRY(hipGetLastError());
   return MGX_OK;
 }
@@ -330,15 +338,28 @@ int mgx_create(const int32_t* program, size_t program_words, const uint16_t* cla
     d.cls_tokinfo = dinfo;
     d.cls_tok = dtoks;
   }
-  e->lds_obs = (size_t)mgx_obs_lds_layout((int)HW, d.NOFF, (int)S, (int)A, d.T, e->pool_tokens, d.X != 0, d.n_obs_values).total;
+  {  // sections INV_FEATURES..OBS_VALUES are contiguous (sections are laid out in id order); small block -> LDS copy
+    const int b0 = d.sec[MGX_SEC_INV_FEATURES], b1 = d.sec[MGX_SEC_WORDLIST];
+    const bool ordered = b0 <= d.sec[MGX_SEC_GV_CODE] && d.sec[MGX_SEC_GV_CODE] <= d.sec[MGX_SEC_REWARDS] &&
+                         d.sec[MGX_SEC_REWARDS] <= d.sec[MGX_SEC_OBS_VALUES] && d.sec[MGX_SEC_OBS_VALUES] <= b1;
+    e->obs_blk_start = b0;
+    e->obs_blk_words = b1 - b0;
+    e->obs_blk_lds = !d.X && ordered && (b0 & 3) == 0 && (e->obs_blk_words & 3) == 0 && e->obs_blk_words * 4 <= 8 * 1024;
+  }
+  e->lds_obs = (size_t)mgx_obs_lds_layout((int)HW, d.NOFF, (int)S, (int)A, d.T, e->pool_tokens, d.X != 0, d.n_obs_values,
+                                          e->obs_blk_lds ? e->obs_blk_words : 0).total;
   if (e->lds_obs > 160 * 1024 || e->lds_world > 64 * 1024) {
     mgx_destroy(e);
     return fail(MGX_ERR_PROGRAM, "mgx_create: map/object count too large for the LDS staging of the observation kernel");
   }
-  hipError_t he = hipFuncSetAttribute((const void*)mgx_obs_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_obs);
-  if (he == hipSuccess) he = hipFuncSetAttribute((const void*)mgx_obs_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_obs);
-  if (he == hipSuccess) he = hipFuncSetAttribute((const void*)mgx_obs_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_obs);
-  if (he == hipSuccess) he = hipFuncSetAttribute((const void*)mgx_obs_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_obs);
+  hipError_t he = hipSuccess;
+  {
+    const void* fns[] = {(const void*)mgx_obs_kernel<true, false, false>, (const void*)mgx_obs_kernel<false, false, false>,
+                         (const void*)mgx_obs_kernel<true, false, true>,  (const void*)mgx_obs_kernel<false, false, true>,
+                         (const void*)mgx_obs_kernel<true, true, false>,  (const void*)mgx_obs_kernel<false, true, false>};
+    for (const void* f : fns)
+      if (he == hipSuccess) he = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_obs);
+  }
   if (he == hipSuccess) he = hipMemcpyAsync(dprog, program, program_words * 4, hipMemcpyHostToDevice, e->stream);
   if (he == hipSuccess) he = hipMemcpyAsync(dmaps, class_maps, E * HW * 2, hipMemcpyHostToDevice, e->stream);
   if (he == hipSuccess) he = hipMemcpyAsync(dseeds, seeds, E * 4, hipMemcpyHostToDevice, e->stream);

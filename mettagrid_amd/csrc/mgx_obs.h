@@ -15,6 +15,8 @@
 #ifndef MGX_OBS_H_
 #define MGX_OBS_H_
 
+#include <type_traits>
+
 #include "mgx_world.h"
 
 #define MGX_OBS_THREADS 256
@@ -49,61 +51,38 @@ __device__ __forceinline__ int mgx_digits(uint32_t v, uint32_t base) {  // encod
 struct MgxObjTok {
   uint16_t* pool;
   int pos;
-  __device__ __forceinline__ void put(uint8_t f, uint8_t v) { pool[pos++] = (uint16_t)(f | (v << 8)); }
+  __device__ __forceinline__ void put(uint32_t f, uint32_t v) { pool[pos++] = (uint16_t)((f & 0xFF) | ((v & 0xFF) << 8)); }
 };
 
-template <class ENV>
-__device__ int mgx_object_dyn_token_count(const MgxDev& d, const ENV& e, int slot, uint32_t cinfo) {
-  int n = 0;
-  if (d.obj_vibe[e.so(slot)] != 0) n++;
-  unsigned long long ord = d.obj_order[e.so(slot)];
-  if (d.obj_flags && (d.obj_flags[e.so(slot)] & 2)) ord = ~0ull;  // created without an ObservationEncoder
-  for (int k = 0; k < 16; k++) {
-    int item = (int)((ord >> (4 * k)) & 0xF);
-    if (item == 0xF) break;
-    n += mgx_digits(e.inv(slot, item), (uint32_t)d.base);
+// Digit arithmetic of the token encoder (encoding_utils.hpp:39-62).  token_value_base is a power of two in every
+// shipped config (default 256): that case is shift/mask; any other base takes the division path.
+struct MgxBase {
+  uint32_t base;
+  int shift;  // log2(base) if base is a power of two, else -1
+  __device__ __forceinline__ explicit MgxBase(uint32_t b) : base(b), shift((b & (b - 1)) == 0 ? __ffs(b) - 1 : -1) {}
+  __device__ __forceinline__ uint32_t lo(uint32_t v) const { return shift >= 0 ? (v & (base - 1)) : v % base; }
+  __device__ __forceinline__ uint32_t hi(uint32_t v) const { return shift >= 0 ? (v >> shift) : v / base; }
+  __device__ __forceinline__ int digits(uint32_t v) const {
+    int n = 1;
+    for (v = hi(v); v > 0; v = hi(v)) n++;
+    return n;
   }
-  if (cinfo & 0x40000000u) n += 2;  // agent: group + agent_id
-  return n;
-}
+};
 
-template <class ENV>
-__device__ void mgx_object_dyn_tokens_build(const MgxDev& d, const ENV& e, int slot, uint32_t cinfo, MgxObjTok w) {
-  uint8_t vibe = d.obj_vibe[e.so(slot)];
-  if (vibe != 0) w.put((uint8_t)d.feat[MGX_F_VIBE], vibe);
-  unsigned long long ord = d.obj_order[e.so(slot)];
-  if (d.obj_flags && (d.obj_flags[e.so(slot)] & 2)) ord = ~0ull;
-  for (int k = 0; k < 16; k++) {  // observation_encoder.hpp:198-225: base digit, then :pK digits while remaining > 0
-    int item = (int)((ord >> (4 * k)) & 0xF);
-    if (item == 0xF) break;
-    const int32_t* F = d.P + d.sec[MGX_SEC_INV_FEATURES] + item * MGX_IF_WORDS;
-    uint32_t rem = e.inv(slot, item);
-    w.put((uint8_t)F[0], (uint8_t)(rem % (uint32_t)d.base));
-    rem /= (uint32_t)d.base;
-    int p = 1;
-    while (rem > 0) {
-      w.put((uint8_t)F[p], (uint8_t)(rem % (uint32_t)d.base));
-      rem /= (uint32_t)d.base;
-      p++;
-    }
-  }
-  if (cinfo & 0x40000000u) {
-    w.put((uint8_t)d.feat[MGX_F_GROUP], (uint8_t)((cinfo >> 16) & 0xFF));
-    w.put((uint8_t)d.feat[MGX_F_AGENT_ID], d.obj_agent[e.so(slot)]);
-  }
-}
+#define MGX_MAX_ITEMS 13  // resources per inventory (mgx_create enforces R <= 13: 4-bit ids, 0xF terminator)
 
 // Dynamic LDS layout, all regions 16-byte aligned (the host calls the same function):
 //   grid u16[HW] | offsets i8x2[NOFF] | minobs u32[S] | visited u32[S] | tokinfo u32[S] (start | count << 16) |
 //   agents u32[A] (slot | rc << 16) | aginfo u32[A] (executed | moved << 8) | spawn u16[A] | vstat f32[A] |
-//   written i32[A] | misc u32[4] | pool u16[POOL] | rows u32[WAVES][Tpad]
+//   written i32[A] | rwinfo u32[A] (reward start | count << 16) | misc u32[4] | pool u16[POOL] | rows u32[WAVES][Tpad] |
+//   blk i32[blk_words]: program sections INV_FEATURES..OBS_VALUES (PL variants only)
 __host__ __device__ inline int mgx_align16(int x) { return (x + 15) & ~15; }
 struct MgxObsLds {
-  int grid, offs, minobs, visited, tokinfo, agents, aginfo, spawn, vstat, written, misc, pool, rows, row_words, total;
+  int grid, offs, minobs, visited, tokinfo, agents, aginfo, spawn, vstat, written, rwinfo, misc, pool, rows, row_words, blk, total;
   int owner, obsval, tscore;  // X only: per-cell territory owner u16[HW], obs values u32[A][NOV], scores i64[8][256]
 };
 __host__ __device__ inline MgxObsLds mgx_obs_lds_layout(int HW, int NOFF, int S, int A, int T, int pool_tokens,
-                                                        bool X = false, int NOV = 0) {
+                                                        bool X = false, int NOV = 0, int blk_words = 0) {
   MgxObsLds l;
   int o = 0;
   l.grid = o; o += mgx_align16(HW * 2);
@@ -116,6 +95,7 @@ __host__ __device__ inline MgxObsLds mgx_obs_lds_layout(int HW, int NOFF, int S,
   l.spawn = o; o += mgx_align16(A * 2);
   l.vstat = o; o += mgx_align16(A * 4);
   l.written = o; o += mgx_align16(A * 4);
+  l.rwinfo = o; o += mgx_align16(A * 4);
   l.misc = o; o += 16;
   l.pool = o; o += mgx_align16(pool_tokens * 2);
   l.row_words = (T + 3) & ~3;
@@ -126,18 +106,26 @@ __host__ __device__ inline MgxObsLds mgx_obs_lds_layout(int HW, int NOFF, int S,
     l.obsval = o; o += mgx_align16((A * NOV + 1) * 4);
     l.tscore = o; o += 8 * MGX_OBS_THREADS * 8;
   }
+  l.blk = o; o += mgx_align16(blk_words * 4);
   l.total = o;
   return l;
 }
 
-template <bool WITH_REWARDS, bool X>
-__global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int pool_tokens, const uint8_t* env_mask) {
+// PL: the program sections this kernel interprets (inventory feature ids, game-value code, reward records, obs
+// values: [blk_start, blk_start + blk_words) of the blob, contiguous because the compiler lays sections out in id
+// order) are copied into LDS so the reward / obs-value interpreter and the token builder never wait on global loads
+// for program words.  The host picks PL when the block is small (mgx_create) and passes a MgxDev whose section
+// offsets for exactly those sections are relative to the block start, so the LDS view is a plain base pointer (no
+// out-of-object pointer arithmetic on an LDS address).
+template <bool WITH_REWARDS, bool X, bool PL>
+__global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int pool_tokens, const uint8_t* env_mask,
+                                                                  int blk_start, int blk_words) {
   extern __shared__ __align__(16) uint8_t smem[];
   const int env = blockIdx.x;
   if (env_mask && !env_mask[env]) return;  // episode restart: only the restarted envs get initial observations
   const int tid = threadIdx.x, lane = tid & (MGX_WAVE - 1), wave = tid / MGX_WAVE;
   const int HW = d.H * d.W, A = d.A, S = d.S, T = d.T, NOFF = d.NOFF;
-  const MgxObsLds L = mgx_obs_lds_layout(HW, NOFF, S, A, T, pool_tokens, X, d.n_obs_values);
+  const MgxObsLds L = mgx_obs_lds_layout(HW, NOFF, S, A, T, pool_tokens, X, d.n_obs_values, PL ? blk_words : 0);
   uint16_t* s_grid = (uint16_t*)(smem + L.grid);
   char2* s_offs = (char2*)(smem + L.offs);
   uint32_t* s_minobs = (uint32_t*)(smem + L.minobs);
@@ -148,6 +136,7 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
   uint16_t* s_spawn = (uint16_t*)(smem + L.spawn);
   float* s_vstat = (float*)(smem + L.vstat);
   int* s_written = (int*)(smem + L.written);
+  uint32_t* s_rwinfo = (uint32_t*)(smem + L.rwinfo);
   uint32_t* s_misc = (uint32_t*)(smem + L.misc);
   uint16_t* s_pool = (uint16_t*)(smem + L.pool);
   uint32_t* s_row = (uint32_t*)(smem + L.rows) + wave * L.row_words;  // one u32 per token: loc | f << 8 | v << 16
@@ -165,6 +154,15 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
     e.xl.lane = tid;
     e.xl.stride = MGX_OBS_THREADS;
   }
+  // Program view of the interpreted sections: LDS copy (PL) or the blob itself.
+  typedef typename std::conditional<PL, MgxLdsProg, MgxGlobalProg>::type VP;
+  VP vp;
+  if constexpr (PL) vp = (MgxLdsProg)(int32_t*)(smem + L.blk);
+  else vp = d.P;
+  MgxEnvT<VP, X> ev(d, vp, env);
+  ev.step = step;
+  ev.xl = e.xl;
+  const MgxBase B((uint32_t)d.base);
 
   MGX_TICK0();
   // ---- phase 0: stage the env (coalesced) and build the per-object token cache ----
@@ -174,54 +172,119 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
     const int n16 = (HW * 2) / 16;
     for (int i = tid; i < n16; i += MGX_OBS_THREADS) dst[i] = src[i];
     for (int i = n16 * 8 + tid; i < HW; i += MGX_OBS_THREADS) s_grid[i] = d.grid[(size_t)env * HW + i];
+    if constexpr (PL) {
+      const int4* bsrc = (const int4*)(d.P + blk_start);
+      int4* bdst = (int4*)(smem + L.blk);
+      for (int i = tid; i < blk_words / 4; i += MGX_OBS_THREADS) bdst[i] = bsrc[i];
+    }
     const int32_t* offs = d.P + d.sec[MGX_SEC_OBS_OFFSETS];
     for (int i = tid; i < NOFF; i += MGX_OBS_THREADS) s_offs[i] = make_char2((char)offs[i * 2], (char)offs[i * 2 + 1]);
     for (int i = tid; i < A; i += MGX_OBS_THREADS) {
-      uint32_t slot = d.ag_obj[e.ao(i)];
-      uint16_t rc = d.obj_rc[e.so(slot)];
+      const uint32_t slot = d.ag_obj[e.ao(i)];
+      const int32_t ex = d.executed[e.ao(i)];
+      const uint16_t sprev = d.ag_stepprev[e.ao(i)];
+      const uint16_t spawn = d.ag_spawn[e.ao(i)];
+      const float vs = step > 0 ? e.astat_get(i, sid_visited) : 0.f;
+      const uint16_t rc = d.obj_rc[e.so(slot)];
+      const int32_t* C = mgx_cls(d, d.obj_cls[e.so(slot)]);
       s_agents[i] = slot | ((uint32_t)rc << 16);
-      s_aginfo[i] = ((uint32_t)d.executed[e.ao(i)] & 0xFF) | (rc != d.ag_stepprev[e.ao(i)] ? 0x100u : 0u);
-      s_spawn[i] = d.ag_spawn[e.ao(i)];
-      s_vstat[i] = step > 0 ? e.astat_get(i, sid_visited) : 0.f;
+      s_aginfo[i] = ((uint32_t)ex & 0xFF) | (rc != sprev ? 0x100u : 0u);
+      s_spawn[i] = spawn;
+      s_vstat[i] = vs;
+      s_rwinfo[i] = ((uint32_t)C[MGX_C_REWARD_START] & 0xFFFFu) | ((uint32_t)C[MGX_C_REWARD_COUNT] << 16);
     }
     if (tid == 0) s_misc[0] = 0;  // pool top
   }
   __syncthreads();
   MGX_TICK(8);
-  for (int s = tid; s < S; s += MGX_OBS_THREADS) {
-    s_minobs[s] = 0xFFFFFFFFu;
-    uint32_t info = 0;
-    uint16_t cls = d.obj_cls[e.so(s)];
-    if (cls != MGX_DEAD_CLASS) {
-      const uint32_t cinfo = d.cls_tokinfo[cls];  // start(16) | group(8) | ntags(6) | agent(1) | static(1)
-      int ntags = (cinfo >> 24) & 0x3F;
-      const bool is_static = (cinfo >> 31) != 0;
-      const bool dyn_tags = X && d.obj_tags != nullptr;
-      if (dyn_tags) {
-        ntags = 0;
-        for (int w = 0; w < MGX_TAG_WORDS; w++) ntags += __popc(d.obj_tags[e.so(s) * MGX_TAG_WORDS + w]);
+  {
+    const int f_vibe = d.feat[MGX_F_VIBE], f_group = d.feat[MGX_F_GROUP], f_agent = d.feat[MGX_F_AGENT_ID], f_tag = d.feat[MGX_F_TAG];
+    VP feat = vp + d.sec[MGX_SEC_INV_FEATURES];
+    for (int s = tid; s < S; s += MGX_OBS_THREADS) {
+      // every field of the slot at once: independent loads, one memory round trip
+      const size_t o = e.so(s);
+      const uint16_t cls = d.obj_cls[o];
+      const uint32_t vis = d.obj_visited[o];
+      const uint32_t vibe = d.obj_vibe[o];
+      const uint32_t agent_id = d.obj_agent[o];
+      unsigned long long ord = d.obj_order[o];
+      if constexpr (X) {
+        if (d.obj_flags && (d.obj_flags[o] & 2)) ord = ~0ull;  // created at run time without an ObservationEncoder
       }
-      int n = ntags + (is_static ? 0 : mgx_object_dyn_token_count(d, e, s, cinfo));
-      uint32_t start = atomicAdd(&s_misc[0], (uint32_t)n);
-      if ((int)(start + n) <= pool_tokens) {
-        if (dyn_tags) {
-          int k = 0;
-          for (int w = 0; w < MGX_TAG_WORDS; w++) {
-            uint32_t m = d.obj_tags[e.so(s) * MGX_TAG_WORDS + w];
-            while (m) { int b = __ffs(m) - 1; m &= m - 1; s_pool[start + k++] = (uint16_t)(d.feat[MGX_F_TAG] | ((w * 32 + b) << 8)); }
+      s_minobs[s] = 0xFFFFFFFFu;
+      uint32_t info = 0;
+      if (cls != MGX_DEAD_CLASS) {
+        const uint32_t cinfo = d.cls_tokinfo[cls];  // start(16) | group(8) | ntags(6) | agent(1) | static(1)
+        const bool is_static = (cinfo >> 31) != 0;
+        const bool is_agent = (cinfo & 0x40000000u) != 0;
+        // inventory amounts in iteration order (second round trip, again all loads in flight together)
+        uint32_t amt[MGX_MAX_ITEMS];
+        uint32_t live_mask = 0;
+        {
+          bool live = !is_static;
+#pragma unroll
+          for (int k = 0; k < MGX_MAX_ITEMS; k++) {
+            const int item = (int)((ord >> (4 * k)) & 0xF);
+            live = live && item != 0xF;
+            amt[k] = live ? (uint32_t)d.obj_inv[o * d.R + item] : 0u;
+            if (live) live_mask |= 1u << k;
           }
-        } else {
-          const uint16_t* src = d.cls_tok + (cinfo & 0xFFFF);
-          for (int k = 0; k < ntags; k++) s_pool[start + k] = src[k];
         }
-        if (!is_static) mgx_object_dyn_tokens_build(d, e, s, cinfo, MgxObjTok{s_pool, (int)start + ntags});
-        info = start | ((uint32_t)n << 16);
-      } else {
-        d.err[env] |= 16u;  // token pool exhausted (sized by the host from the program's per-object maximum)
+        int ntags = (cinfo >> 24) & 0x3F;
+        const bool dyn_tags = X && d.obj_tags != nullptr;
+        uint32_t tagw[MGX_TAG_WORDS];
+        if (dyn_tags) {
+          ntags = 0;
+#pragma unroll
+          for (int w = 0; w < MGX_TAG_WORDS; w++) { tagw[w] = d.obj_tags[o * MGX_TAG_WORDS + w]; ntags += __popc(tagw[w]); }
+        }
+        int n = ntags;
+        if (!is_static) {
+          if (vibe != 0) n++;
+#pragma unroll
+          for (int k = 0; k < MGX_MAX_ITEMS; k++)
+            if (live_mask & (1u << k)) n += B.digits(amt[k]);
+          if (is_agent) n += 2;  // group + agent_id
+        }
+        const uint32_t start = atomicAdd(&s_misc[0], (uint32_t)n);
+        if ((int)(start + n) <= pool_tokens) {
+          MgxObjTok w{s_pool, (int)start};
+          if (dyn_tags) {  // ascending tag id (core/grid_object.cpp:181-186)
+#pragma unroll
+            for (int wd = 0; wd < MGX_TAG_WORDS; wd++) {
+              uint32_t m = tagw[wd];
+              while (m) { int b = __ffs(m) - 1; m &= m - 1; w.put(f_tag, wd * 32 + b); }
+            }
+          } else {
+            const uint16_t* src = d.cls_tok + (cinfo & 0xFFFF);
+            for (int k = 0; k < ntags; k++) s_pool[w.pos++] = src[k];
+          }
+          if (!is_static) {
+            if (vibe != 0) w.put(f_vibe, vibe);
+#pragma unroll
+            for (int k = 0; k < MGX_MAX_ITEMS; k++) {  // observation_encoder.hpp:198-225: base digit, then :pK digits
+              if (live_mask & (1u << k)) {
+                const int item = (int)((ord >> (4 * k)) & 0xF);
+                VP F = feat + item * MGX_IF_WORDS;
+                uint32_t rem = amt[k];
+                w.put((uint32_t)F[0], B.lo(rem));
+                rem = B.hi(rem);
+                for (int pdig = 1; rem > 0; pdig++) { w.put((uint32_t)F[pdig], B.lo(rem)); rem = B.hi(rem); }
+              }
+            }
+            if (is_agent) {
+              w.put(f_group, (cinfo >> 16) & 0xFF);
+              w.put(f_agent, agent_id);
+            }
+          }
+          info = start | ((uint32_t)n << 16);
+        } else {
+          d.err[env] |= 16u;  // token pool exhausted (sized by the host from the program's per-object maximum)
+        }
+        s_visited[s] = vis;
       }
-      s_visited[s] = d.obj_visited[e.so(s)];
+      s_tokinfo[s] = info;
     }
-    s_tokinfo[s] = info;
   }
   if constexpr (X) {
     if (want_mask) {  // TerritoryTracker::compute_observability_at (:254-273): first territory with an owner decides
@@ -302,19 +365,19 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
         else if (dr < 0) put(d.feat[MGX_F_LP_SOUTH], (uint32_t)min(-dr, 255));
       }
       for (int i = 0; i < d.n_obs_values; i++) {  // _emit_obs_value_tokens :1207-1238
-        const int32_t* V = d.P + d.sec[MGX_SEC_OBS_VALUES] + i * MGX_OV_WORDS;
+        VP V = vp + d.sec[MGX_SEC_OBS_VALUES] + i * MGX_OV_WORDS;
         uint32_t rem;
         if constexpr (X) {
           rem = s_obsval[a * d.n_obs_values + i];
         } else {
           MgxCtx vc = mgx_ctx(my_slot, my_slot);
-          rem = (uint32_t)e.template eval_code<0>(V[MGX_OV_GV_START], V[MGX_OV_GV_COUNT], my_slot, vc, 0);
+          rem = (uint32_t)ev.template eval_code<0>(V[MGX_OV_GV_START], V[MGX_OV_GV_COUNT], my_slot, vc, 0);
         }
         int f = V[MGX_OV_FEATURE];
-        put(f, rem % (uint32_t)d.base);
-        rem /= (uint32_t)d.base;
+        put(f, B.lo(rem));
+        rem = B.hi(rem);
         f++;
-        while (rem > 0) { put(f, rem % (uint32_t)d.base); rem /= (uint32_t)d.base; f++; }
+        while (rem > 0) { put(f, B.lo(rem)); rem = B.hi(rem); f++; }
       }
       n_global = pos;
     }
@@ -366,10 +429,29 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
         if (mask[0]) { if (pos0 < T) s_row[pos0] = loc[0] | ((uint32_t)d.aoe_mask_feat << 8) | (mask[0] << 16); pos0++; n[0]--; }
         if (mask[1]) { if (pos1 < T) s_row[pos1] = loc[1] | ((uint32_t)d.aoe_mask_feat << 8) | (mask[1] << 16); pos1++; n[1]--; }
       }
-      for (int k = 0; k < n[0]; k++)
-        if (pos0 + k < T) s_row[pos0 + k] = loc[0] | ((uint32_t)s_pool[start[0] + k] << 8);
-      for (int k = 0; k < n[1]; k++)
-        if (pos1 + k < T) s_row[pos1 + k] = loc[1] | ((uint32_t)s_pool[start[1] + k] << 8);
+      // Token lists of up to MGX_SMALL_LIST entries (walls, plain objects) are copied by the cell's own lane; longer
+      // ones (agents carrying an inventory: the observer itself is always one) by the whole wavefront, one list at
+      // a time, so the copy loop's trip count is not set by the longest list in the window.
+#define MGX_SMALL_LIST 3
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const int ph = h ? pos1 : pos0;
+        const bool big = n[h] > MGX_SMALL_LIST;
+        const int ns = big ? 0 : n[h];
+#pragma unroll
+        for (int k = 0; k < MGX_SMALL_LIST; k++)
+          if (k < ns && ph + k < T) s_row[ph + k] = loc[h] | ((uint32_t)s_pool[start[h] + k] << 8);
+        unsigned long long bm = __ballot(big);
+        while (bm) {
+          const int l = __ffsll((long long)bm) - 1;
+          bm &= bm - 1;
+          const int bp = __builtin_amdgcn_readlane(ph, l), bs = __builtin_amdgcn_readlane(start[h], l);
+          const int bn = __builtin_amdgcn_readlane(n[h], l);
+          const uint32_t bl = (uint32_t)__builtin_amdgcn_readlane((int)loc[h], l);
+          for (int k = lane; k < bn; k += MGX_WAVE)
+            if (bp + k < T) s_row[bp + k] = bl | ((uint32_t)s_pool[bs + k] << 8);
+        }
+      }
       base_pos += (tot & 0xFFFF) + (tot >> 16);
       // cell.visited staleness, added in cell order exactly like the serial reference loop (:789-796)
 #pragma unroll
@@ -433,20 +515,23 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
     // X: query-backed values share one workspace per env -> one thread walks the agents in order
     for (int a = X ? (tid == 0 ? 0 : A) : tid; a < A; a += X ? 1 : MGX_OBS_THREADS) {  // RewardHelper::compute_entries (reward.hpp:56-77)
       const int slot = s_agents[a] & 0xFFFF;
-      const int32_t* C = e.cls_of(slot);
-      const int32_t* rw = d.P + d.sec[MGX_SEC_REWARDS] + C[MGX_C_REWARD_START] * MGX_RW_WORDS;
+      const uint32_t rwi = s_rwinfo[a];
+      const int nrw = (int)(rwi >> 16);
+      VP rw = vp + d.sec[MGX_SEC_REWARDS] + (int)(rwi & 0xFFFF) * MGX_RW_WORDS;
+      const float ep = d.episode_rewards[e.ao(a)];
       float total = 0.f;
-      for (int k = 0; k < C[MGX_C_REWARD_COUNT]; k++, rw += MGX_RW_WORDS) {
-        MgxCtx vc = mgx_ctx(slot, slot);
-        float val = e.template eval_code<Env::TOPQ>(rw[MGX_RW_GV_START], rw[MGX_RW_GV_COUNT], slot, vc, 0);
+      for (int k = 0; k < nrw; k++, rw += MGX_RW_WORDS) {
         float* prev = &d.ag_rprev[e.ao(a) * d.NRW + k];
+        const float pv = *prev;
+        MgxCtx vc = mgx_ctx(slot, slot);
+        float val = ev.template eval_code<Env::TOPQ>(rw[MGX_RW_GV_START], rw[MGX_RW_GV_COUNT], slot, vc, 0);
         if (rw[MGX_RW_ACCUMULATE]) total = __fadd_rn(total, val);
-        else total = __fadd_rn(total, __fsub_rn(val, *prev));
+        else total = __fadd_rn(total, __fsub_rn(val, pv));
         *prev = val;
       }
       float reward = total != 0.f ? total : 0.f;  // rewards were zeroed at the top of the step; += total
       d.rewards[e.ao(a)] = reward;
-      d.episode_rewards[e.ao(a)] = __fadd_rn(d.episode_rewards[e.ao(a)], reward);
+      d.episode_rewards[e.ao(a)] = __fadd_rn(ep, reward);
       if (d.max_steps > 0 && step >= (uint32_t)d.max_steps) {  // mettagrid_c.cpp:1086-1096
         if (d.truncates) d.truncations[e.ao(a)] = 1;
         else d.terminals[e.ao(a)] = 1;

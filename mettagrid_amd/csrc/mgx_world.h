@@ -84,6 +84,15 @@ __device__ __forceinline__ unsigned long long mgx_floor_sqrt(unsigned long long 
   return r;
 }
 
+// Evaluation stack of the game-value postfix code: eight f32 held in registers, top of stack in s0.  The compiler
+// bounds expression depth at 8 (compile_spec), like the array this replaces.
+struct MgxValueStack {
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f, s5 = 0.f, s6 = 0.f, s7 = 0.f;
+  int n = 0;
+  __device__ __forceinline__ void push(float v) { s7 = s6; s6 = s5; s5 = s4; s4 = s3; s3 = s2; s2 = s1; s1 = s0; s0 = v; n++; }
+  __device__ __forceinline__ float pop() { float v = s0; s0 = s1; s1 = s2; s2 = s3; s3 = s4; s4 = s5; s5 = s6; s6 = s7; n--; return v; }
+};
+
 template <class PP, bool X>
 struct MgxEnvT {  // per-lane view of one env
   const MgxDev& d;
@@ -431,32 +440,31 @@ struct MgxEnvT {  // per-lane view of one env
   // ---- game values (cpp/src/mettagrid/core/game_value.cpp:14-148): postfix code on a small f32 stack ----
   template <int QD>
   __device__ float eval_code(int start, int count, int entity, const MgxCtx& outer, int depth) const {
-    float st[8];
-    int sp = 0;
+    MgxValueStack st;  // registers, not a dynamically indexed array (which the compiler would place in scratch)
     PP code = P + d.sec[MGX_SEC_GV_CODE] + start * MGX_GV_WORDS;
     for (int i = 0; i < count; i++, code += MGX_GV_WORDS) {
       int a0 = code[MGX_GV_A0], a1 = code[MGX_GV_A1], a2 = code[MGX_GV_A2];
       switch (code[MGX_GV_OP]) {
-        case MGX_GOP_INVENTORY: st[sp++ & 7] = entity >= 0 ? (float)inv(entity, a0) : 0.f; break;
+        case MGX_GOP_INVENTORY: st.push(entity >= 0 ? (float)inv(entity, a0) : 0.f); break;
         case MGX_GOP_STAT: {
           float v = 0.f;
           if (a0 == 1) { gstat_touch(a1); v = d.game_stats[(size_t)env * d.NG + a1]; }
           else { int a = agent_of(entity); if (a >= 0) { astat_touch(a, a1); v = astat_get(a, a1); } }
-          st[sp++ & 7] = v;
+          st.push(v);
           break;
         }
-        case MGX_GOP_CONST: st[sp++ & 7] = __int_as_float(a0); break;
+        case MGX_GOP_CONST: st.push(__int_as_float(a0)); break;
         case MGX_GOP_ADD_TERM: {
-          float t = st[--sp & 7];
+          float t = st.pop();
           if (a0) t = mgx_logf(__fadd_rn(t, 1.0f));
           if (a1) t = __fmul_rn(t, __int_as_float(a2));
-          float acc = st[--sp & 7];
-          st[sp++ & 7] = __fadd_rn(acc, t);
+          float acc = st.pop();
+          st.push(__fadd_rn(acc, t));
           break;
         }
-        case MGX_GOP_RATIO: { float den = st[--sp & 7], num = st[--sp & 7]; st[sp++ & 7] = den > 0.f ? __fdiv_rn(num, den) : num; break; }
-        case MGX_GOP_MAX2: { float v = st[--sp & 7], b = st[--sp & 7]; st[sp++ & 7] = (b < v) ? v : b; break; }
-        case MGX_GOP_MIN2: { float v = st[--sp & 7], b = st[--sp & 7]; st[sp++ & 7] = (v < b) ? v : b; break; }
+        case MGX_GOP_RATIO: { float den = st.pop(), num = st.pop(); st.push(den > 0.f ? __fdiv_rn(num, den) : num); break; }
+        case MGX_GOP_MAX2: { float v = st.pop(), b = st.pop(); st.push((b < v) ? v : b); break; }
+        case MGX_GOP_MIN2: { float v = st.pop(), b = st.pop(); st.push((v < b) ? v : b); break; }
         case MGX_GOP_QUERY_INVENTORY: {  // game_value.cpp:45-57 (captured ctx: actor = the value's entity)
           float total = 0.f;
           if constexpr (X && QD > 0) {
@@ -468,7 +476,7 @@ struct MgxEnvT {  // per-lane view of one env
           } else {
             flag(4u);
           }
-          st[sp++ & 7] = total;
+          st.push(total);
           break;
         }
         case MGX_GOP_QUERY_COUNT: {
@@ -480,12 +488,12 @@ struct MgxEnvT {  // per-lane view of one env
           } else {
             flag(4u);
           }
-          st[sp++ & 7] = cnt;
+          st.push(cnt);
           break;
         }
       }
     }
-    return sp > 0 ? st[(sp - 1) & 7] : 0.f;
+    return st.n > 0 ? st.s0 : 0.f;
   }
   template <int QD>
   __device__ float eval_value(int rec, int entity, const MgxCtx& c, int depth) const {
