@@ -53,6 +53,7 @@ struct mgx_engine {
   bool prog_in_lds = false;
   int obs_blk_start = 0, obs_blk_words = 0;  // program block the observation kernel interprets
   bool obs_blk_lds = false;
+  bool rewards_early = false;  // reward expressions have no stat operands: evaluated beside the token-cache phase
   int world_lpw = MGX_WAVE;  // envs per wavefront of the world kernel (64, 32, 16 or 8)
   int world_wpe = 0;         // 4: the 128-VGPR build of the non-extended world kernel
   uint16_t* dmaps = nullptr;
@@ -93,9 +94,9 @@ static void launch_obs_t(mgx_engine* e, bool with_rewards, const uint8_t* mask) 
   if (PL)  // the interpreted sections are addressed relative to their LDS copy
     for (int k = MGX_SEC_INV_FEATURES; k < MGX_SEC_WORDLIST; k++) dd.sec[k] -= e->obs_blk_start;
   if (with_rewards)
-    hipLaunchKernelGGL((mgx_obs_kernel<true, X, PL>), grid, block, e->lds_obs, e->stream, dd, e->pool_tokens, mask, e->obs_blk_start, e->obs_blk_words);
+    hipLaunchKernelGGL((mgx_obs_kernel<true, X, PL>), grid, block, e->lds_obs, e->stream, dd, e->pool_tokens, mask, e->obs_blk_start, e->obs_blk_words, (int)e->rewards_early);
   else
-    hipLaunchKernelGGL((mgx_obs_kernel<false, X, PL>), grid, block, e->lds_obs, e->stream, dd, e->pool_tokens, mask, e->obs_blk_start, e->obs_blk_words);
+    hipLaunchKernelGGL((mgx_obs_kernel<false, X, PL>), grid, block, e->lds_obs, e->stream, dd, e->pool_tokens, mask, e->obs_blk_start, e->obs_blk_words, (int)e->rewards_early);
 }
 static int launch_obs(mgx_engine* e, bool with_rewards, const uint8_t* mask = nullptr) {
   if (e->d.X) launch_obs_t<true, false>(e, with_rewards, mask);
@@ -346,8 +347,21 @@ int mgx_create(const int32_t* program, size_t program_words, const uint16_t* cla
     e->obs_blk_words = b1 - b0;
     e->obs_blk_lds = !d.X && ordered && (b0 & 3) == 0 && (e->obs_blk_words & 3) == 0 && e->obs_blk_words * 4 <= 8 * 1024;
   }
+  {  // reward code made only of inventory / constant arithmetic reads nothing the observation kernel writes
+    bool pure = !d.X;
+    const int32_t* rw = P + d.sec[MGX_SEC_REWARDS];
+    const int n_rw = P[MGX_H_SECTION_BASE + 2 * MGX_SEC_REWARDS + 1];
+    for (int k = 0; k < n_rw && pure; k++) {
+      const int32_t* code = P + d.sec[MGX_SEC_GV_CODE] + rw[k * MGX_RW_WORDS + MGX_RW_GV_START] * MGX_GV_WORDS;
+      for (int i = 0; i < rw[k * MGX_RW_WORDS + MGX_RW_GV_COUNT]; i++) {
+        const int op = code[i * MGX_GV_WORDS + MGX_GV_OP];
+        if (op == MGX_GOP_STAT || op == MGX_GOP_QUERY_INVENTORY || op == MGX_GOP_QUERY_COUNT) pure = false;
+      }
+    }
+    e->rewards_early = pure;
+  }
   e->lds_obs = (size_t)mgx_obs_lds_layout((int)HW, d.NOFF, (int)S, (int)A, d.T, e->pool_tokens, d.X != 0, d.n_obs_values,
-                                          e->obs_blk_lds ? e->obs_blk_words : 0).total;
+                                          e->obs_blk_lds ? e->obs_blk_words : 0, mgx_obs_gt(d.n_obs_values, d.base)).total;
   if (e->lds_obs > 160 * 1024 || e->lds_world > 64 * 1024) {
     mgx_destroy(e);
     return fail(MGX_ERR_PROGRAM, "mgx_create: map/object count too large for the LDS staging of the observation kernel");

@@ -20,6 +20,11 @@
 #include "mgx_world.h"
 
 #define MGX_OBS_THREADS 256
+#ifdef MGX_OBS_STOP  // profiling builds only: leave the kernel after phase k to attribute its time (scripts/obs_phases.sh)
+#define MGX_PHASE_END(k) do { if (MGX_OBS_STOP == (k)) return; } while (0)
+#else
+#define MGX_PHASE_END(k)
+#endif
 #define MGX_OBS_WAVES (MGX_OBS_THREADS / MGX_WAVE)
 
 // Wavefront inclusive scan with DPP row shifts / row broadcasts (no LDS traffic): Hillis-Steele inside each 16-lane
@@ -75,14 +80,21 @@ struct MgxBase {
 //   grid u16[HW] | offsets i8x2[NOFF] | minobs u32[S] | visited u32[S] | tokinfo u32[S] (start | count << 16) |
 //   agents u32[A] (slot | rc << 16) | aginfo u32[A] (executed | moved << 8) | spawn u16[A] | vstat f32[A] |
 //   written i32[A] | rwinfo u32[A] (reward start | count << 16) | misc u32[4] | pool u16[POOL] | rows u32[WAVES][Tpad] |
-//   blk i32[blk_words]: program sections INV_FEATURES..OBS_VALUES (PL variants only)
+//   blk i32[blk_words]: program sections INV_FEATURES..OBS_VALUES (PL variants only) | gtok u32[A][GT] global tokens
 __host__ __device__ inline int mgx_align16(int x) { return (x + 15) & ~15; }
 struct MgxObsLds {
-  int grid, offs, minobs, visited, tokinfo, agents, aginfo, spawn, vstat, written, rwinfo, misc, pool, rows, row_words, blk, total;
+  int grid, offs, minobs, visited, tokinfo, agents, aginfo, spawn, vstat, written, rwinfo, misc, pool, rows, row_words, blk, gtok, total;
   int owner, obsval, tscore;  // X only: per-cell territory owner u16[HW], obs values u32[A][NOV], scores i64[8][256]
 };
+// Upper bound of the global (location 0xFE) tokens of one agent: completion, last action, last action move, last
+// reward, two local-position tokens and every digit of every obs value (a u32 has at most 32 digits in base 2).
+__host__ __device__ inline int mgx_obs_gt(int NOV, int base) {
+  int digits = 1;
+  for (unsigned long long v = 0xFFFFFFFFull / (unsigned)base; v > 0; v /= (unsigned)base) digits++;
+  return 6 + NOV * digits;
+}
 __host__ __device__ inline MgxObsLds mgx_obs_lds_layout(int HW, int NOFF, int S, int A, int T, int pool_tokens,
-                                                        bool X = false, int NOV = 0, int blk_words = 0) {
+                                                        bool X = false, int NOV = 0, int blk_words = 0, int GT = 6) {
   MgxObsLds l;
   int o = 0;
   l.grid = o; o += mgx_align16(HW * 2);
@@ -107,6 +119,7 @@ __host__ __device__ inline MgxObsLds mgx_obs_lds_layout(int HW, int NOFF, int S,
     l.tscore = o; o += 8 * MGX_OBS_THREADS * 8;
   }
   l.blk = o; o += mgx_align16(blk_words * 4);
+  l.gtok = o; o += mgx_align16(A * GT * 4);
   l.total = o;
   return l;
 }
@@ -119,13 +132,14 @@ __host__ __device__ inline MgxObsLds mgx_obs_lds_layout(int HW, int NOFF, int S,
 // out-of-object pointer arithmetic on an LDS address).
 template <bool WITH_REWARDS, bool X, bool PL>
 __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int pool_tokens, const uint8_t* env_mask,
-                                                                  int blk_start, int blk_words) {
+                                                                  int blk_start, int blk_words, int rewards_early) {
   extern __shared__ __align__(16) uint8_t smem[];
   const int env = blockIdx.x;
   if (env_mask && !env_mask[env]) return;  // episode restart: only the restarted envs get initial observations
   const int tid = threadIdx.x, lane = tid & (MGX_WAVE - 1), wave = tid / MGX_WAVE;
   const int HW = d.H * d.W, A = d.A, S = d.S, T = d.T, NOFF = d.NOFF;
-  const MgxObsLds L = mgx_obs_lds_layout(HW, NOFF, S, A, T, pool_tokens, X, d.n_obs_values, PL ? blk_words : 0);
+  const int GT = mgx_obs_gt(d.n_obs_values, d.base);
+  const MgxObsLds L = mgx_obs_lds_layout(HW, NOFF, S, A, T, pool_tokens, X, d.n_obs_values, PL ? blk_words : 0, GT);
   uint16_t* s_grid = (uint16_t*)(smem + L.grid);
   char2* s_offs = (char2*)(smem + L.offs);
   uint32_t* s_minobs = (uint32_t*)(smem + L.minobs);
@@ -140,6 +154,7 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
   uint32_t* s_misc = (uint32_t*)(smem + L.misc);
   uint16_t* s_pool = (uint16_t*)(smem + L.pool);
   uint32_t* s_row = (uint32_t*)(smem + L.rows) + wave * L.row_words;  // one u32 per token: loc | f << 8 | v << 16
+  uint32_t* s_gtok = (uint32_t*)(smem + L.gtok);
 
   typedef MgxEnvT<MgxGlobalProg, X> Env;
   Env e(d, d.P, env);
@@ -163,6 +178,32 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
   ev.step = step;
   ev.xl = e.xl;
   const MgxBase B((uint32_t)d.base);
+
+  // RewardHelper::compute_entries (reward.hpp:56-77) + truncation/termination (mettagrid_c.cpp:1086-1096) of one agent
+  auto agent_rewards = [&](int a) {
+    const int slot = s_agents[a] & 0xFFFF;
+    const uint32_t rwi = s_rwinfo[a];
+    const int nrw = (int)(rwi >> 16);
+    VP rw = vp + d.sec[MGX_SEC_REWARDS] + (int)(rwi & 0xFFFF) * MGX_RW_WORDS;
+    const float ep = d.episode_rewards[e.ao(a)];
+    float total = 0.f;
+    for (int k = 0; k < nrw; k++, rw += MGX_RW_WORDS) {
+      float* prev = &d.ag_rprev[e.ao(a) * d.NRW + k];
+      const float pv = *prev;
+      MgxCtx vc = mgx_ctx(slot, slot);
+      float val = ev.template eval_code<Env::TOPQ>(rw[MGX_RW_GV_START], rw[MGX_RW_GV_COUNT], slot, vc, 0);
+      if (rw[MGX_RW_ACCUMULATE]) total = __fadd_rn(total, val);
+      else total = __fadd_rn(total, __fsub_rn(val, pv));
+      *prev = val;
+    }
+    float reward = total != 0.f ? total : 0.f;  // rewards were zeroed at the top of the step; += total
+    d.rewards[e.ao(a)] = reward;
+    d.episode_rewards[e.ao(a)] = __fadd_rn(ep, reward);
+    if (d.max_steps > 0 && step >= (uint32_t)d.max_steps) {
+      if (d.truncates) d.truncations[e.ao(a)] = 1;
+      else d.terminals[e.ao(a)] = 1;
+    }
+  };
 
   MGX_TICK0();
   // ---- phase 0: stage the env (coalesced) and build the per-object token cache ----
@@ -197,6 +238,7 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
   }
   __syncthreads();
   MGX_TICK(8);
+  MGX_PHASE_END(1);
   {
     const int f_vibe = d.feat[MGX_F_VIBE], f_group = d.feat[MGX_F_GROUP], f_agent = d.feat[MGX_F_AGENT_ID], f_tag = d.feat[MGX_F_TAG];
     VP feat = vp + d.sec[MGX_SEC_INV_FEATURES];
@@ -286,6 +328,10 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
       s_tokinfo[s] = info;
     }
   }
+  // Rewards that read nothing this kernel writes (no stat operands; host flag) are evaluated here by the last
+  // wavefront, which has little or no token-cache work, instead of serially at the end of the workgroup.
+  if (WITH_REWARDS && rewards_early && wave == MGX_OBS_WAVES - 1)
+    for (int a = lane; a < A; a += MGX_WAVE) agent_rewards(a);
   if constexpr (X) {
     if (want_mask) {  // TerritoryTracker::compute_observability_at (:254-273): first territory with an owner decides
       for (int cellidx = tid; cellidx < HW; cellidx += MGX_OBS_THREADS) {
@@ -307,10 +353,57 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
   }
   __syncthreads();
   MGX_TICK(9);
+  MGX_PHASE_END(2);
 
   const int hr = d.feat[14], wr = d.feat[15];  // obs_height >> 1, obs_width >> 1 (stored by the host)
   const int NPASS = (NOFF + 2 * MGX_WAVE - 1) / (2 * MGX_WAVE);  // two window cells per lane and pass
 
+  // global tokens (location 0xFE), mettagrid_c.cpp:700-753: one thread per agent, all agents at once
+  if (tid < A) {
+    const int a = tid;
+    const uint32_t ag = s_agents[a];
+    const int my_slot = ag & 0xFFFF;
+    const int r0 = (ag >> 24) & 0xFF, c0 = (ag >> 16) & 0xFF;
+    uint32_t* g = s_gtok + a * GT;
+    int pos = 0;
+    auto put = [&](int f, uint32_t v) { g[pos++] = 0xFEu | ((uint32_t)(f & 0xFF) << 8) | ((v & 0xFF) << 16); };
+    const uint32_t info = s_aginfo[a];
+    if (d.flags & MGX_G_COMPLETION) {
+      uint32_t pct = 0;
+      if (d.max_steps > 0) pct = step >= (uint32_t)d.max_steps ? 255u : (256u * step / (uint32_t)d.max_steps);
+      put(d.feat[MGX_F_COMPLETION], pct);
+    }
+    if (d.flags & MGX_G_LAST_ACTION) put(d.feat[MGX_F_LAST_ACTION], info & 0xFF);
+    if ((d.flags & MGX_G_LAST_ACTION_MOVE) && d.feat[MGX_F_LAST_ACTION_MOVE] != 0)
+      put(d.feat[MGX_F_LAST_ACTION_MOVE], (info >> 8) & 1);
+    // last_reward: the reference reads the reward buffer it zeroed at the top of the step (:937-938,722-726),
+    // so the token is always round(0 * 100) = 0.
+    if (d.flags & MGX_G_LAST_REWARD) put(d.feat[MGX_F_LAST_REWARD], 0);
+    if (d.flags & MGX_G_LOCAL_POSITION) {
+      uint16_t sp = s_spawn[a];
+      int dc = c0 - (int)(sp & 0xFF), dr = (int)(sp >> 8) - r0;
+      if (dc > 0) put(d.feat[MGX_F_LP_EAST], (uint32_t)min(dc, 255));
+      else if (dc < 0) put(d.feat[MGX_F_LP_WEST], (uint32_t)min(-dc, 255));
+      if (dr > 0) put(d.feat[MGX_F_LP_NORTH], (uint32_t)min(dr, 255));
+      else if (dr < 0) put(d.feat[MGX_F_LP_SOUTH], (uint32_t)min(-dr, 255));
+    }
+    for (int i = 0; i < d.n_obs_values; i++) {  // _emit_obs_value_tokens :1207-1238
+      VP V = vp + d.sec[MGX_SEC_OBS_VALUES] + i * MGX_OV_WORDS;
+      uint32_t rem;
+      if constexpr (X) {
+        rem = s_obsval[a * d.n_obs_values + i];
+      } else {
+        MgxCtx vc = mgx_ctx(my_slot, my_slot);
+        rem = (uint32_t)ev.template eval_code<0>(V[MGX_OV_GV_START], V[MGX_OV_GV_COUNT], my_slot, vc, 0);
+      }
+      int f = V[MGX_OV_FEATURE];
+      put(f, B.lo(rem));
+      rem = B.hi(rem);
+      f++;
+      while (rem > 0) { put(f, B.lo(rem)); rem = B.hi(rem); f++; }
+    }
+    s_aginfo[a] = (uint32_t)pos;  // from here on: the agent's global token count
+  }
   // ---- phase 1: first observer (lowest agent index) of every visible object ----
   if (step > 0) {
     for (int a = wave; a < A; a += MGX_OBS_WAVES) {
@@ -328,6 +421,7 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
   }
   __syncthreads();
   MGX_TICK(10);
+  MGX_PHASE_END(3);
 
   // ---- phase 2: encode ----
   for (int a = wave; a < A; a += MGX_OBS_WAVES) {
@@ -336,52 +430,10 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
     const int r0 = (ag >> 24) & 0xFF, c0 = (ag >> 16) & 0xFF;
     for (int i = lane; i < L.row_words / 4; i += MGX_WAVE) ((uint4*)s_row)[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
 
-    // global tokens (location 0xFE), mettagrid_c.cpp:700-753 — a handful, written by lane 0
-    int n_global = 0;
-    if (lane == 0) {
-      int pos = 0;
-      auto put = [&](int f, uint32_t v) {
-        if (pos < T) s_row[pos] = 0xFEu | ((uint32_t)(f & 0xFF) << 8) | ((v & 0xFF) << 16);
-        pos++;
-      };
-      const uint32_t info = s_aginfo[a];
-      if (d.flags & MGX_G_COMPLETION) {
-        uint32_t pct = 0;
-        if (d.max_steps > 0) pct = step >= (uint32_t)d.max_steps ? 255u : (256u * step / (uint32_t)d.max_steps);
-        put(d.feat[MGX_F_COMPLETION], pct);
-      }
-      if (d.flags & MGX_G_LAST_ACTION) put(d.feat[MGX_F_LAST_ACTION], info & 0xFF);
-      if ((d.flags & MGX_G_LAST_ACTION_MOVE) && d.feat[MGX_F_LAST_ACTION_MOVE] != 0)
-        put(d.feat[MGX_F_LAST_ACTION_MOVE], (info >> 8) & 1);
-      // last_reward: the reference reads the reward buffer it zeroed at the top of the step (:937-938,722-726),
-      // so the token is always round(0 * 100) = 0.
-      if (d.flags & MGX_G_LAST_REWARD) put(d.feat[MGX_F_LAST_REWARD], 0);
-      if (d.flags & MGX_G_LOCAL_POSITION) {
-        uint16_t sp = s_spawn[a];
-        int dc = c0 - (int)(sp & 0xFF), dr = (int)(sp >> 8) - r0;
-        if (dc > 0) put(d.feat[MGX_F_LP_EAST], (uint32_t)min(dc, 255));
-        else if (dc < 0) put(d.feat[MGX_F_LP_WEST], (uint32_t)min(-dc, 255));
-        if (dr > 0) put(d.feat[MGX_F_LP_NORTH], (uint32_t)min(dr, 255));
-        else if (dr < 0) put(d.feat[MGX_F_LP_SOUTH], (uint32_t)min(-dr, 255));
-      }
-      for (int i = 0; i < d.n_obs_values; i++) {  // _emit_obs_value_tokens :1207-1238
-        VP V = vp + d.sec[MGX_SEC_OBS_VALUES] + i * MGX_OV_WORDS;
-        uint32_t rem;
-        if constexpr (X) {
-          rem = s_obsval[a * d.n_obs_values + i];
-        } else {
-          MgxCtx vc = mgx_ctx(my_slot, my_slot);
-          rem = (uint32_t)ev.template eval_code<0>(V[MGX_OV_GV_START], V[MGX_OV_GV_COUNT], my_slot, vc, 0);
-        }
-        int f = V[MGX_OV_FEATURE];
-        put(f, B.lo(rem));
-        rem = B.hi(rem);
-        f++;
-        while (rem > 0) { put(f, B.lo(rem)); rem = B.hi(rem); f++; }
-      }
-      n_global = pos;
-    }
-    int base_pos = __shfl(n_global, 0);
+    // global tokens (location 0xFE) were assembled once per env in phase 1; copy this agent's
+    const int n_global = (int)s_aginfo[a];
+    for (int k = lane; k < n_global && k < T; k += MGX_WAVE) s_row[k] = s_gtok[a * GT + k];
+    int base_pos = n_global;
 
     // window cells in reference order: lane handles cells j and j + 64 of each 128-cell pass; everything is LDS
     float visited_acc = s_vstat[a];
@@ -490,6 +542,7 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
   MGX_TICK(11);
   __syncthreads();
   MGX_TICK(12);
+  MGX_PHASE_END(4);
 
   // ---- visited stamps, token statistics, rewards, termination ----
   if (step > 0)
@@ -510,33 +563,10 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
     if (overflow) d.err[env] |= 1u;
   }
   MGX_TICK(13);
-  if (WITH_REWARDS) {
+  if (WITH_REWARDS && !rewards_early) {
     if constexpr (X) __syncthreads();  // cell.visited stats of all waves are in before value expressions read them
     // X: query-backed values share one workspace per env -> one thread walks the agents in order
-    for (int a = X ? (tid == 0 ? 0 : A) : tid; a < A; a += X ? 1 : MGX_OBS_THREADS) {  // RewardHelper::compute_entries (reward.hpp:56-77)
-      const int slot = s_agents[a] & 0xFFFF;
-      const uint32_t rwi = s_rwinfo[a];
-      const int nrw = (int)(rwi >> 16);
-      VP rw = vp + d.sec[MGX_SEC_REWARDS] + (int)(rwi & 0xFFFF) * MGX_RW_WORDS;
-      const float ep = d.episode_rewards[e.ao(a)];
-      float total = 0.f;
-      for (int k = 0; k < nrw; k++, rw += MGX_RW_WORDS) {
-        float* prev = &d.ag_rprev[e.ao(a) * d.NRW + k];
-        const float pv = *prev;
-        MgxCtx vc = mgx_ctx(slot, slot);
-        float val = ev.template eval_code<Env::TOPQ>(rw[MGX_RW_GV_START], rw[MGX_RW_GV_COUNT], slot, vc, 0);
-        if (rw[MGX_RW_ACCUMULATE]) total = __fadd_rn(total, val);
-        else total = __fadd_rn(total, __fsub_rn(val, pv));
-        *prev = val;
-      }
-      float reward = total != 0.f ? total : 0.f;  // rewards were zeroed at the top of the step; += total
-      d.rewards[e.ao(a)] = reward;
-      d.episode_rewards[e.ao(a)] = __fadd_rn(ep, reward);
-      if (d.max_steps > 0 && step >= (uint32_t)d.max_steps) {  // mettagrid_c.cpp:1086-1096
-        if (d.truncates) d.truncations[e.ao(a)] = 1;
-        else d.terminals[e.ao(a)] = 1;
-      }
-    }
+    for (int a = X ? (tid == 0 ? 0 : A) : tid; a < A; a += X ? 1 : MGX_OBS_THREADS) agent_rewards(a);
   }
   MGX_TICK(14);
 }

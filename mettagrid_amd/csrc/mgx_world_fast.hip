@@ -14,22 +14,11 @@ template <bool PROG_LDS>
 __global__ void __launch_bounds__(MGX_WORLD_MAX_THREADS) mgx_world_kernel_fast(MgxDev d, int prog_words, int lpw) {
   mgx_world_entry<PROG_LDS, false>(d, prog_words, lpw);
 }
-// Same code under a 128-VGPR budget: 4 wavefronts per SIMD resident instead of 2.
-template <bool PROG_LDS>
-__global__ void __launch_bounds__(MGX_WORLD_MAX_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
-mgx_world_kernel_fast_w4(MgxDev d, int prog_words, int lpw) {
-  mgx_world_entry<PROG_LDS, false>(d, prog_words, lpw);
-}
-
 void mgx_launch_world_fast(bool prog_lds, int wpe, int lpw, size_t lds, hipStream_t stream, const MgxDev& d, int prog_words) {
   dim3 grid((d.E + MGX_WAVE - 1) / MGX_WAVE), block(MGX_WAVE * (MGX_WAVE / lpw));
-  if (wpe >= 4) {
-    if (prog_lds) hipLaunchKernelGGL((mgx_world_kernel_fast_w4<true>), grid, block, lds, stream, d, prog_words, lpw);
-    else hipLaunchKernelGGL((mgx_world_kernel_fast_w4<false>), grid, block, lds, stream, d, prog_words, lpw);
-  } else {
-    if (prog_lds) hipLaunchKernelGGL((mgx_world_kernel_fast<true>), grid, block, lds, stream, d, prog_words, lpw);
-    else hipLaunchKernelGGL((mgx_world_kernel_fast<false>), grid, block, lds, stream, d, prog_words, lpw);
-  }
+  (void)wpe;
+  if (prog_lds) hipLaunchKernelGGL((mgx_world_kernel_fast<true>), grid, block, lds, stream, d, prog_words, lpw);
+  else hipLaunchKernelGGL((mgx_world_kernel_fast<false>), grid, block, lds, stream, d, prog_words, lpw);
 }
 
 #ifdef MGX_WORLD_TIMING
