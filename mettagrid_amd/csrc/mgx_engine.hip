@@ -49,10 +49,30 @@ struct mgx_engine {
   int32_t *h_act = nullptr, *h_vact = nullptr;
   bool external = false;
   size_t lds_world = 0, lds_obs = 0;
-  int pool_tokens = 0;
+  int pool_tokens = 0;   // capacity of the LDS token pool (entries), including the class-tag prefix
+  int pool_prefix = 0;   // entries of the per-class static tag table at the head of the pool
   bool prog_in_lds = false;
   int obs_blk_start = 0, obs_blk_words = 0;  // program block the observation kernel interprets
   bool obs_blk_lds = false;
+  std::vector<int> class_list_tokens;  // worst-case per-step token list length per class (0: static class)
+  bool pool_from_maps = false;         // pool sized from the class maps (no run-time object creation / tag changes)
+  // max over the selected envs of the summed worst-case list lengths of the objects on their class maps
+  long long list_tokens_bound(const uint16_t* class_maps, size_t first, size_t count, const uint8_t* mask) const {
+    const size_t hw = (size_t)d.H * d.W;
+    const int nc = (int)class_list_tokens.size();
+    long long best = 0;
+    for (size_t env = first; env < first + count; env++) {
+      if (mask && !mask[env]) continue;
+      const uint16_t* cm = class_maps + env * hw;
+      long long t = 0;
+      for (size_t i = 0; i < hw; i++) {
+        const int k = cm[i];
+        if (k > 0 && k <= nc) t += class_list_tokens[k - 1];
+      }
+      best = std::max(best, t);
+    }
+    return best;
+  }
   bool rewards_early = false;  // reward expressions have no stat operands: evaluated beside the token-cache phase
   int world_lpw = MGX_WAVE;  // envs per wavefront of the world kernel (64, 32, 16 or 8)
   int world_wpe = 0;         // 4: the 128-VGPR build of the non-extended world kernel
@@ -87,6 +107,21 @@ struct mgx_engine {
   }
 };
 
+// Dynamic LDS of the observation kernel for the current pool capacity (mgx_create; mgx_reset_envs when new maps need
+// a larger pool).
+static int size_obs_lds(mgx_engine* e) {
+  const MgxDev& d = e->d;
+  e->lds_obs = (size_t)mgx_obs_lds_layout(d.H * d.W, d.NOFF, d.S, d.A, d.T, e->pool_tokens, d.X != 0, d.n_obs_values,
+                                          e->obs_blk_lds ? e->obs_blk_words : 0, mgx_obs_gt(d.n_obs_values, d.base)).total;
+  if (e->lds_obs > 160 * 1024)
+    return fail(MGX_ERR_PROGRAM, "map/object count too large for the LDS staging of the observation kernel");
+  const void* fns[] = {(const void*)mgx_obs_kernel<true, false, false>, (const void*)mgx_obs_kernel<false, false, false>,
+                       (const void*)mgx_obs_kernel<true, false, true>,  (const void*)mgx_obs_kernel<false, false, true>,
+                       (const void*)mgx_obs_kernel<true, true, false>,  (const void*)mgx_obs_kernel<false, true, false>};
+  for (const void* f : fns) HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_obs));
+  return MGX_OK;
+}
+
 template <bool X, bool PL>
 static void launch_obs_t(mgx_engine* e, bool with_rewards, const uint8_t* mask) {
   dim3 grid(e->d.E), block(MGX_OBS_THREADS);
@@ -94,9 +129,9 @@ static void launch_obs_t(mgx_engine* e, bool with_rewards, const uint8_t* mask) 
   if (PL)  // the interpreted sections are addressed relative to their LDS copy
     for (int k = MGX_SEC_INV_FEATURES; k < MGX_SEC_WORDLIST; k++) dd.sec[k] -= e->obs_blk_start;
   if (with_rewards)
-    hipLaunchKernelGGL((mgx_obs_kernel<true, X, PL>), grid, block, e->lds_obs, e->stream, dd, e->pool_tokens, mask, e->obs_blk_start, e->obs_blk_words, (int)e->rewards_early);
+    hipLaunchKernelGGL((mgx_obs_kernel<true, X, PL>), grid, block, e->lds_obs, e->stream, dd, e->pool_tokens, e->pool_prefix, mask, e->obs_blk_start, e->obs_blk_words, (int)e->rewards_early);
   else
-    hipLaunchKernelGGL((mgx_obs_kernel<false, X, PL>), grid, block, e->lds_obs, e->stream, dd, e->pool_tokens, mask, e->obs_blk_start, e->obs_blk_words, (int)e->rewards_early);
+    hipLaunchKernelGGL((mgx_obs_kernel<false, X, PL>), grid, block, e->lds_obs, e->stream, dd, e->pool_tokens, e->pool_prefix, mask, e->obs_blk_start, e->obs_blk_words, (int)e->rewards_early);
 }
 static int launch_obs(mgx_engine* e, bool with_rewards, const uint8_t* mask = nullptr) {
   if (e->d.X) launch_obs_t<true, false>(e, with_rewards, mask);
@@ -297,22 +332,6 @@ int mgx_create(const int32_t* program, size_t program_words, const uint16_t* cla
   if (getenv("MGX_VERBOSE"))
     fprintf(stderr, "[mgx] E=%d A=%d S=%d program=%zu B world: X=%d prog_in_lds=%d lds=%zu B lpw=%d\n", d.E, d.A, d.S,
             program_words * 4, d.X, (int)e->prog_in_lds, e->lds_world, e->world_lpw);
-  {  // LDS token pool: every object of an env caches its (feature, value) list once per step.  Upper bound per
-     // object from the program: tags + vibe + R * digits + 2; capped so that several workgroups fit one CU.
-    int digits = 1;
-    for (unsigned v = 65535u / (unsigned)d.base; v > 0; v /= (unsigned)d.base) digits++;
-    int max_per_obj = 1;
-    for (int c = 0; c < P[MGX_H_NUM_CLASSES]; c++) {
-      const int32_t* C = P + d.sec[MGX_SEC_CLASSES] + c * MGX_C_WORDS;
-      int n = 0;
-      for (int w = 0; w < MGX_TAG_WORDS; w++) n += __builtin_popcount((unsigned)C[MGX_C_TAGS + w]);
-      if (!C[MGX_C_STATIC]) n += 1 + P[MGX_H_NUM_RESOURCES] * digits + (C[MGX_C_KIND] == MGX_KIND_AGENT ? 2 : 0);
-      max_per_obj = std::max(max_per_obj, n);
-    }
-    long long bound = (long long)S * max_per_obj;
-    e->pool_tokens = (int)std::min<long long>(bound, 16384);
-    e->pool_tokens = (e->pool_tokens + 7) & ~7;
-  }
   {  // per-class static tag tokens (ascending tag id, core/grid_object.cpp:181-186)
     std::vector<uint32_t> info(P[MGX_H_NUM_CLASSES]);
     std::vector<uint16_t> toks;
@@ -338,6 +357,27 @@ int mgx_create(const int32_t* program, size_t program_words, const uint16_t* cla
     if (ce != hipSuccess) { mgx_destroy(e); return fail(MGX_ERR_HIP, std::string("class token upload: ") + hipGetErrorString(ce)); }
     d.cls_tokinfo = dinfo;
     d.cls_tok = dtoks;
+    e->pool_prefix = (int)toks.size();
+  }
+  {  // LDS token pool = class-tag prefix + room for the per-step lists (objects of non-static classes).  Worst case
+     // per class from the program: tags + vibe + R * digits + 2.  Without run-time object creation the class maps
+     // bound it exactly (sum over the env's objects, max over envs); otherwise one worst-case list per slot.
+    int digits = 1;
+    for (unsigned v = 65535u / (unsigned)d.base; v > 0; v /= (unsigned)d.base) digits++;
+    const int nc = P[MGX_H_NUM_CLASSES];
+    e->class_list_tokens.assign(nc, 0);
+    int max_per_obj = 1;
+    for (int c = 0; c < nc; c++) {
+      const int32_t* C = P + d.sec[MGX_SEC_CLASSES] + c * MGX_C_WORDS;
+      int n = 0;
+      for (int w = 0; w < MGX_TAG_WORDS; w++) n += __builtin_popcount((unsigned)C[MGX_C_TAGS + w]);
+      if (!C[MGX_C_STATIC]) n += 1 + P[MGX_H_NUM_RESOURCES] * digits + (C[MGX_C_KIND] == MGX_KIND_AGENT ? 2 : 0);
+      max_per_obj = std::max(max_per_obj, n);
+      e->class_list_tokens[c] = C[MGX_C_STATIC] ? 0 : n;
+    }
+    e->pool_from_maps = !d.X && !P[MGX_H_SPAWNS] && !P[MGX_H_DYNAMIC_TAGS];
+    long long bound = e->pool_from_maps ? e->list_tokens_bound(class_maps, 0, (size_t)E, nullptr) : (long long)S * max_per_obj;
+    e->pool_tokens = (e->pool_prefix + (int)std::min<long long>(bound, 16384) + 7) & ~7;
   }
   {  // sections INV_FEATURES..OBS_VALUES are contiguous (sections are laid out in id order); small block -> LDS copy
     const int b0 = d.sec[MGX_SEC_INV_FEATURES], b1 = d.sec[MGX_SEC_WORDLIST];
@@ -360,20 +400,10 @@ int mgx_create(const int32_t* program, size_t program_words, const uint16_t* cla
     }
     e->rewards_early = pure;
   }
-  e->lds_obs = (size_t)mgx_obs_lds_layout((int)HW, d.NOFF, (int)S, (int)A, d.T, e->pool_tokens, d.X != 0, d.n_obs_values,
-                                          e->obs_blk_lds ? e->obs_blk_words : 0, mgx_obs_gt(d.n_obs_values, d.base)).total;
-  if (e->lds_obs > 160 * 1024 || e->lds_world > 64 * 1024) {
-    mgx_destroy(e);
-    return fail(MGX_ERR_PROGRAM, "mgx_create: map/object count too large for the LDS staging of the observation kernel");
-  }
+  if (e->lds_world > 64 * 1024) { mgx_destroy(e); return fail(MGX_ERR_PROGRAM, "mgx_create: world kernel LDS staging too large"); }
+  rc = size_obs_lds(e);
+  if (rc != MGX_OK) { mgx_destroy(e); return rc; }
   hipError_t he = hipSuccess;
-  {
-    const void* fns[] = {(const void*)mgx_obs_kernel<true, false, false>, (const void*)mgx_obs_kernel<false, false, false>,
-                         (const void*)mgx_obs_kernel<true, false, true>,  (const void*)mgx_obs_kernel<false, false, true>,
-                         (const void*)mgx_obs_kernel<true, true, false>,  (const void*)mgx_obs_kernel<false, true, false>};
-    for (const void* f : fns)
-      if (he == hipSuccess) he = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_obs);
-  }
   if (he == hipSuccess) he = hipMemcpyAsync(dprog, program, program_words * 4, hipMemcpyHostToDevice, e->stream);
   if (he == hipSuccess) he = hipMemcpyAsync(dmaps, class_maps, E * HW * 2, hipMemcpyHostToDevice, e->stream);
   if (he == hipSuccess) he = hipMemcpyAsync(dseeds, seeds, E * 4, hipMemcpyHostToDevice, e->stream);
@@ -448,6 +478,15 @@ int mgx_reset_envs(mgx_engine* e, const uint8_t* env_mask, const uint16_t* class
   int first = -1, last = -1;
   for (size_t i = 0; i < E; i++) if (env_mask[i]) { if (first < 0) first = (int)i; last = (int)i; }
   if (first < 0) return MGX_OK;
+  if (class_maps && e->pool_from_maps) {  // new maps may hold more non-static objects than any map seen so far
+    const long long bound = e->list_tokens_bound(class_maps, (size_t)first, (size_t)(last - first + 1), env_mask);
+    const int need = (e->pool_prefix + (int)std::min<long long>(bound, 16384) + 7) & ~7;
+    if (need > e->pool_tokens) {
+      e->pool_tokens = need;
+      int rcl = size_obs_lds(e);
+      if (rcl) return rcl;
+    }
+  }
   HIP_TRY(hipMemcpyAsync(e->dmask, env_mask, E, hipMemcpyHostToDevice, e->stream));
   for (int i = first; i <= last; i++) {
     if (!env_mask[i]) continue;

@@ -12,6 +12,11 @@
 // fused away) and the finished 3*T-byte row is written to HBM with coalesced dword stores.
 // The reference's "first observer of an object this step gets the cell.visited staleness" rule (:789-796, serial
 // agent order) becomes an LDS atomicMin over observer indices followed by an in-order wavefront reduction.
+//
+// The kernel is instruction-issue bound (profiles/), so the hot loops are written branch-free: LDS reads use clamped
+// indices and selects instead of nested divergent ifs, predicated LDS stores go to a per-wave trash word instead of
+// toggling EXEC, and everything that is the same for all observers is computed once per env (token lists, global
+// tokens, the window -> slot map of every agent).
 #ifndef MGX_OBS_H_
 #define MGX_OBS_H_
 
@@ -77,13 +82,17 @@ struct MgxBase {
 #define MGX_MAX_ITEMS 13  // resources per inventory (mgx_create enforces R <= 13: 4-bit ids, 0xF terminator)
 
 // Dynamic LDS layout, all regions 16-byte aligned (the host calls the same function):
-//   grid u16[HW] | offsets i8x2[NOFF] | minobs u32[S] | visited u32[S] | tokinfo u32[S] (start | count << 16) |
-//   agents u32[A] (slot | rc << 16) | aginfo u32[A] (executed | moved << 8) | spawn u16[A] | vstat f32[A] |
-//   written i32[A] | rwinfo u32[A] (reward start | count << 16) | misc u32[4] | pool u16[POOL] | rows u32[WAVES][Tpad] |
+//   grid u16[HW] | offsets i8x2[NOFF] | loc u8[CP] (packed window coordinate of offset j) | minobs u32[S+1] |
+//   visited u32[S] | tokinfo u32[S] (start | count << 16) | dyn u16[S] (slots whose token list is built per step) |
+//   agents u32[A] (slot | rc << 16) | aginfo u32[A] | spawn u16[A] | vstat f32[A] | written i32[A] |
+//   rwinfo u32[A] (reward start | count << 16) | misc u32[4] | pool u16[POOL+8] | rows u32[WAVES][Tpad+64] |
+//   cell u16[A][CP] (slot + 1 under window cell j of agent a, 0 = empty / outside) | X extras |
 //   blk i32[blk_words]: program sections INV_FEATURES..OBS_VALUES (PL variants only) | gtok u32[A][GT] global tokens
+// CP = NOFF rounded up to 128 (two window cells per lane and pass).
 __host__ __device__ inline int mgx_align16(int x) { return (x + 15) & ~15; }
 struct MgxObsLds {
-  int grid, offs, minobs, visited, tokinfo, agents, aginfo, spawn, vstat, written, rwinfo, misc, pool, rows, row_words, blk, gtok, total;
+  int grid, offs, loc, minobs, visited, tokinfo, dyn, agents, aginfo, spawn, vstat, written, rwinfo, misc, pool, rows, row_words,
+      row_pitch, cell, cp, blk, gtok, total;
   int owner, obsval, tscore;  // X only: per-cell territory owner u16[HW], obs values u32[A][NOV], scores i64[8][256]
 };
 // Upper bound of the global (location 0xFE) tokens of one agent: completion, last action, last action move, last
@@ -97,11 +106,14 @@ __host__ __device__ inline MgxObsLds mgx_obs_lds_layout(int HW, int NOFF, int S,
                                                         bool X = false, int NOV = 0, int blk_words = 0, int GT = 6) {
   MgxObsLds l;
   int o = 0;
+  l.cp = ((NOFF + 2 * MGX_WAVE - 1) / (2 * MGX_WAVE)) * 2 * MGX_WAVE;
   l.grid = o; o += mgx_align16(HW * 2);
   l.offs = o; o += mgx_align16(NOFF * 2);
-  l.minobs = o; o += mgx_align16(S * 4);
+  l.loc = o; o += mgx_align16(l.cp);
+  l.minobs = o; o += mgx_align16((S + 1) * 4);
   l.visited = o; o += mgx_align16(S * 4);
   l.tokinfo = o; o += mgx_align16(S * 4);
+  l.dyn = o; o += mgx_align16(S * 2);
   l.agents = o; o += mgx_align16(A * 4);
   l.aginfo = o; o += mgx_align16(A * 4);
   l.spawn = o; o += mgx_align16(A * 2);
@@ -109,9 +121,11 @@ __host__ __device__ inline MgxObsLds mgx_obs_lds_layout(int HW, int NOFF, int S,
   l.written = o; o += mgx_align16(A * 4);
   l.rwinfo = o; o += mgx_align16(A * 4);
   l.misc = o; o += 16;
-  l.pool = o; o += mgx_align16(pool_tokens * 2);
+  l.pool = o; o += mgx_align16((pool_tokens + 8) * 2);
   l.row_words = (T + 3) & ~3;
-  l.rows = o; o += MGX_OBS_WAVES * l.row_words * 4;
+  l.row_pitch = l.row_words + MGX_WAVE;  // + one trash word per lane: masked-off stores land there, conflict-free
+  l.rows = o; o += MGX_OBS_WAVES * l.row_pitch * 4;
+  l.cell = o; o += mgx_align16(A * l.cp * 2);
   l.owner = l.obsval = l.tscore = 0;
   if (X) {
     l.owner = o; o += mgx_align16(HW * 2);
@@ -124,27 +138,38 @@ __host__ __device__ inline MgxObsLds mgx_obs_lds_layout(int HW, int NOFF, int S,
   return l;
 }
 
+// Wavefront sum (every lane gets the total).
+__device__ __forceinline__ uint32_t mgx_wave_sum(uint32_t x) {
+  return (uint32_t)__builtin_amdgcn_readlane(mgx_wave_incl_scan((int)x), MGX_WAVE - 1);
+}
+
 // PL: the program sections this kernel interprets (inventory feature ids, game-value code, reward records, obs
 // values: [blk_start, blk_start + blk_words) of the blob, contiguous because the compiler lays sections out in id
 // order) are copied into LDS so the reward / obs-value interpreter and the token builder never wait on global loads
 // for program words.  The host picks PL when the block is small (mgx_create) and passes a MgxDev whose section
 // offsets for exactly those sections are relative to the block start, so the LDS view is a plain base pointer (no
 // out-of-object pointer arithmetic on an LDS address).
+// pool_prefix: the first pool_prefix pool entries are the per-class static tag tokens (a copy of MgxDev::cls_tok), which
+// is all a static object (walls ...) ever shows; only the other objects get a per-step list behind them.
 template <bool WITH_REWARDS, bool X, bool PL>
-__global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int pool_tokens, const uint8_t* env_mask,
+__global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int pool_tokens, int pool_prefix, const uint8_t* env_mask,
                                                                   int blk_start, int blk_words, int rewards_early) {
   extern __shared__ __align__(16) uint8_t smem[];
   const int env = blockIdx.x;
   if (env_mask && !env_mask[env]) return;  // episode restart: only the restarted envs get initial observations
-  const int tid = threadIdx.x, lane = tid & (MGX_WAVE - 1), wave = tid / MGX_WAVE;
+  const int tid = threadIdx.x, lane = tid & (MGX_WAVE - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(tid / MGX_WAVE);  // wave-uniform: per-agent values and branches go scalar
   const int HW = d.H * d.W, A = d.A, S = d.S, T = d.T, NOFF = d.NOFF;
   const int GT = mgx_obs_gt(d.n_obs_values, d.base);
   const MgxObsLds L = mgx_obs_lds_layout(HW, NOFF, S, A, T, pool_tokens, X, d.n_obs_values, PL ? blk_words : 0, GT);
+  const int CP = L.cp;
   uint16_t* s_grid = (uint16_t*)(smem + L.grid);
   char2* s_offs = (char2*)(smem + L.offs);
+  uint8_t* s_loc = smem + L.loc;
   uint32_t* s_minobs = (uint32_t*)(smem + L.minobs);
   uint32_t* s_visited = (uint32_t*)(smem + L.visited);
   uint32_t* s_tokinfo = (uint32_t*)(smem + L.tokinfo);
+  uint16_t* s_dyn = (uint16_t*)(smem + L.dyn);
   uint32_t* s_agents = (uint32_t*)(smem + L.agents);
   uint32_t* s_aginfo = (uint32_t*)(smem + L.aginfo);
   uint16_t* s_spawn = (uint16_t*)(smem + L.spawn);
@@ -153,7 +178,9 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
   uint32_t* s_rwinfo = (uint32_t*)(smem + L.rwinfo);
   uint32_t* s_misc = (uint32_t*)(smem + L.misc);
   uint16_t* s_pool = (uint16_t*)(smem + L.pool);
-  uint32_t* s_row = (uint32_t*)(smem + L.rows) + wave * L.row_words;  // one u32 per token: loc | f << 8 | v << 16
+  uint32_t* s_row = (uint32_t*)(smem + L.rows) + wave * L.row_pitch;  // one u32 per token: loc | f << 8 | v << 16
+  const int TRASH = L.row_words + lane;                               // s_row[TRASH]: target of this lane's masked-off stores
+  uint16_t* s_cell = (uint16_t*)(smem + L.cell);
   uint32_t* s_gtok = (uint32_t*)(smem + L.gtok);
 
   typedef MgxEnvT<MgxGlobalProg, X> Env;
@@ -178,6 +205,7 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
   ev.step = step;
   ev.xl = e.xl;
   const MgxBase B((uint32_t)d.base);
+  const int hr = d.feat[14], wr = d.feat[15];  // obs_height >> 1, obs_width >> 1 (stored by the host)
 
   // RewardHelper::compute_entries (reward.hpp:56-77) + truncation/termination (mettagrid_c.cpp:1086-1096) of one agent
   auto agent_rewards = [&](int a) {
@@ -206,7 +234,7 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
   };
 
   MGX_TICK0();
-  // ---- phase 0: stage the env (coalesced) and build the per-object token cache ----
+  // ---- phase 0a: stage the env (coalesced) ----
   {
     const uint4* src = (const uint4*)(d.grid + (size_t)env * HW);
     uint4* dst = (uint4*)s_grid;
@@ -218,8 +246,14 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
       int4* bdst = (int4*)(smem + L.blk);
       for (int i = tid; i < blk_words / 4; i += MGX_OBS_THREADS) bdst[i] = bsrc[i];
     }
+    for (int i = tid; i < pool_prefix; i += MGX_OBS_THREADS) s_pool[i] = d.cls_tok[i];
     const int32_t* offs = d.P + d.sec[MGX_SEC_OBS_OFFSETS];
-    for (int i = tid; i < NOFF; i += MGX_OBS_THREADS) s_offs[i] = make_char2((char)offs[i * 2], (char)offs[i * 2 + 1]);
+    for (int i = tid; i < CP; i += MGX_OBS_THREADS) {
+      const int ii = min(i, NOFF - 1);
+      const int orow = offs[ii * 2], ocol = offs[ii * 2 + 1];
+      if (i < NOFF) s_offs[i] = make_char2((char)orow, (char)ocol);
+      s_loc[i] = (uint8_t)(((orow + hr) << 4) | (ocol + wr));
+    }
     for (int i = tid; i < A; i += MGX_OBS_THREADS) {
       const uint32_t slot = d.ag_obj[e.ao(i)];
       const int32_t ex = d.executed[e.ao(i)];
@@ -234,102 +268,122 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
       s_vstat[i] = vs;
       s_rwinfo[i] = ((uint32_t)C[MGX_C_REWARD_START] & 0xFFFFu) | ((uint32_t)C[MGX_C_REWARD_COUNT] << 16);
     }
-    if (tid == 0) s_misc[0] = 0;  // pool top
+    if (tid == 0) { s_misc[0] = (uint32_t)pool_prefix; s_misc[1] = 0; }  // pool top, number of per-step lists
   }
+  const bool dyn_tags = X && d.obj_tags != nullptr;
+  // ---- phase 0b: classify the object slots.  Static classes show their class tag list (pool prefix); everything
+  // else is queued for the list builder. ----
   __syncthreads();
   MGX_TICK(8);
   MGX_PHASE_END(1);
+  for (int s = tid; s < S; s += MGX_OBS_THREADS) {
+    const size_t o = e.so(s);
+    const uint16_t cls = d.obj_cls[o];
+    const uint32_t vis = d.obj_visited[o];
+    s_minobs[s] = 0xFFFFFFFFu;
+    uint32_t info = 0;
+    if (cls != MGX_DEAD_CLASS) {
+      const uint32_t cinfo = d.cls_tokinfo[cls];  // start(16) | group(8) | ntags(6) | agent(1) | static(1)
+      s_visited[s] = vis;
+      if ((cinfo >> 31) != 0 && !dyn_tags) {
+        info = (cinfo & 0xFFFFu) | (((cinfo >> 24) & 0x3Fu) << 16);
+      } else {
+        const uint32_t k = atomicAdd(&s_misc[1], 1u);
+        s_dyn[k] = (uint16_t)s;
+        info = cinfo;  // parked here for the builder, which replaces it with start | count << 16
+      }
+    }
+    s_tokinfo[s] = info;
+  }
+  __syncthreads();
+
+  // ---- phase 0c: per-step token lists, one thread per queued object (a fraction of one wavefront in most envs) ----
   {
+    const int ndyn = (int)s_misc[1];
     const int f_vibe = d.feat[MGX_F_VIBE], f_group = d.feat[MGX_F_GROUP], f_agent = d.feat[MGX_F_AGENT_ID], f_tag = d.feat[MGX_F_TAG];
     VP feat = vp + d.sec[MGX_SEC_INV_FEATURES];
-    for (int s = tid; s < S; s += MGX_OBS_THREADS) {
+    for (int i = tid; i < ndyn; i += MGX_OBS_THREADS) {
+      const int s = s_dyn[i];
+      const uint32_t cinfo = s_tokinfo[s];
       // every field of the slot at once: independent loads, one memory round trip
       const size_t o = e.so(s);
-      const uint16_t cls = d.obj_cls[o];
-      const uint32_t vis = d.obj_visited[o];
       const uint32_t vibe = d.obj_vibe[o];
       const uint32_t agent_id = d.obj_agent[o];
       unsigned long long ord = d.obj_order[o];
       if constexpr (X) {
         if (d.obj_flags && (d.obj_flags[o] & 2)) ord = ~0ull;  // created at run time without an ObservationEncoder
       }
-      s_minobs[s] = 0xFFFFFFFFu;
+      const bool is_static = (cinfo >> 31) != 0;
+      const bool is_agent = (cinfo & 0x40000000u) != 0;
+      // inventory amounts in iteration order (second round trip, again all loads in flight together)
+      uint32_t amt[MGX_MAX_ITEMS];
+      uint32_t live_mask = 0;
+      {
+        bool live = !is_static;
+#pragma unroll
+        for (int k = 0; k < MGX_MAX_ITEMS; k++) {
+          const int item = (int)((ord >> (4 * k)) & 0xF);
+          live = live && item != 0xF;
+          amt[k] = live ? (uint32_t)d.obj_inv[o * d.R + item] : 0u;
+          if (live) live_mask |= 1u << k;
+        }
+      }
+      int ntags = (cinfo >> 24) & 0x3F;
+      uint32_t tagw[MGX_TAG_WORDS];
+      if (dyn_tags) {
+        ntags = 0;
+#pragma unroll
+        for (int w = 0; w < MGX_TAG_WORDS; w++) { tagw[w] = d.obj_tags[o * MGX_TAG_WORDS + w]; ntags += __popc(tagw[w]); }
+      }
+      int n = ntags;
+      if (!is_static) {
+        if (vibe != 0) n++;
+#pragma unroll
+        for (int k = 0; k < MGX_MAX_ITEMS; k++)
+          if (live_mask & (1u << k)) n += B.digits(amt[k]);
+        if (is_agent) n += 2;  // group + agent_id
+      }
       uint32_t info = 0;
-      if (cls != MGX_DEAD_CLASS) {
-        const uint32_t cinfo = d.cls_tokinfo[cls];  // start(16) | group(8) | ntags(6) | agent(1) | static(1)
-        const bool is_static = (cinfo >> 31) != 0;
-        const bool is_agent = (cinfo & 0x40000000u) != 0;
-        // inventory amounts in iteration order (second round trip, again all loads in flight together)
-        uint32_t amt[MGX_MAX_ITEMS];
-        uint32_t live_mask = 0;
-        {
-          bool live = !is_static;
+      const uint32_t start = atomicAdd(&s_misc[0], (uint32_t)n);
+      if ((int)(start + n) <= pool_tokens) {
+        MgxObjTok w{s_pool, (int)start};
+        if (dyn_tags) {  // ascending tag id (core/grid_object.cpp:181-186)
 #pragma unroll
-          for (int k = 0; k < MGX_MAX_ITEMS; k++) {
-            const int item = (int)((ord >> (4 * k)) & 0xF);
-            live = live && item != 0xF;
-            amt[k] = live ? (uint32_t)d.obj_inv[o * d.R + item] : 0u;
-            if (live) live_mask |= 1u << k;
+          for (int wd = 0; wd < MGX_TAG_WORDS; wd++) {
+            uint32_t m = tagw[wd];
+            while (m) { int b = __ffs(m) - 1; m &= m - 1; w.put(f_tag, wd * 32 + b); }
           }
-        }
-        int ntags = (cinfo >> 24) & 0x3F;
-        const bool dyn_tags = X && d.obj_tags != nullptr;
-        uint32_t tagw[MGX_TAG_WORDS];
-        if (dyn_tags) {
-          ntags = 0;
-#pragma unroll
-          for (int w = 0; w < MGX_TAG_WORDS; w++) { tagw[w] = d.obj_tags[o * MGX_TAG_WORDS + w]; ntags += __popc(tagw[w]); }
-        }
-        int n = ntags;
-        if (!is_static) {
-          if (vibe != 0) n++;
-#pragma unroll
-          for (int k = 0; k < MGX_MAX_ITEMS; k++)
-            if (live_mask & (1u << k)) n += B.digits(amt[k]);
-          if (is_agent) n += 2;  // group + agent_id
-        }
-        const uint32_t start = atomicAdd(&s_misc[0], (uint32_t)n);
-        if ((int)(start + n) <= pool_tokens) {
-          MgxObjTok w{s_pool, (int)start};
-          if (dyn_tags) {  // ascending tag id (core/grid_object.cpp:181-186)
-#pragma unroll
-            for (int wd = 0; wd < MGX_TAG_WORDS; wd++) {
-              uint32_t m = tagw[wd];
-              while (m) { int b = __ffs(m) - 1; m &= m - 1; w.put(f_tag, wd * 32 + b); }
-            }
-          } else {
-            const uint16_t* src = d.cls_tok + (cinfo & 0xFFFF);
-            for (int k = 0; k < ntags; k++) s_pool[w.pos++] = src[k];
-          }
-          if (!is_static) {
-            if (vibe != 0) w.put(f_vibe, vibe);
-#pragma unroll
-            for (int k = 0; k < MGX_MAX_ITEMS; k++) {  // observation_encoder.hpp:198-225: base digit, then :pK digits
-              if (live_mask & (1u << k)) {
-                const int item = (int)((ord >> (4 * k)) & 0xF);
-                VP F = feat + item * MGX_IF_WORDS;
-                uint32_t rem = amt[k];
-                w.put((uint32_t)F[0], B.lo(rem));
-                rem = B.hi(rem);
-                for (int pdig = 1; rem > 0; pdig++) { w.put((uint32_t)F[pdig], B.lo(rem)); rem = B.hi(rem); }
-              }
-            }
-            if (is_agent) {
-              w.put(f_group, (cinfo >> 16) & 0xFF);
-              w.put(f_agent, agent_id);
-            }
-          }
-          info = start | ((uint32_t)n << 16);
         } else {
-          d.err[env] |= 16u;  // token pool exhausted (sized by the host from the program's per-object maximum)
+          const uint16_t* src = s_pool + (cinfo & 0xFFFF);  // class tag list from the pool prefix
+          for (int k = 0; k < ntags; k++) s_pool[w.pos++] = src[k];
         }
-        s_visited[s] = vis;
+        if (!is_static) {
+          if (vibe != 0) w.put(f_vibe, vibe);
+#pragma unroll
+          for (int k = 0; k < MGX_MAX_ITEMS; k++) {  // observation_encoder.hpp:198-225: base digit, then :pK digits
+            if (live_mask & (1u << k)) {
+              const int item = (int)((ord >> (4 * k)) & 0xF);
+              VP F = feat + item * MGX_IF_WORDS;
+              uint32_t rem = amt[k];
+              w.put((uint32_t)F[0], B.lo(rem));
+              rem = B.hi(rem);
+              for (int pdig = 1; rem > 0; pdig++) { w.put((uint32_t)F[pdig], B.lo(rem)); rem = B.hi(rem); }
+            }
+          }
+          if (is_agent) {
+            w.put(f_group, (cinfo >> 16) & 0xFF);
+            w.put(f_agent, agent_id);
+          }
+        }
+        info = start | ((uint32_t)n << 16);
+      } else {
+        d.err[env] |= 16u;  // token pool exhausted (sized by the host from the class maps)
       }
       s_tokinfo[s] = info;
     }
   }
   // Rewards that read nothing this kernel writes (no stat operands; host flag) are evaluated here by the last
-  // wavefront, which has little or no token-cache work, instead of serially at the end of the workgroup.
+  // wavefront, which has little or no list-building work, instead of serially at the end of the workgroup.
   if (WITH_REWARDS && rewards_early && wave == MGX_OBS_WAVES - 1)
     for (int a = lane; a < A; a += MGX_WAVE) agent_rewards(a);
   if constexpr (X) {
@@ -350,14 +404,22 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
               (uint32_t)e.template eval_code<Env::TOPQ>(V[MGX_OV_GV_START], V[MGX_OV_GV_COUNT], slot, vc, 0);
         }
     }
+    if (d.n_obs_values > 0) __syncthreads();  // obs values are read by the global-token threads below
   }
-  __syncthreads();
-  MGX_TICK(9);
-  MGX_PHASE_END(2);
 
-  const int hr = d.feat[14], wr = d.feat[15];  // obs_height >> 1, obs_width >> 1 (stored by the host)
-  const int NPASS = (NOFF + 2 * MGX_WAVE - 1) / (2 * MGX_WAVE);  // two window cells per lane and pass
-
+  // ---- phase 1: window -> slot map of every agent, and the first observer (lowest agent index) of every object ----
+  for (int a = wave; a < A; a += MGX_OBS_WAVES) {
+    const uint32_t ag = s_agents[a];
+    const int r0 = (ag >> 24) & 0xFF, c0 = (ag >> 16) & 0xFF;
+    for (int j = lane; j < CP; j += MGX_WAVE) {
+      const char2 o = s_offs[min(j, NOFF - 1)];
+      const int r = r0 + o.x, c = c0 + o.y;
+      const bool inb = j < NOFF && (unsigned)r < (unsigned)d.H && (unsigned)c < (unsigned)d.W;
+      const uint32_t cs = inb ? (uint32_t)s_grid[inb ? r * d.W + c : 0] : 0u;
+      s_cell[a * CP + j] = (uint16_t)cs;
+      if (step > 0 && cs) atomicMin(&s_minobs[cs - 1], (uint32_t)a);
+    }
+  }
   // global tokens (location 0xFE), mettagrid_c.cpp:700-753: one thread per agent, all agents at once
   if (tid < A) {
     const int a = tid;
@@ -404,68 +466,50 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
     }
     s_aginfo[a] = (uint32_t)pos;  // from here on: the agent's global token count
   }
-  // ---- phase 1: first observer (lowest agent index) of every visible object ----
-  if (step > 0) {
-    for (int a = wave; a < A; a += MGX_OBS_WAVES) {
-      uint32_t ag = s_agents[a];
-      int r0 = (ag >> 24) & 0xFF, c0 = (ag >> 16) & 0xFF;
-      for (int j = lane; j < NOFF; j += MGX_WAVE) {
-        char2 o = s_offs[j];
-        int r = r0 + o.x, c = c0 + o.y;
-        if ((unsigned)r < (unsigned)d.H && (unsigned)c < (unsigned)d.W) {
-          int slot = (int)s_grid[r * d.W + c] - 1;
-          if (slot >= 0) atomicMin(&s_minobs[slot], (uint32_t)a);
-        }
-      }
-    }
-  }
   __syncthreads();
   MGX_TICK(10);
   MGX_PHASE_END(3);
 
   // ---- phase 2: encode ----
+  const int NPASS = CP / (2 * MGX_WAVE);  // two window cells per lane and pass
   for (int a = wave; a < A; a += MGX_OBS_WAVES) {
     const uint32_t ag = s_agents[a];
     const int my_slot = ag & 0xFFFF;
-    const int r0 = (ag >> 24) & 0xFF, c0 = (ag >> 16) & 0xFF;
     for (int i = lane; i < L.row_words / 4; i += MGX_WAVE) ((uint4*)s_row)[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
-
-    // global tokens (location 0xFE) were assembled once per env in phase 1; copy this agent's
+    // global tokens were assembled once per env above; copy this agent's
     const int n_global = (int)s_aginfo[a];
     for (int k = lane; k < n_global && k < T; k += MGX_WAVE) s_row[k] = s_gtok[a * GT + k];
     int base_pos = n_global;
 
-    // window cells in reference order: lane handles cells j and j + 64 of each 128-cell pass; everything is LDS
+    // window cells in reference order: lane handles cells j and j + 64 of each 128-cell pass; everything is LDS and
+    // every read is unconditional (empty / outside cells read slot 0 and are masked by a select)
     float visited_acc = s_vstat[a];
     bool visited_any = false;
     for (int p = 0; p < NPASS; p++) {
-      int n[2] = {0, 0}, start[2] = {0, 0};
-      uint32_t loc[2] = {0, 0}, mask[2] = {0, 0};
-      float stale[2] = {0.f, 0.f};
-      bool first[2] = {false, false};
+      int n[2], start[2];
+      uint32_t loc[2], mask[2] = {0, 0}, stale[2];
 #pragma unroll
       for (int h = 0; h < 2; h++) {
         const int j = p * 2 * MGX_WAVE + h * MGX_WAVE + lane;
-        if (j < NOFF) {
-          char2 o = s_offs[j];
-          int r = r0 + o.x, c = c0 + o.y;
-          if ((unsigned)r < (unsigned)d.H && (unsigned)c < (unsigned)d.W) {
-            int slot = (int)s_grid[r * d.W + c] - 1;
-            loc[h] = (uint32_t)(((o.x + hr) << 4) | (o.y + wr));
-            if constexpr (X) {
-              if (want_mask) {  // _emit_tile_observability_tokens (:337-362): before the cell's object tokens
-                uint16_t ow = s_owner[r * d.W + c];
-                if (ow != 0xFFFF) { mask[h] = e.has_tag(my_slot, ow) ? 1u : 2u; n[h] = 1; }
-              }
-            }
-            if (slot >= 0) {
-              uint32_t info = s_tokinfo[slot];
-              start[h] = info & 0xFFFF;
-              n[h] += info >> 16;
-              if (step > 0 && s_minobs[slot] == (uint32_t)a) {
-                uint32_t pv = s_visited[slot];
-                if (pv < step) { first[h] = true; stale[h] = (float)(step - pv); }
-              }
+        const uint32_t cs = s_cell[a * CP + j];
+        const bool has = cs != 0;
+        const int slot = has ? (int)cs - 1 : 0;
+        const uint32_t info = s_tokinfo[slot];
+        loc[h] = s_loc[j];
+        start[h] = info & 0xFFFF;
+        n[h] = has ? (int)(info >> 16) : 0;
+        stale[h] = 0;
+        if (step > 0) {  // uniform
+          const uint32_t mo = s_minobs[slot], pv = s_visited[slot];
+          stale[h] = (has && mo == (uint32_t)a && pv < step) ? step - pv : 0u;
+        }
+        if constexpr (X) {
+          if (want_mask) {  // _emit_tile_observability_tokens (:337-362): before the cell's object tokens
+            const char2 o = s_offs[min(j, NOFF - 1)];
+            const int r = (int)((ag >> 24) & 0xFF) + o.x, c = (int)((ag >> 16) & 0xFF) + o.y;
+            if (j < NOFF && (unsigned)r < (unsigned)d.H && (unsigned)c < (unsigned)d.W) {
+              uint16_t ow = s_owner[r * d.W + c];
+              if (ow != 0xFFFF) { mask[h] = e.has_tag(my_slot, ow) ? 1u : 2u; n[h] += 1; }
             }
           }
         }
@@ -473,7 +517,7 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
       // one packed scan gives both halves' prefix sums (counts stay far below 65 536)
       const int packed = n[0] | (n[1] << 16);
       const int incl = mgx_wave_incl_scan(packed);
-      const int tot = __shfl(incl, MGX_WAVE - 1);
+      const int tot = __builtin_amdgcn_readlane(incl, MGX_WAVE - 1);
       const int excl = incl - packed;
       int pos0 = base_pos + (excl & 0xFFFF);
       int pos1 = base_pos + (tot & 0xFFFF) + (excl >> 16);
@@ -491,8 +535,10 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
         const bool big = n[h] > MGX_SMALL_LIST;
         const int ns = big ? 0 : n[h];
 #pragma unroll
-        for (int k = 0; k < MGX_SMALL_LIST; k++)
-          if (k < ns && ph + k < T) s_row[ph + k] = loc[h] | ((uint32_t)s_pool[start[h] + k] << 8);
+        for (int k = 0; k < MGX_SMALL_LIST; k++) {  // pool has 8 spare entries: the read is always in range
+          const uint32_t tok = loc[h] | ((uint32_t)s_pool[start[h] + k] << 8);
+          s_row[(k < ns && ph + k < T) ? ph + k : TRASH] = tok;
+        }
         unsigned long long bm = __ballot(big);
         while (bm) {
           const int l = __ffsll((long long)bm) - 1;
@@ -505,15 +551,25 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
         }
       }
       base_pos += (tot & 0xFFFF) + (tot >> 16);
-      // cell.visited staleness, added in cell order exactly like the serial reference loop (:789-796)
+      // cell.visited staleness (:789-796): the reference adds the values one by one in cell order.  All of them are
+      // integers, so while the running sum is an integer below 2^24 every partial sum is exact and the order does not
+      // matter: one wavefront sum.  Otherwise replay the serial order.
+      const unsigned long long fm0 = __ballot(stale[0] != 0), fm1 = __ballot(stale[1] != 0);
+      if (fm0 | fm1) {
+        visited_any = true;
+        const uint32_t ssum = mgx_wave_sum(stale[0] + stale[1]);
+        if (visited_acc == truncf(visited_acc) && visited_acc >= 0.f && visited_acc + (float)ssum <= 16777216.f && ssum < 16777216u) {
+          visited_acc += (float)ssum;
+        } else {
 #pragma unroll
-      for (int h = 0; h < 2; h++) {
-        unsigned long long m = __ballot(first[h]);
-        while (m) {
-          int l = __ffsll((long long)m) - 1;
-          m &= m - 1;
-          visited_acc = __fadd_rn(visited_acc, __shfl(stale[h], l));
-          visited_any = true;
+          for (int h = 0; h < 2; h++) {
+            unsigned long long m = h ? fm1 : fm0;
+            while (m) {
+              const int l = __ffsll((long long)m) - 1;
+              m &= m - 1;
+              visited_acc = __fadd_rn(visited_acc, (float)(uint32_t)__builtin_amdgcn_readlane((int)stale[h], l));
+            }
+          }
         }
       }
     }
