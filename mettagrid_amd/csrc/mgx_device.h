@@ -107,6 +107,15 @@ struct MgxDev {
   const int32_t* vibe_actions;  // [E*A]
 };
 
+// MGX_CONST_DEV: the translation unit keeps the engine's MgxDev in constant memory instead of passing it as a kernel
+// argument.  Every function of the handler VM then reads it by name: scalar, invariant loads (s_load from the
+// constant cache) even inside out-of-line callees, where a by-reference MgxDev would be flat-loaded through `this`
+// and re-loaded after every store that might alias it.  The host keeps the symbol in step with the engine that
+// launches (mgx_world_fast.hip).
+#ifdef MGX_CONST_DEV
+static __constant__ MgxDev g_mgx_dev;
+#endif
+
 __device__ __forceinline__ const int32_t* mgx_cls(const MgxDev& d, int cls) {
   return d.P + d.sec[MGX_SEC_CLASSES] + cls * MGX_C_WORDS;
 }

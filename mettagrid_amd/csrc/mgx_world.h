@@ -95,14 +95,22 @@ struct MgxValueStack {
 
 template <class PP, bool X>
 struct MgxEnvT {  // per-lane view of one env
+#ifdef MGX_CONST_DEV
+  static constexpr const MgxDev& d = g_mgx_dev;
+#else
   const MgxDev& d;
+#endif
   PP P;
   int env;
   uint32_t step;
   MgxXLds xl;
   MgxALds al;
   mutable int cur_agent, cur_slot;  // agent whose action is being executed (LDS write-through of its position)
+#ifdef MGX_CONST_DEV
+  __device__ MgxEnvT(const MgxDev&, PP prog, int e) : P(prog), env(e), step(0), cur_agent(-1), cur_slot(-1) {
+#else
   __device__ MgxEnvT(const MgxDev& dd, PP prog, int e) : d(dd), P(prog), env(e), step(0), cur_agent(-1), cur_slot(-1) {
+#endif
     al.slot = nullptr; al.rc = nullptr; al.prev = nullptr; al.swm = nullptr; al.act = nullptr; al.lane = 0; al.A = 0;
     xl.def_delta = nullptr; xl.terr_score = nullptr; xl.lane = 0; xl.stride = MGX_WAVE; }
   __device__ __forceinline__ PP cls(int c) const { return P + d.sec[MGX_SEC_CLASSES] + c * MGX_C_WORDS; }
