@@ -15,8 +15,8 @@
 #include "mgx_world.h"
 
 template <bool PROG_LDS>
-__global__ void __launch_bounds__(MGX_WORLD_MAX_THREADS) mgx_world_kernel_ext(MgxDev d, int prog_words, int lpw) {
-  mgx_world_entry<PROG_LDS, true>(d, prog_words, lpw);
+__global__ void __launch_bounds__(MGX_WAVE) mgx_world_kernel_ext(MgxDev d, int prog_words) {
+  mgx_world_entry<PROG_LDS, true>(d, prog_words);
 }
 
 static thread_local std::string g_err;
@@ -74,8 +74,6 @@ struct mgx_engine {
     return best;
   }
   bool rewards_early = false;  // reward expressions have no stat operands: evaluated beside the token-cache phase
-  int world_lpw = MGX_WAVE;  // envs per wavefront of the world kernel (64, 32, 16 or 8)
-  int world_wpe = 0;         // 4: the 128-VGPR build of the non-extended world kernel
   uint16_t* dmaps = nullptr;
   uint32_t* dseeds = nullptr;
   uint8_t* dmask = nullptr;
@@ -324,14 +322,9 @@ int mgx_create(const int32_t* program, size_t program_words, const uint16_t* cla
   e->lds_world = (size_t)mgx_world_lds_fixed(d.A, d.X != 0);
   e->prog_in_lds = program_words * 4 + e->lds_world <= 39 * 1024;  // 4 workgroups per CU (160 KB LDS) keep their copy
   if (e->prog_in_lds) e->lds_world += program_words * 4;
-  if (const char* v = getenv("MGX_WORLD_LPW")) {  // tuning knobs (bench sweeps); defaults are the measured best
-    int l = atoi(v);
-    if (l == 8 || l == 16 || l == 32 || l == 64) e->world_lpw = l;
-  }
-  if (const char* v = getenv("MGX_WORLD_WPE")) e->world_wpe = atoi(v);
   if (getenv("MGX_VERBOSE"))
-    fprintf(stderr, "[mgx] E=%d A=%d S=%d program=%zu B world: X=%d prog_in_lds=%d lds=%zu B lpw=%d\n", d.E, d.A, d.S,
-            program_words * 4, d.X, (int)e->prog_in_lds, e->lds_world, e->world_lpw);
+    fprintf(stderr, "[mgx] E=%d A=%d S=%d program=%zu B world: X=%d prog_in_lds=%d lds=%zu B\n", d.E, d.A, d.S,
+            program_words * 4, d.X, (int)e->prog_in_lds, e->lds_world);
   {  // per-class static tag tokens (ascending tag id, core/grid_object.cpp:181-186)
     std::vector<uint32_t> info(P[MGX_H_NUM_CLASSES]);
     std::vector<uint16_t> toks;
@@ -535,13 +528,13 @@ int mgx_step(mgx_engine* e) {
   HIP_TRY(hipMemsetAsync(d.success, 0, rows, e->stream));
   if (e->profiling) HIP_TRY(hipEventRecord(e->ev[0], e->stream));
   {
-    const int pw = (int)e->prog.size(), lpw = e->world_lpw;
+    const int pw = (int)e->prog.size();
     if (d.X) {
-      dim3 grid((d.E + MGX_WAVE - 1) / MGX_WAVE), block(MGX_WAVE * (MGX_WAVE / lpw));
-      if (e->prog_in_lds) hipLaunchKernelGGL((mgx_world_kernel_ext<true>), grid, block, e->lds_world, e->stream, e->d, pw, lpw);
-      else hipLaunchKernelGGL((mgx_world_kernel_ext<false>), grid, block, e->lds_world, e->stream, e->d, pw, lpw);
+      dim3 grid((d.E + MGX_WAVE - 1) / MGX_WAVE), block(MGX_WAVE);
+      if (e->prog_in_lds) hipLaunchKernelGGL((mgx_world_kernel_ext<true>), grid, block, e->lds_world, e->stream, e->d, pw);
+      else hipLaunchKernelGGL((mgx_world_kernel_ext<false>), grid, block, e->lds_world, e->stream, e->d, pw);
     } else {
-      mgx_launch_world_fast(e->prog_in_lds, e->world_wpe, lpw, e->lds_world, e->stream, e->d, pw);
+      mgx_launch_world_fast(e->prog_in_lds, e->lds_world, e->stream, e->d, pw);
     }
   }
   HIP_TRY(hipGetLastError());

@@ -13,6 +13,8 @@
 #ifndef MGX_WORLD_H_
 #define MGX_WORLD_H_
 
+#include <type_traits>
+
 #include "mgx_device.h"
 
 struct MgxCtx {  // handler/handler_context.hpp:38-112 (the fields the supported filters/mutations read)
@@ -76,6 +78,25 @@ MGX_DBG_LINKAGE __device__ unsigned long long mgx_dbg_cycles[16];
 #endif
 
 __host__ __device__ inline int mgx_world_alds_bytes(int A) { return A * MGX_WAVE * (2 + 2 + 2 + 4 + 4); }
+// Dynamic LDS of the world kernels: order u8[A][64] | swm u32[A][64] | act i16[2][A][64] | slot, rc, prev u16[A][64] |
+// [X: deferred i32[28][64] | territory i64[8][64]] | program i32[prog_words] (when it fits).
+__host__ __device__ inline int mgx_world_lds_fixed(int A, bool X) {
+  int o = ((A * MGX_WAVE + 15) & ~15) + ((mgx_world_alds_bytes(A) + 15) & ~15);
+  if (X) o += 28 * MGX_WAVE * 4 + 8 * MGX_WAVE * 8;
+  return o;
+}
+extern __shared__ __align__(16) uint8_t mgx_dyn_lds[];
+__device__ __forceinline__ MgxALds mgx_world_alds(uint8_t* lds, int A, int lane) {
+  const int off = (A * MGX_WAVE + 15) & ~15;
+  MgxALds al;
+  al.lane = lane; al.A = A;
+  al.swm = (uint32_t*)(lds + off);
+  al.act = (int16_t*)(lds + off + A * MGX_WAVE * 4);
+  al.slot = (uint16_t*)(lds + off + A * MGX_WAVE * 8);
+  al.rc = al.slot + A * MGX_WAVE;
+  al.prev = al.rc + A * MGX_WAVE;
+  return al;
+}
 
 __device__ __forceinline__ unsigned long long mgx_floor_sqrt(unsigned long long v) {  // == floor_sqrt_u64 (:17-33), v < 2^53
   unsigned long long r = (unsigned long long)__dsqrt_rn((double)v);
@@ -100,23 +121,39 @@ struct MgxEnvT {  // per-lane view of one env
 #else
   const MgxDev& d;
 #endif
-  PP P;
-  int env;
+  PP P_;
+  int env_;
   uint32_t step;
   MgxXLds xl;
-  MgxALds al;
+  MgxALds al_;
   mutable int cur_agent, cur_slot;  // agent whose action is being executed (LDS write-through of its position)
 #ifdef MGX_CONST_DEV
-  __device__ MgxEnvT(const MgxDev&, PP prog, int e) : P(prog), env(e), step(0), cur_agent(-1), cur_slot(-1) {
+  __device__ MgxEnvT(const MgxDev&, PP prog, int e) : P_(prog), env_(e), step(0), cur_agent(-1), cur_slot(-1) {
 #else
-  __device__ MgxEnvT(const MgxDev& dd, PP prog, int e) : d(dd), P(prog), env(e), step(0), cur_agent(-1), cur_slot(-1) {
+  __device__ MgxEnvT(const MgxDev& dd, PP prog, int e) : d(dd), P_(prog), env_(e), step(0), cur_agent(-1), cur_slot(-1) {
 #endif
-    al.slot = nullptr; al.rc = nullptr; al.prev = nullptr; al.swm = nullptr; al.act = nullptr; al.lane = 0; al.A = 0;
+    al_.slot = nullptr; al_.rc = nullptr; al_.prev = nullptr; al_.swm = nullptr; al_.act = nullptr; al_.lane = 0; al_.A = 0;
     xl.def_delta = nullptr; xl.terr_score = nullptr; xl.lane = 0; xl.stride = MGX_WAVE; }
-  __device__ __forceinline__ PP cls(int c) const { return P + d.sec[MGX_SEC_CLASSES] + c * MGX_C_WORDS; }
+  // MGX_WORLD_IDS (the lane-per-env world kernel's own translation unit): env index, program base and the LDS agent
+  // staging are recomputed from the work-item ids and constant memory wherever they are needed.  As members they
+  // live in the kernel's stack frame, and an out-of-line handler function has to re-load them through `this` after
+  // every store that might alias it.
+#ifdef MGX_WORLD_IDS
+  __device__ __forceinline__ int envi() const { return (int)(blockIdx.x * MGX_WAVE + threadIdx.x); }
+  __device__ __forceinline__ PP prog() const {
+    if constexpr (std::is_same<PP, MgxLdsProg>::value) return (MgxLdsProg)(int32_t*)(mgx_dyn_lds + mgx_world_lds_fixed(d.A, X));
+    else return d.P;
+  }
+  __device__ __forceinline__ MgxALds AL() const { return mgx_world_alds(mgx_dyn_lds, d.A, (int)threadIdx.x); }
+#else
+  __device__ __forceinline__ int envi() const { return env_; }
+  __device__ __forceinline__ PP prog() const { return P_; }
+  __device__ __forceinline__ const MgxALds& AL() const { return al_; }
+#endif
+  __device__ __forceinline__ PP cls(int c) const { return prog() + d.sec[MGX_SEC_CLASSES] + c * MGX_C_WORDS; }
 
-  __device__ __forceinline__ size_t so(int slot) const { return (size_t)env * d.S + slot; }
-  __device__ __forceinline__ size_t ao(int agent) const { return (size_t)env * d.A + agent; }
+  __device__ __forceinline__ size_t so(int slot) const { return (size_t)envi() * d.S + slot; }
+  __device__ __forceinline__ size_t ao(int agent) const { return (size_t)envi() * d.A + agent; }
   __device__ __forceinline__ uint16_t& inv(int slot, int item) const { return d.obj_inv[so(slot) * d.R + item]; }
   __device__ __forceinline__ int inv_of(int slot, int item) const { return slot >= 0 ? (int)inv(slot, item) : 0; }
   __device__ __forceinline__ PP cls_of(int slot) const { return cls(d.obj_cls[so(slot)]); }
@@ -125,7 +162,7 @@ struct MgxEnvT {  // per-lane view of one env
     int a = d.obj_agent[so(slot)];
     return a == MGX_NO_AGENT ? -1 : a;
   }
-  __device__ __forceinline__ void flag(uint32_t bit) const { d.err[env] |= bit; }
+  __device__ __forceinline__ void flag(uint32_t bit) const { d.err[envi()] |= bit; }
 
   // ---- stats (systems/stats_tracker.hpp:69-90) ----
   __device__ __forceinline__ void astat_touch(int agent, int id) const { d.ag_touched[ao(agent) * d.NSW + (id >> 5)] |= 1u << (id & 31); }
@@ -150,22 +187,22 @@ struct MgxEnvT {  // per-lane view of one env
   __device__ __forceinline__ float astat_get(int agent, int id) const {
     return id < 0 ? 0.f : d.ag_stats[ao(agent) * d.NS + id];
   }
-  __device__ __forceinline__ void gstat_touch(int id) const { d.game_touched[(size_t)env * d.NGW + (id >> 5)] |= 1u << (id & 31); }
+  __device__ __forceinline__ void gstat_touch(int id) const { d.game_touched[(size_t)envi() * d.NGW + (id >> 5)] |= 1u << (id & 31); }
   __device__ __forceinline__ void gstat_set(int id, float v) const {
     if (id < 0) return;
-    d.game_stats[(size_t)env * d.NG + id] = v;
+    d.game_stats[(size_t)envi() * d.NG + id] = v;
     gstat_touch(id);
   }
   __device__ __forceinline__ void gstat_add(int id, float v) const {
     if (id < 0) return;
-    d.game_stats[(size_t)env * d.NG + id] += v;
+    d.game_stats[(size_t)envi() * d.NG + id] += v;
     gstat_touch(id);
   }
 
   // ---- inventory (cpp/src/mettagrid/objects/inventory.cpp) ----
   __device__ __forceinline__ int effective_limit(int slot, PP L) const {  // objects/inventory.hpp:26-40
     int sum = 0;
-    PP mods = P + d.sec[MGX_SEC_MODS] + L[MGX_L_MOD_START] * MGX_MOD_WORDS;
+    PP mods = prog() + d.sec[MGX_SEC_MODS] + L[MGX_L_MOD_START] * MGX_MOD_WORDS;
     for (int i = 0; i < L[MGX_L_MOD_COUNT]; i++)
       sum += (int)inv(slot, mods[i * MGX_MOD_WORDS + MGX_MOD_ITEM]) * mods[i * MGX_MOD_WORDS + MGX_MOD_BONUS];
     int eff = min(L[MGX_L_MAX], max(L[MGX_L_MIN], sum));
@@ -183,7 +220,7 @@ struct MgxEnvT {  // per-lane view of one env
   }
   __device__ __forceinline__ PP limit_of(PP C, int item) const {
     int li = C[MGX_C_RES_LIMIT + item];
-    return li < 0 ? (PP) nullptr : P + d.sec[MGX_SEC_LIMITS] + li * MGX_L_WORDS;
+    return li < 0 ? (PP) nullptr : prog() + d.sec[MGX_SEC_LIMITS] + li * MGX_L_WORDS;
   }
   __device__ MGX_BIG void on_inventory_change(int slot, int item, int delta, int amount) const {  // objects/agent.cpp:106-121
     int a = agent_of(slot);
@@ -235,11 +272,11 @@ struct MgxEnvT {  // per-lane view of one env
   template <int DEPTH>
   __device__ MGX_BIG void enforce_all_limits(int slot, PP C) const {  // inventory.cpp:141-173
     for (int li = 0; li < C[MGX_C_LIMIT_COUNT]; li++) {
-      PP L = P + d.sec[MGX_SEC_LIMITS] + (C[MGX_C_LIMIT_START] + li) * MGX_L_WORDS;
+      PP L = prog() + d.sec[MGX_SEC_LIMITS] + (C[MGX_C_LIMIT_START] + li) * MGX_L_WORDS;
       if (L[MGX_L_DROP_COUNT] == 0) continue;
       int excess = group_amount(slot, L) - effective_limit(slot, L);
       if (excess <= 0) continue;
-      PP drop = P + d.sec[MGX_SEC_DROP_ORDER] + L[MGX_L_DROP_START];
+      PP drop = prog() + d.sec[MGX_SEC_DROP_ORDER] + L[MGX_L_DROP_START];
       for (int k = 0; k < L[MGX_L_DROP_COUNT]; k++) {
         int item = drop[k];
         int to_drop = min((int)inv(slot, item), excess);
@@ -280,13 +317,13 @@ struct MgxEnvT {  // per-lane view of one env
     if constexpr (X) { if (d.obj_tags) return (d.obj_tags[so(slot) * MGX_TAG_WORDS + (t >> 5)] >> (t & 31)) & 1u; }
     return ((uint32_t)cls_of(slot)[MGX_C_TAGS + (t >> 5)] >> (t & 31)) & 1u;
   }
-  __device__ __forceinline__ int tag_list(int tag) const { return P[d.sec[MGX_SEC_TAG_LISTS] + tag]; }
-  __device__ __forceinline__ uint16_t* tl_items(int li) const { return d.tl_items + ((size_t)env * d.NL + li) * d.S; }
-  __device__ __forceinline__ uint16_t& tl_count(int li) const { return d.tl_count[(size_t)env * d.NL + li]; }
+  __device__ __forceinline__ int tag_list(int tag) const { return prog()[d.sec[MGX_SEC_TAG_LISTS] + tag]; }
+  __device__ __forceinline__ uint16_t* tl_items(int li) const { return d.tl_items + ((size_t)envi() * d.NL + li) * d.S; }
+  __device__ __forceinline__ uint16_t& tl_count(int li) const { return d.tl_count[(size_t)envi() * d.NL + li]; }
   template <int DEPTH>
   __device__ void fire_tag_handlers(int o, int tag, int start_field, const MgxCtx& c) const {  // grid_object.cpp:83-123
     PP C = cls_of(o);
-    PP th = P + d.sec[MGX_SEC_TAG_HANDLERS] + C[start_field] * MGX_TH_WORDS;
+    PP th = prog() + d.sec[MGX_SEC_TAG_HANDLERS] + C[start_field] * MGX_TH_WORDS;
     for (int i = 0; i < C[start_field + 1]; i++, th += MGX_TH_WORDS) {
       if (th[MGX_TH_TAG] != tag) continue;
       if constexpr (DEPTH > 0) {
@@ -322,8 +359,8 @@ struct MgxEnvT {  // per-lane view of one env
   }
 
   // ---- query workspace ----
-  __device__ __forceinline__ uint16_t* qbuf(int idx) const { return d.qws + ((size_t)env * d.QB + idx) * d.S; }
-  __device__ __forceinline__ uint32_t* qvis(int depth) const { return d.qvis + ((size_t)env * (d.QD + 1) + depth) * d.SW; }
+  __device__ __forceinline__ uint16_t* qbuf(int idx) const { return d.qws + ((size_t)envi() * d.QB + idx) * d.S; }
+  __device__ __forceinline__ uint32_t* qvis(int depth) const { return d.qvis + ((size_t)envi() * (d.QD + 1) + depth) * d.SW; }
   enum { QB_EVENT = 0, QB_LOST = 1, QB_KEEP = 2, QB_BASE = 3 };  // then two buffers per nesting level
 
   // ---- queries (core/query_system.cpp:28-89, 178-330).  Results land in qbuf(QB_BASE + 2*depth); QD bounds the
@@ -335,7 +372,7 @@ struct MgxEnvT {  // per-lane view of one env
   }
   template <int QD>
   __device__ int apply_limits(uint16_t* res, int n, PP Q, const MgxCtx& c, int depth) const {  // :74-89
-    if (Q[MGX_Q_ORDER] & 1) {  // std::shuffle with the env's mt19937 (bits/stl_algo.h:3729-3795)
+    if (Q[MGX_Q_ORDER] & 1) {  // std::shuffle with the envi()'s mt19937 (bits/stl_algo.h:3729-3795)
       if (n >= 2) {
         uint32_t i = 1;
         if ((n & 1) == 0) { uint32_t j = rng_below(2); uint16_t t = res[1]; res[1] = res[j]; res[j] = t; i = 2; }
@@ -358,7 +395,7 @@ struct MgxEnvT {  // per-lane view of one env
       return 0;
     } else {
       if (depth > d.QD) { flag(4u); return 0; }
-      PP Q = P + d.sec[MGX_SEC_QUERIES] + qi * MGX_Q_WORDS;
+      PP Q = prog() + d.sec[MGX_SEC_QUERIES] + qi * MGX_Q_WORDS;
       uint16_t* out = qbuf(QB_BASE + 2 * depth);
       uint16_t* tmp = qbuf(QB_BASE + 2 * depth + 1);
       int n = 0;
@@ -415,7 +452,7 @@ struct MgxEnvT {  // per-lane view of one env
         int ns = eval_query<QD - 1>(a0, c, depth + 1);
         const uint16_t* src = qbuf(QB_BASE + 2 * (depth + 1));
         for (int i = 0; i < ns; i++) tmp[i] = src[i];
-        PP dirs = P + d.sec[MGX_SEC_WORDLIST] + a2;
+        PP dirs = prog() + d.sec[MGX_SEC_WORDLIST] + a2;
         const int blocker_pc = Q[MGX_Q_A4];
         for (int i = 0; i < ns; i++) {
           int s = tmp[i];
@@ -449,14 +486,14 @@ struct MgxEnvT {  // per-lane view of one env
   template <int QD>
   __device__ float eval_code(int start, int count, int entity, const MgxCtx& outer, int depth) const {
     MgxValueStack st;  // registers, not a dynamically indexed array (which the compiler would place in scratch)
-    PP code = P + d.sec[MGX_SEC_GV_CODE] + start * MGX_GV_WORDS;
+    PP code = prog() + d.sec[MGX_SEC_GV_CODE] + start * MGX_GV_WORDS;
     for (int i = 0; i < count; i++, code += MGX_GV_WORDS) {
       int a0 = code[MGX_GV_A0], a1 = code[MGX_GV_A1], a2 = code[MGX_GV_A2];
       switch (code[MGX_GV_OP]) {
         case MGX_GOP_INVENTORY: st.push(entity >= 0 ? (float)inv(entity, a0) : 0.f); break;
         case MGX_GOP_STAT: {
           float v = 0.f;
-          if (a0 == 1) { gstat_touch(a1); v = d.game_stats[(size_t)env * d.NG + a1]; }
+          if (a0 == 1) { gstat_touch(a1); v = d.game_stats[(size_t)envi() * d.NG + a1]; }
           else { int a = agent_of(entity); if (a >= 0) { astat_touch(a, a1); v = astat_get(a, a1); } }
           st.push(v);
           break;
@@ -505,7 +542,7 @@ struct MgxEnvT {  // per-lane view of one env
   }
   template <int QD>
   __device__ float eval_value(int rec, int entity, const MgxCtx& c, int depth) const {
-    PP V = P + d.sec[MGX_SEC_OBS_VALUES] + rec * MGX_OV_WORDS;
+    PP V = prog() + d.sec[MGX_SEC_OBS_VALUES] + rec * MGX_OV_WORDS;
     return eval_code<QD>(V[MGX_OV_GV_START], V[MGX_OV_GV_COUNT], entity, c, depth);
   }
 
@@ -518,7 +555,7 @@ struct MgxEnvT {  // per-lane view of one env
       case MGX_FOP_VIBE: { int e = resolve(c, a0); return e != MGX_SLOT_NONE && (e >= 0 ? (int)d.obj_vibe[so(e)] : 0) == a1; }
       case MGX_FOP_RESOURCE: { int e = resolve(c, a0); return e != MGX_SLOT_NONE && inv_of(e, a1) >= a2; }
       case MGX_FOP_SHARED_TAG: {
-        PP mask = P + d.sec[MGX_SEC_WORDLIST] + a0;
+        PP mask = prog() + d.sec[MGX_SEC_WORDLIST] + a0;
         uint32_t any = 0;
         for (int w = 0; w < MGX_TAG_WORDS; w++) any |= tagword(c.actor, w, c) & tagword(c.target, w, c) & (uint32_t)mask[w];
         return any != 0;
@@ -526,7 +563,7 @@ struct MgxEnvT {  // per-lane view of one env
       case MGX_FOP_TAG: {
         int e = resolve(c, a0);
         if (e == MGX_SLOT_NONE) return false;
-        PP mask = P + d.sec[MGX_SEC_WORDLIST] + a1;
+        PP mask = prog() + d.sec[MGX_SEC_WORDLIST] + a1;
         uint32_t any = 0;
         for (int w = 0; w < MGX_TAG_WORDS; w++) any |= tagword(e, w, c) & (uint32_t)mask[w];
         return any != 0;
@@ -571,7 +608,7 @@ struct MgxEnvT {  // per-lane view of one env
         if constexpr (X && QD > 0) {
           int n = eval_query<QD>(a0, c, depth);
           const uint16_t* res = qbuf(QB_BASE + 2 * depth);
-          PP req = P + d.sec[MGX_SEC_WORDLIST] + a1;
+          PP req = prog() + d.sec[MGX_SEC_WORDLIST] + a1;
           for (int i = 0; i < a2; i++) {
             uint32_t total = 0, need = (uint32_t)req[i * 2 + 1];
             for (int k = 0; k < n; k++) { total += inv(res[k], req[i * 2]); if (total >= need) break; }
@@ -589,7 +626,7 @@ struct MgxEnvT {  // per-lane view of one env
   }
   template <int QD>
   __device__ MGX_BIG bool check_filters(int pc, const MgxCtx& c, int depth) const {  // handler/handler.cpp:95-103
-    PP atoms = P + d.sec[MGX_SEC_ATOMS];
+    PP atoms = prog() + d.sec[MGX_SEC_ATOMS];
     while (pc >= 0) {
       PP a = atoms + pc * MGX_AT_WORDS;
       pc = atom<QD>(a, c, depth) ? a[MGX_AT_ON_TRUE] : a[MGX_AT_ON_FALSE];
@@ -599,14 +636,14 @@ struct MgxEnvT {  // per-lane view of one env
   static constexpr int TOPQ = X ? 3 : 0;  // query nesting available to top-level filter/value evaluation
 
   // ---- grid (core/grid.hpp:75-113) ----
-  __device__ __forceinline__ uint16_t& cell(int r, int c) const { return d.grid[(size_t)env * d.H * d.W + r * d.W + c]; }
+  __device__ __forceinline__ uint16_t& cell(int r, int c) const { return d.grid[(size_t)envi() * d.H * d.W + r * d.W + c]; }
   __device__ void territory_moved(int slot) const {  // TerritoryTracker::notify_source_moved (:187-199)
     if constexpr (X) {
       if (d.NTS == 0) return;
-      uint16_t* to = d.ts_obj + (size_t)env * d.NTS;
-      uint16_t* tc = d.ts_ctrl + (size_t)env * d.NTS;
-      uint16_t* tr = d.ts_rc + (size_t)env * d.NTS;
-      int n = d.ts_count[env];
+      uint16_t* to = d.ts_obj + (size_t)envi() * d.NTS;
+      uint16_t* tc = d.ts_ctrl + (size_t)envi() * d.NTS;
+      uint16_t* tr = d.ts_rc + (size_t)envi() * d.NTS;
+      int n = d.ts_count[envi()];
       // entries of the moved object are re-registered at the END, keeping their relative order
       int mine = 0;
       for (int i = 0; i < n; i++) mine += to[i] == (uint16_t)slot;
@@ -628,9 +665,9 @@ struct MgxEnvT {  // per-lane view of one env
     cell(r, c) = (uint16_t)(slot + 1);
     cell(rc >> 8, rc & 0xFF) = 0;
     d.obj_rc[so(slot)] = (uint16_t)((r << 8) | c);
-    if (al.rc) {
-      if (slot == cur_slot) al.rc[cur_agent * MGX_WAVE + al.lane] = (uint16_t)((r << 8) | c);
-      else { int a = agent_of(slot); if (a >= 0) al.rc[a * MGX_WAVE + al.lane] = (uint16_t)((r << 8) | c); }
+    if (AL().rc) {
+      if (slot == cur_slot) AL().rc[cur_agent * MGX_WAVE + AL().lane] = (uint16_t)((r << 8) | c);
+      else { int a = agent_of(slot); if (a >= 0) AL().rc[a * MGX_WAVE + AL().lane] = (uint16_t)((r << 8) | c); }
     }
     territory_moved(slot);
     return true;
@@ -641,9 +678,9 @@ struct MgxEnvT {  // per-lane view of one env
     if constexpr (!X) { flag(4u); return -1; } else {
       PP C = cls(cls_id);
       if (C[MGX_C_KIND] == MGX_KIND_AGENT) { flag(64u); return -1; }
-      uint32_t n = d.num_objs[env];
+      uint32_t n = d.num_objs[envi()];
       if ((int)n >= d.S) { flag(8u); return -1; }
-      d.num_objs[env] = n + 1;
+      d.num_objs[envi()] = n + 1;
       const int slot = (int)n;
       d.obj_cls[so(slot)] = (uint16_t)cls_id;
       d.obj_rc[so(slot)] = (uint16_t)((r << 8) | c);
@@ -654,7 +691,7 @@ struct MgxEnvT {  // per-lane view of one env
       for (int k = 0; k < d.R; k++) inv(slot, k) = 0;
       d.obj_flags[so(slot)] = 2;  // no ObservationEncoder: inventory is not observable (grid_object.cpp:194)
       cell(r, c) = (uint16_t)(slot + 1);
-      PP ii = P + d.sec[MGX_SEC_INIT_INV] + C[MGX_C_INIT_INV_START] * MGX_II_WORDS;
+      PP ii = prog() + d.sec[MGX_SEC_INIT_INV] + C[MGX_C_INIT_INV_START] * MGX_II_WORDS;
       for (int i = 0; i < C[MGX_C_INIT_INV_COUNT]; i++, ii += MGX_II_WORDS) inv_update<0>(slot, ii[MGX_II_ITEM], ii[MGX_II_AMOUNT], true, true);
       for (int w = 0; w < MGX_TAG_WORDS; w++) d.obj_tags[so(slot) * MGX_TAG_WORDS + w] = (uint32_t)C[MGX_C_TAGS + w];
       for (int t = 0; t < 256 && d.NL > 0; t++) {
@@ -662,7 +699,7 @@ struct MgxEnvT {  // per-lane view of one env
         int li = tag_list(t);
         if (li >= 0) { uint16_t k = tl_count(li); if (k < d.S) { tl_items(li)[k] = (uint16_t)slot; tl_count(li) = k + 1; } }
       }
-      if (C[MGX_C_AOE_COUNT] > 0) { uint16_t k = d.def_count[env]; d.def_aoe[(size_t)env * d.S + k] = (uint16_t)slot; d.def_count[env] = k + 1; }
+      if (C[MGX_C_AOE_COUNT] > 0) { uint16_t k = d.def_count[envi()]; d.def_aoe[(size_t)envi() * d.S + k] = (uint16_t)slot; d.def_count[envi()] = k + 1; }
       return slot;
     }
   }
@@ -671,27 +708,27 @@ struct MgxEnvT {  // per-lane view of one env
     for (int i = 0; i < C[MGX_C_AOE_COUNT]; i++) {
       int a = C[MGX_C_AOE_START] + i;
       if (aoe(a)[MGX_AO_STATIC]) {
-        uint16_t n = d.fx_count[env];
+        uint16_t n = d.fx_count[envi()];
         if (n >= d.NF) { flag(8u); continue; }
-        size_t q = (size_t)env * d.NF + n;
+        size_t q = (size_t)envi() * d.NF + n;
         d.fx_obj[q] = (uint16_t)slot; d.fx_aoe[q] = (uint16_t)a; d.fx_rc[q] = d.obj_rc[so(slot)];
         for (int w = 0; w < d.AW; w++) d.fx_inside[q * d.AW + w] = 0;
-        d.fx_count[env] = n + 1;
+        d.fx_count[envi()] = n + 1;
       } else {
-        uint16_t n = d.mb_count[env];
+        uint16_t n = d.mb_count[envi()];
         if (n >= d.NM) { flag(8u); continue; }
-        size_t q = (size_t)env * d.NM + n;
+        size_t q = (size_t)envi() * d.NM + n;
         d.mb_obj[q] = (uint16_t)slot; d.mb_aoe[q] = (uint16_t)a;
         for (int w = 0; w < d.AW; w++) d.mb_inside[q * d.AW + w] = 0;
-        d.mb_count[env] = n + 1;
+        d.mb_count[envi()] = n + 1;
       }
     }
   }
   __device__ void remove_object(int slot) const {  // resource_mutation.hpp:88-97
     if (agent_of(slot) >= 0) { flag(64u); return; }
     if (d.NF) {
-      const size_t fb = (size_t)env * d.NF;
-      for (int f = 0; f < d.fx_count[env]; f++) {
+      const size_t fb = (size_t)envi() * d.NF;
+      for (int f = 0; f < d.fx_count[envi()]; f++) {
         if (d.fx_obj[fb + f] != (uint16_t)slot) continue;
         PP a = aoe(d.fx_aoe[fb + f]);
         for (int ai = 0; ai < d.A; ai++) {
@@ -702,8 +739,8 @@ struct MgxEnvT {  // per-lane view of one env
       }
     }
     if (d.NM) {
-      const size_t mb = (size_t)env * d.NM;
-      for (int f = 0; f < d.mb_count[env]; f++) {
+      const size_t mb = (size_t)envi() * d.NM;
+      for (int f = 0; f < d.mb_count[envi()]; f++) {
         if (d.mb_obj[mb + f] != (uint16_t)slot) continue;
         PP a = aoe(d.mb_aoe[mb + f]);
         for (int ai = 0; ai < d.A; ai++) {
@@ -771,7 +808,7 @@ struct MgxEnvT {  // per-lane view of one env
             inv_update<1>(e, item, -(int)inv(e, item));
           }
         } else {
-          PP ids = P + d.sec[MGX_SEC_WORDLIST] + a1;
+          PP ids = prog() + d.sec[MGX_SEC_WORDLIST] + a1;
           for (int i = 0; i < a2; i++) inv_update<1>(e, ids[i], -(int)inv(e, ids[i]));
         }
         break;
@@ -800,7 +837,7 @@ struct MgxEnvT {  // per-lane view of one env
         cell(ry >> 8, ry & 0xFF) = (uint16_t)(c.actor + 1);
         d.obj_rc[so(c.actor)] = ry;
         d.obj_rc[so(c.target)] = rx;
-        if (al.rc) { al.rc[xa * MGX_WAVE + al.lane] = ry; al.rc[ya * MGX_WAVE + al.lane] = rx; }
+        if (AL().rc) { AL().rc[xa * MGX_WAVE + AL().lane] = ry; AL().rc[ya * MGX_WAVE + AL().lane] = rx; }
         territory_moved(c.actor);  // on_object_moved twice (core/grid.hpp:100-103)
         territory_moved(c.target);
         astat_add(xa, mgx_wk(d, MGX_S_SWAP), 1.f);
@@ -834,15 +871,15 @@ struct MgxEnvT {  // per-lane view of one env
       case MGX_MOP_REMOVE_TAG: remove_tag<DEPTH>(resolve(c, a0), a1, c); break;  // :32-45
       case MGX_MOP_REMOVE_TAGS_PREFIX: {                                         // :47-67
         int e = resolve(c, a0);
-        PP ids = P + d.sec[MGX_SEC_WORDLIST] + a1;
+        PP ids = prog() + d.sec[MGX_SEC_WORDLIST] + a1;
         for (int i = 0; i < a2; i++) remove_tag<DEPTH>(e, ids[i], c);
         break;
       }
       case MGX_MOP_GAME_VALUE: {  // game_value_mutation.hpp:21-27 (a0 target entity, a1 value, a2 source)
         int e = resolve(c, a0);
         float delta = eval_value<TOPQ>(a2, e, c, 0);
-        PP V = P + d.sec[MGX_SEC_OBS_VALUES] + a1 * MGX_OV_WORDS;
-        PP code = P + d.sec[MGX_SEC_GV_CODE] + V[MGX_OV_GV_START] * MGX_GV_WORDS;
+        PP V = prog() + d.sec[MGX_SEC_OBS_VALUES] + a1 * MGX_OV_WORDS;
+        PP code = prog() + d.sec[MGX_SEC_GV_CODE] + V[MGX_OV_GV_START] * MGX_GV_WORDS;
         if (code[MGX_GV_OP] == MGX_GOP_INVENTORY) {
           if (e >= 0) inv_update<1>(e, code[MGX_GV_A0], (int)delta);
         } else if (code[MGX_GV_OP] == MGX_GOP_STAT) {
@@ -874,7 +911,7 @@ struct MgxEnvT {  // per-lane view of one env
         tc.actor = c.target;
         int range = (int)eval_value<TOPQ>(a3, c.target, tc, 0);
         if (range <= 0) break;
-        PP dirs = P + d.sec[MGX_SEC_WORDLIST] + a1;
+        PP dirs = prog() + d.sec[MGX_SEC_WORDLIST] + a1;
         const int blocker_pc = m[MGX_MU_A4];
         for (int k = 0; k < a2; k++)
           for (int dist = 1; dist <= range; dist++) {
@@ -894,8 +931,8 @@ struct MgxEnvT {  // per-lane view of one env
       case MGX_MOP_QUERY_INVENTORY: {  // query_inventory_mutation.hpp:26-52
         int n = eval_query<TOPQ>(a0, c, 0);
         const uint16_t* res = qbuf(QB_BASE);
-        PP dl = P + d.sec[MGX_SEC_WORDLIST] + a1;
-        PP sn = P + d.sec[MGX_SEC_WORDLIST] + m[MGX_MU_A4];
+        PP dl = prog() + d.sec[MGX_SEC_WORDLIST] + a1;
+        PP sn = prog() + d.sec[MGX_SEC_WORDLIST] + m[MGX_MU_A4];
         int nsn = m[MGX_MU_PAD0];
         if (a3 >= 0) {
           int srcobj = resolve(c, a3);
@@ -925,7 +962,7 @@ struct MgxEnvT {  // per-lane view of one env
     uint16_t* lost = qbuf(QB_LOST);
     uint16_t* keep = qbuf(QB_KEEP);
     int nl = 0, nk = 0;
-    PP mq = P + d.sec[MGX_SEC_MATQ];
+    PP mq = prog() + d.sec[MGX_SEC_MATQ];
     for (int i = 0; i < d.n_matq; i++, mq += MGX_MQ_WORDS) {
       if (mq[MGX_MQ_TAG] != tag) continue;
       int li = tag_list(tag);
@@ -960,11 +997,11 @@ struct MgxEnvT {  // per-lane view of one env
   // DEPTH bounds nesting (multi -> leaf -> use_target -> on_use multi -> leaf); exceeded depth raises MGX_ENV_DEPTH.
   template <int DEPTH>
   __device__ MGX_BIG bool apply_handler(int h, MgxCtx& c) const {
-    PP hd = P + d.sec[MGX_SEC_HANDLERS] + h * MGX_HD_WORDS;
+    PP hd = prog() + d.sec[MGX_SEC_HANDLERS] + h * MGX_HD_WORDS;
     if (hd[MGX_HD_KIND] == MGX_HK_LEAF) {
       if (!check_filters<TOPQ>(hd[MGX_HD_FILTER_PC], c, 0)) return false;
       c.mutation_failed = false;
-      PP m = P + d.sec[MGX_SEC_MUTS] + hd[MGX_HD_MUT_START] * MGX_MU_WORDS;
+      PP m = prog() + d.sec[MGX_SEC_MUTS] + hd[MGX_HD_MUT_START] * MGX_MU_WORDS;
       for (int i = 0; i < hd[MGX_HD_MUT_COUNT]; i++, m += MGX_MU_WORDS) {
         mutate<DEPTH>(m, c);
         if (c.mutation_failed) return false;
@@ -973,7 +1010,7 @@ struct MgxEnvT {  // per-lane view of one env
     }
     bool any = false;
     if constexpr (DEPTH > 0) {
-      PP kids = P + d.sec[MGX_SEC_CHILDREN] + hd[MGX_HD_CHILD_START];
+      PP kids = prog() + d.sec[MGX_SEC_CHILDREN] + hd[MGX_HD_CHILD_START];
       bool first = hd[MGX_HD_KIND] == MGX_HK_FIRST_MATCH;
       for (int i = 0; i < hd[MGX_HD_CHILD_COUNT]; i++) {
         if (apply_handler<DEPTH - 1>(kids[i], c)) {
@@ -990,7 +1027,7 @@ struct MgxEnvT {  // per-lane view of one env
   // handler/event.cpp:86-92, core/aoe_tracker.cpp:99-113, core/territory_tracker.cpp:62-66).
   __device__ MGX_BIG bool apply_all(int filter_pc, int mut_start, int mut_count, MgxCtx& c) const {
     if (!check_filters<TOPQ>(filter_pc, c, 0)) return false;
-    PP m = P + d.sec[MGX_SEC_MUTS] + mut_start * MGX_MU_WORDS;
+    PP m = prog() + d.sec[MGX_SEC_MUTS] + mut_start * MGX_MU_WORDS;
     for (int i = 0; i < mut_count; i++, m += MGX_MU_WORDS) mutate<2>(m, c);
     return true;
   }
@@ -998,7 +1035,7 @@ struct MgxEnvT {  // per-lane view of one env
   // ---- events (handler/event.cpp:34-101, handler/event_scheduler.cpp:36-53) ----
   __device__ int execute_event(int ev) const {
     for (int hop = 0; hop < 8; hop++) {  // fallback chain
-      PP E = P + d.sec[MGX_SEC_EVENTS] + ev * MGX_EV_WORDS;
+      PP E = prog() + d.sec[MGX_SEC_EVENTS] + ev * MGX_EV_WORDS;
       MgxCtx g = mgx_ctx(MGX_SLOT_NONE, MGX_SLOT_NONE);
       int n = eval_query<TOPQ>(E[MGX_EV_QUERY], g, 0);
       uint16_t* targets = qbuf(QB_EVENT);
@@ -1032,17 +1069,17 @@ struct MgxEnvT {  // per-lane view of one env
     return 0;
   }
   __device__ void process_events() const {
-    PP sc = P + d.sec[MGX_SEC_SCHEDULE];
-    uint32_t k = d.next_event[env];
+    PP sc = prog() + d.sec[MGX_SEC_SCHEDULE];
+    uint32_t k = d.next_event[envi()];
     while (k < (uint32_t)d.n_schedule && (uint32_t)sc[k * MGX_SC_WORDS + MGX_SC_TIMESTEP] <= step) {
       execute_event(sc[k * MGX_SC_WORDS + MGX_SC_EVENT]);
       k++;
     }
-    d.next_event[env] = k;
+    d.next_event[envi()] = k;
   }
 
   // ---- AoE (core/aoe_tracker.cpp) ----
-  __device__ __forceinline__ PP aoe(int a) const { return P + d.sec[MGX_SEC_AOES] + a * MGX_AO_WORDS; }
+  __device__ __forceinline__ PP aoe(int a) const { return prog() + d.sec[MGX_SEC_AOES] + a * MGX_AO_WORDS; }
   __device__ bool fixed_covers(PP a, uint16_t src_rc, int r, int c) const {  // register_fixed :166-200
     long long range = a[MGX_AO_RADIUS], dr = r - (int)(src_rc >> 8), dc = c - (int)(src_rc & 0xFF);
     if (dr < -range || dr > range || dc < -range || dc > range) return false;
@@ -1053,16 +1090,16 @@ struct MgxEnvT {  // per-lane view of one env
     return true;
   }
   __device__ void presence(PP a, int target, int mult) const {  // apply_presence_deltas :122-126
-    PP pr = P + d.sec[MGX_SEC_PRESENCE] + a[MGX_AO_PRES_START] * MGX_PR_WORDS;
+    PP pr = prog() + d.sec[MGX_SEC_PRESENCE] + a[MGX_AO_PRES_START] * MGX_PR_WORDS;
     for (int i = 0; i < a[MGX_AO_PRES_COUNT]; i++, pr += MGX_PR_WORDS) inv_update<1>(target, pr[MGX_PR_RESOURCE], pr[MGX_PR_DELTA] * mult);
   }
   __device__ void apply_fixed(int ai) const {  // :278-362
-    const int nf = d.NF ? d.fx_count[env] : 0;
+    const int nf = d.NF ? d.fx_count[envi()] : 0;
     if (nf == 0) return;
     const int tgt = d.ag_obj[ao(ai)];
     const uint16_t rc = d.obj_rc[so(tgt)];
     const int r = rc >> 8, c = rc & 0xFF;
-    const size_t fb = (size_t)env * d.NF;
+    const size_t fb = (size_t)envi() * d.NF;
     xl.def_delta[13 * xl.stride + xl.lane] = 0;  // seen mask
     xl.def_delta[14 * xl.stride + xl.lane] = 0;  // count
     // exits first.  The reference walks an unordered_set<AOESource*> here (address order); registration order is used.
@@ -1101,8 +1138,8 @@ struct MgxEnvT {  // per-lane view of one env
     }
   }
   __device__ void apply_mobile() const {  // :364-415
-    const int nm = d.NM ? d.mb_count[env] : 0;
-    const size_t mb = (size_t)env * d.NM;
+    const int nm = d.NM ? d.mb_count[envi()] : 0;
+    const size_t mb = (size_t)envi() * d.NM;
     for (int m = 0; m < nm; m++) {
       if (d.mb_obj[mb + m] == 0xFFFF) continue;
       PP a = aoe(d.mb_aoe[mb + m]);
@@ -1133,16 +1170,16 @@ struct MgxEnvT {  // per-lane view of one env
 
   // ---- territory (core/territory_tracker.cpp) ----
   __device__ int cell_owner(int r, int c, int ti) const {  // compute_cell_ownership :215-252 -> winning tag or -1
-    PP TE = P + d.sec[MGX_SEC_TERRITORIES] + ti * MGX_TE_WORDS;
-    PP prefix = P + d.sec[MGX_SEC_WORDLIST] + TE[MGX_TE_TAGS_START];
+    PP TE = prog() + d.sec[MGX_SEC_TERRITORIES] + ti * MGX_TE_WORDS;
+    PP prefix = prog() + d.sec[MGX_SEC_WORDLIST] + TE[MGX_TE_TAGS_START];
     const int np = min(TE[MGX_TE_TAGS_COUNT], 8);
     if (TE[MGX_TE_TAGS_COUNT] > 8) flag(4u);
     long long* score = xl.terr_score + xl.lane;
     for (int k = 0; k < np; k++) score[k * xl.stride] = 0;
-    const size_t tb = (size_t)env * d.NTS;
-    const int n = d.ts_count[env];
+    const size_t tb = (size_t)envi() * d.NTS;
+    const int n = d.ts_count[envi()];
     for (int i = 0; i < n; i++) {
-      PP tc = P + d.sec[MGX_SEC_TERR_CONTROLS] + d.ts_ctrl[tb + i] * MGX_TC_WORDS;
+      PP tc = prog() + d.sec[MGX_SEC_TERR_CONTROLS] + d.ts_ctrl[tb + i] * MGX_TC_WORDS;
       if (tc[MGX_TC_TERRITORY] != ti) continue;
       const int strength = tc[MGX_TC_STRENGTH], decay = tc[MGX_TC_DECAY];
       const long long range = decay > 0 ? strength / decay : strength;
@@ -1177,7 +1214,7 @@ struct MgxEnvT {  // per-lane view of one env
   }
   __device__ void run_territory_handlers(int start, int count, int tag, int tgt) const {
     for (int i = 0; i < count; i++) {
-      PP hd = P + d.sec[MGX_SEC_HANDLERS] + (start + i) * MGX_HD_WORDS;
+      PP hd = prog() + d.sec[MGX_SEC_HANDLERS] + (start + i) * MGX_HD_WORDS;
       MgxCtx c = mgx_ctx(MGX_SLOT_PROXY, tgt);
       c.proxy_tag = tag;
       uint16_t rc = d.obj_rc[so(tgt)];
@@ -1188,7 +1225,7 @@ struct MgxEnvT {  // per-lane view of one env
   __device__ void apply_territory(int ai) const {  // apply_effects :275-346
     const int tgt = d.ag_obj[ao(ai)];
     for (int ti = 0; ti < d.NT; ti++) {
-      PP TE = P + d.sec[MGX_SEC_TERRITORIES] + ti * MGX_TE_WORDS;
+      PP TE = prog() + d.sec[MGX_SEC_TERRITORIES] + ti * MGX_TE_WORDS;
       uint16_t rc = d.obj_rc[so(tgt)];
       int cur = cell_owner(rc >> 8, rc & 0xFF, ti);
       int16_t& pv = d.terr_prev[ao(ai) * d.NT + ti];
@@ -1204,9 +1241,9 @@ struct MgxEnvT {  // per-lane view of one env
   __device__ MGX_BIG bool do_move(int slot, int orient) const {  // actions/move.hpp:81-115, orientation.hpp:28-48
     const int dx = (orient == 2 || orient == 4 || orient == 6) ? -1 : (orient == 3 || orient == 5 || orient == 7) ? 1 : 0;
     const int dy = (orient == 0 || orient == 4 || orient == 5) ? -1 : (orient == 1 || orient == 6 || orient == 7) ? 1 : 0;
-    PP mh = P + d.sec[MGX_SEC_MOVE_HANDLERS];
+    PP mh = prog() + d.sec[MGX_SEC_MOVE_HANDLERS];
     for (int k = 0; k < d.n_move_handlers; k++, mh += MGX_MH_WORDS) {
-      uint16_t rc = (al.rc && slot == cur_slot) ? al.rc[cur_agent * MGX_WAVE + al.lane] : d.obj_rc[so(slot)];
+      uint16_t rc = (AL().rc && slot == cur_slot) ? AL().rc[cur_agent * MGX_WAVE + AL().lane] : d.obj_rc[so(slot)];
       for (int i = 1; i <= mh[MGX_MH_MAX_RANGE]; i++) {
         int r = (rc >> 8) + dy * i, c = (rc & 0xFF) + dx * i;
         if (r < 0 || c < 0 || r >= d.H || c >= d.W) break;
@@ -1221,10 +1258,10 @@ struct MgxEnvT {  // per-lane view of one env
     return false;
   }
   __device__ MGX_BIG bool handle_action(int ai, int action) const {  // actions/action_handler.hpp:78-105
-    PP ac = P + d.sec[MGX_SEC_ACTIONS] + action * MGX_AC_WORDS;
+    PP ac = prog() + d.sec[MGX_SEC_ACTIONS] + action * MGX_AC_WORDS;
     int kind = ac[MGX_AC_KIND];
-    const int li = ai * MGX_WAVE + al.lane;
-    int slot = al.slot ? (int)al.slot[li] : (int)d.ag_obj[ao(ai)];
+    const int li = ai * MGX_WAVE + AL().lane;
+    int slot = AL().slot ? (int)AL().slot[li] : (int)d.ag_obj[ao(ai)];
     cur_agent = ai;
     cur_slot = slot;
     bool ok = true;
@@ -1232,18 +1269,18 @@ struct MgxEnvT {  // per-lane view of one env
     if (kind == MGX_AK_MOVE) ok = do_move(slot, ac[MGX_AC_ARG]);
     else if (kind == MGX_AK_VIBE) d.obj_vibe[so(slot)] = (uint8_t)ac[MGX_AC_ARG];  // actions/change_vibe.hpp:48-57
     MGX_TICK(6);
-    uint16_t rc = al.rc ? al.rc[li] : d.obj_rc[so(slot)];
-    uint16_t prev = al.prev ? al.prev[li] : d.ag_prev[ao(ai)];
+    uint16_t rc = AL().rc ? AL().rc[li] : d.obj_rc[so(slot)];
+    uint16_t prev = AL().prev ? AL().prev[li] : d.ag_prev[ao(ai)];
     if (rc == prev) {
-      uint32_t swm = (al.swm ? al.swm[li] : d.ag_swm[ao(ai)]) + 1;
-      if (al.swm) al.swm[li] = swm;
+      uint32_t swm = (AL().swm ? AL().swm[li] : d.ag_swm[ao(ai)]) + 1;
+      if (AL().swm) AL().swm[li] = swm;
       d.ag_swm[ao(ai)] = swm;
       int sid = mgx_wk(d, MGX_S_MAX_STEPS_WITHOUT_MOTION);
       if ((float)swm > astat_get(ai, sid)) astat_set(ai, sid, (float)swm);
     } else {
-      if (al.swm) al.swm[li] = 0;
+      if (AL().swm) AL().swm[li] = 0;
       d.ag_swm[ao(ai)] = 0;
-      if (al.prev) al.prev[li] = rc;
+      if (AL().prev) AL().prev[li] = rc;
       d.ag_prev[ao(ai)] = rc;
     }
     cur_agent = cur_slot = -1;
@@ -1255,7 +1292,7 @@ struct MgxEnvT {  // per-lane view of one env
   }
 
   __device__ MGX_BIG void track_coverage(int ai) const {  // objects/agent.cpp:49-57
-    uint16_t rc = al.rc ? al.rc[ai * MGX_WAVE + al.lane] : d.obj_rc[so(d.ag_obj[ao(ai)])];
+    uint16_t rc = AL().rc ? AL().rc[ai * MGX_WAVE + AL().lane] : d.obj_rc[so(d.ag_obj[ao(ai)])];
     // Unchanged position since the last call => the set is unchanged and both stats.set() calls would store the
     // values they already hold (keys exist since Agent::init): nothing to do.
     if (rc == d.ag_covrc[ao(ai)]) return;
@@ -1275,14 +1312,14 @@ struct MgxEnvT {  // per-lane view of one env
 
   // ---- std::mt19937 + libstdc++ uniform_int_distribution / shuffle ----
   __device__ __forceinline__ uint32_t rng_next() const {  // incremental twist: identical stream to the batch _M_gen_rand
-    uint32_t i = d.mt_idx[env];
+    uint32_t i = d.mt_idx[envi()];
     uint32_t i1 = i + 1 == 624 ? 0 : i + 1;
     uint32_t im = i + 397 >= 624 ? i + 397 - 624 : i + 397;
     size_t E = (size_t)d.E;
-    uint32_t y = (d.mt[i * E + env] & 0x80000000u) | (d.mt[i1 * E + env] & 0x7fffffffu);
-    uint32_t x = d.mt[im * E + env] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
-    d.mt[i * E + env] = x;
-    d.mt_idx[env] = i1;
+    uint32_t y = (d.mt[i * E + envi()] & 0x80000000u) | (d.mt[i1 * E + envi()] & 0x7fffffffu);
+    uint32_t x = d.mt[im * E + envi()] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    d.mt[i * E + envi()] = x;
+    d.mt_idx[envi()] = i1;
     x ^= x >> 11;
     x ^= (x << 7) & 0x9d2c5680u;
     x ^= (x << 15) & 0xefc60000u;
@@ -1357,7 +1394,7 @@ __device__ __forceinline__ void mgx_world_body(const MgxDev& d, PP P, uint8_t* o
       }
     }
   }
-  e.al = al;
+  e.al_ = al;
   MGX_TICK(0);
   // std::shuffle (bits/stl_algo.h:3729-3795): one draw for an even n, then paired draws
   if (A >= 2) {
@@ -1441,64 +1478,43 @@ __device__ __forceinline__ void mgx_world_body(const MgxDev& d, PP P, uint8_t* o
 }
 
 // PROG_LDS: the program blob is first copied into LDS (16-byte coalesced loads) and every table lookup of the
-// handler VM becomes a ds_read.  Dynamic LDS: order u8[A][64] | [X: deferred i32[28][64] | territory i64[8][64]] |
-// program i32[prog_words].
-__host__ __device__ inline int mgx_world_lds_fixed(int A, bool X) {
-  int o = ((A * MGX_WAVE + 15) & ~15) + ((mgx_world_alds_bytes(A) + 15) & ~15);
-  if (X) o += 28 * MGX_WAVE * 4 + 8 * MGX_WAVE * 8;
-  return o;
-}
-// lpw = envs (active lanes) per wavefront.  The interpreter is a chain of dependent loads, so what bounds it is how
-// many wavefronts each SIMD can switch between, not lane utilisation: a workgroup always owns 64 envs, spread over
-// 64/lpw wavefronts that use their first lpw lanes.  LDS arrays stay [k][64] indexed by the env's index in the group.
+// handler VM becomes a ds_read.
 template <bool PROG_LDS, bool X>
-__device__ __forceinline__ void mgx_world_entry(const MgxDev& d, int prog_words, int lpw) {
-  extern __shared__ __align__(16) uint8_t wsmem[];
-  uint8_t* order = wsmem;
-  const int wl = threadIdx.x & (MGX_WAVE - 1);
-  const int lane = (threadIdx.x >> 6) * lpw + wl;
-  const bool active = wl < lpw;
+__device__ __forceinline__ void mgx_world_entry(const MgxDev& d, int prog_words) {
+  uint8_t* order = mgx_dyn_lds;
+  const int lane = threadIdx.x;
   const int env = blockIdx.x * MGX_WAVE + lane;
   MgxXLds xl;
   xl.lane = lane;
   xl.stride = MGX_WAVE;
-  int off = (d.A * MGX_WAVE + 15) & ~15;
-  MgxALds al;
-  al.lane = lane; al.A = d.A;
-  al.swm = (uint32_t*)(wsmem + off);                 // u32 [A][64]
-  al.act = (int16_t*)(wsmem + off + d.A * MGX_WAVE * 4);   // i16 [2][A][64]
-  al.slot = (uint16_t*)(wsmem + off + d.A * MGX_WAVE * 8);
-  al.rc = al.slot + d.A * MGX_WAVE;
-  al.prev = al.rc + d.A * MGX_WAVE;
-  off += (mgx_world_alds_bytes(d.A) + 15) & ~15;
+  const MgxALds al = mgx_world_alds(mgx_dyn_lds, d.A, lane);
+  int off = ((d.A * MGX_WAVE + 15) & ~15) + ((mgx_world_alds_bytes(d.A) + 15) & ~15);
   if (X) {
-    xl.def_delta = (int*)(wsmem + off);
+    xl.def_delta = (int*)(mgx_dyn_lds + off);
     off += 28 * MGX_WAVE * 4;
-    xl.terr_score = (long long*)(wsmem + off);
+    xl.terr_score = (long long*)(mgx_dyn_lds + off);
     off += 8 * MGX_WAVE * 8;
   } else {
     xl.def_delta = nullptr;
     xl.terr_score = nullptr;
   }
   if (PROG_LDS) {
-    int32_t* lprog = (int32_t*)(wsmem + off);
+    int32_t* lprog = (int32_t*)(mgx_dyn_lds + off);
     const int4* src = (const int4*)d.P;
     int4* dst = (int4*)lprog;
     for (int i = threadIdx.x; i < prog_words / 4; i += blockDim.x) dst[i] = src[i];
     __syncthreads();
-    if (!active || env >= d.E) return;
+    if (env >= d.E) return;
     mgx_world_body<MgxLdsProg, X>(d, (MgxLdsProg)lprog, order, xl, al, lane, env);
   } else {
-    if (!active || env >= d.E) return;
+    if (env >= d.E) return;
     mgx_world_body<MgxGlobalProg, X>(d, d.P, order, xl, al, lane, env);
   }
 }
 
-#define MGX_WORLD_MAX_THREADS 512  // lpw >= 8
 
-// Host launcher of the non-extended world kernels (defined in mgx_world_fast.hip).  wpe = 0 or a waves-per-SIMD
-// occupancy target the kernel variant was compiled for (VGPR budget 512 / wpe).
-void mgx_launch_world_fast(bool prog_lds, int wpe, int lpw, size_t lds, hipStream_t stream, const MgxDev& d, int prog_words);
+// Host launcher of the non-extended world kernels (defined in mgx_world_fast.hip).
+void mgx_launch_world_fast(bool prog_lds, size_t lds, hipStream_t stream, const MgxDev& d, int prog_words);
 
 #ifndef MGX_WORLD_FAST_TU
 // Construction: MettaGrid ctor + _init_grid (mettagrid_c.cpp:42-191, 200-269).  One lane per env scans the class

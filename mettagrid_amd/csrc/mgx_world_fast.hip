@@ -6,6 +6,7 @@
 #endif
 #define MGX_WORLD_FAST_TU 1
 #define MGX_CONST_DEV 1
+#define MGX_WORLD_IDS 1
 #include <hip/hip_runtime.h>
 
 #include <cstring>
@@ -15,8 +16,8 @@
 #include "mgx_world.h"
 
 template <bool PROG_LDS>
-__global__ void __launch_bounds__(MGX_WORLD_MAX_THREADS) mgx_world_kernel_fast(int prog_words, int lpw) {
-  mgx_world_entry<PROG_LDS, false>(g_mgx_dev, prog_words, lpw);
+__global__ void __launch_bounds__(MGX_WAVE) mgx_world_kernel_fast(int prog_words) {
+  mgx_world_entry<PROG_LDS, false>(g_mgx_dev, prog_words);
 }
 
 // Keeps g_mgx_dev equal to the launching engine's MgxDev.  The symbol is shared by every engine of the process, so a
@@ -25,8 +26,7 @@ static std::mutex g_dev_mutex;
 static MgxDev g_dev_host;
 static bool g_dev_valid = false;
 
-void mgx_launch_world_fast(bool prog_lds, int wpe, int lpw, size_t lds, hipStream_t stream, const MgxDev& d, int prog_words) {
-  (void)wpe;
+void mgx_launch_world_fast(bool prog_lds, size_t lds, hipStream_t stream, const MgxDev& d, int prog_words) {
   std::lock_guard<std::mutex> lock(g_dev_mutex);
   if (!g_dev_valid || memcmp(&g_dev_host, &d, sizeof(MgxDev)) != 0) {
     if (g_dev_valid) (void)hipDeviceSynchronize();  // kernels of another engine (or older buffers) may still read it
@@ -34,9 +34,9 @@ void mgx_launch_world_fast(bool prog_lds, int wpe, int lpw, size_t lds, hipStrea
     memcpy(&g_dev_host, &d, sizeof(MgxDev));
     g_dev_valid = true;
   }
-  dim3 grid((d.E + MGX_WAVE - 1) / MGX_WAVE), block(MGX_WAVE * (MGX_WAVE / lpw));
-  if (prog_lds) hipLaunchKernelGGL((mgx_world_kernel_fast<true>), grid, block, lds, stream, prog_words, lpw);
-  else hipLaunchKernelGGL((mgx_world_kernel_fast<false>), grid, block, lds, stream, prog_words, lpw);
+  dim3 grid((d.E + MGX_WAVE - 1) / MGX_WAVE), block(MGX_WAVE);
+  if (prog_lds) hipLaunchKernelGGL((mgx_world_kernel_fast<true>), grid, block, lds, stream, prog_words);
+  else hipLaunchKernelGGL((mgx_world_kernel_fast<false>), grid, block, lds, stream, prog_words);
 }
 
 #ifdef MGX_WORLD_TIMING
