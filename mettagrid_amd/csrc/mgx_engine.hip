@@ -320,7 +320,7 @@ int mgx_create(const int32_t* program, size_t program_words, const uint16_t* cla
   d.actions = e->own_act; d.vibe_actions = e->own_vact;
 
   e->lds_world = (size_t)mgx_world_lds_fixed(d.A, d.X != 0);
-  e->prog_in_lds = program_words * 4 + e->lds_world <= 39 * 1024;  // 4 workgroups per CU (160 KB LDS) keep their copy
+  e->prog_in_lds = program_words * 4 + e->lds_world <= 40 * 1024;  // 4 workgroups per CU (160 KB LDS) keep their copy
   if (e->prog_in_lds) e->lds_world += program_words * 4;
   if (getenv("MGX_VERBOSE"))
     fprintf(stderr, "[mgx] E=%d A=%d S=%d program=%zu B world: X=%d prog_in_lds=%d lds=%zu B\n", d.E, d.A, d.S,

@@ -54,6 +54,7 @@ struct MgxALds {
   uint16_t* prev;
   uint32_t* swm;
   int16_t* act;   // [2][A][64] action ids, saturated to int16 (see mgx_sat16)
+  uint16_t* cls;  // [A][64] class of the agent's object (fixed for the episode)
   int lane, A;
 };
 // MGX_WORLD_TIMING (debug builds only): per-phase shader-clock totals of lane 0 of every wavefront.
@@ -77,8 +78,8 @@ MGX_DBG_LINKAGE __device__ unsigned long long mgx_dbg_cycles[16];
 #define MGX_BIG
 #endif
 
-__host__ __device__ inline int mgx_world_alds_bytes(int A) { return A * MGX_WAVE * (2 + 2 + 2 + 4 + 4); }
-// Dynamic LDS of the world kernels: order u8[A][64] | swm u32[A][64] | act i16[2][A][64] | slot, rc, prev u16[A][64] |
+__host__ __device__ inline int mgx_world_alds_bytes(int A) { return A * MGX_WAVE * (2 + 2 + 2 + 2 + 4 + 4); }
+// Dynamic LDS of the world kernels: order u8[A][64] | swm u32[A][64] | act i16[2][A][64] | slot, rc, prev, cls u16[A][64] |
 // [X: deferred i32[28][64] | territory i64[8][64]] | program i32[prog_words] (when it fits).
 __host__ __device__ inline int mgx_world_lds_fixed(int A, bool X) {
   int o = ((A * MGX_WAVE + 15) & ~15) + ((mgx_world_alds_bytes(A) + 15) & ~15);
@@ -95,6 +96,7 @@ __device__ __forceinline__ MgxALds mgx_world_alds(uint8_t* lds, int A, int lane)
   al.slot = (uint16_t*)(lds + off + A * MGX_WAVE * 8);
   al.rc = al.slot + A * MGX_WAVE;
   al.prev = al.rc + A * MGX_WAVE;
+  al.cls = al.prev + A * MGX_WAVE;
   return al;
 }
 
@@ -132,7 +134,7 @@ struct MgxEnvT {  // per-lane view of one env
 #else
   __device__ MgxEnvT(const MgxDev& dd, PP prog, int e) : d(dd), P_(prog), env_(e), step(0), cur_agent(-1), cur_slot(-1) {
 #endif
-    al_.slot = nullptr; al_.rc = nullptr; al_.prev = nullptr; al_.swm = nullptr; al_.act = nullptr; al_.lane = 0; al_.A = 0;
+    al_.slot = nullptr; al_.rc = nullptr; al_.prev = nullptr; al_.swm = nullptr; al_.act = nullptr; al_.cls = nullptr; al_.lane = 0; al_.A = 0;
     xl.def_delta = nullptr; xl.terr_score = nullptr; xl.lane = 0; xl.stride = MGX_WAVE; }
   // MGX_WORLD_IDS (the lane-per-env world kernel's own translation unit): env index, program base and the LDS agent
   // staging are recomputed from the work-item ids and constant memory wherever they are needed.  As members they
@@ -1311,6 +1313,91 @@ struct MgxEnvT {  // per-lane view of one env
   }
 
   // ---- std::mt19937 + libstdc++ uniform_int_distribution / shuffle ----
+  // `cnt` (<= 8) consecutive generator outputs, same stream as cnt calls of rng_next: word i of the incremental twist
+  // needs the OLD words i + 1 and i + 397, and none of the words this block rewrites is within 397 of another.
+  __device__ __forceinline__ void rng_block(uint32_t (&r)[8], uint32_t cnt) const {
+    const size_t E = (size_t)d.E;
+    const int ev = envi();
+    const uint32_t i0 = d.mt_idx[ev];
+    uint32_t w[9], m[8];
+#pragma unroll
+    for (int q = 0; q < 9; q++) {
+      uint32_t i = i0 + q; i = i >= 624 ? i - 624 : i;
+      w[q] = (uint32_t)q <= cnt ? d.mt[i * E + ev] : 0u;
+    }
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      uint32_t i = i0 + q + 397; i = i >= 624 ? i - 624 : i; i = i >= 624 ? i - 624 : i;
+      m[q] = (uint32_t)q < cnt ? d.mt[i * E + ev] : 0u;
+    }
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      if ((uint32_t)q < cnt) {
+        uint32_t i = i0 + q; i = i >= 624 ? i - 624 : i;
+        const uint32_t y = (w[q] & 0x80000000u) | (w[q + 1] & 0x7fffffffu);
+        uint32_t x = m[q] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+        d.mt[i * E + ev] = x;
+        x ^= x >> 11;
+        x ^= (x << 7) & 0x9d2c5680u;
+        x ^= (x << 15) & 0xefc60000u;
+        x ^= x >> 18;
+        r[q] = x;
+      } else {
+        r[q] = 0;
+      }
+    }
+    uint32_t i1 = i0 + cnt;
+    d.mt_idx[ev] = i1 >= 624 ? i1 - 624 : i1;
+  }
+
+  // track_coverage of every agent (mettagrid_c.cpp:1054-1056).  Agents are independent here, so the loads of eight
+  // of them are issued together.  Both stat keys exist since Agent::init (mgx_init_kernel calls track_coverage).
+  __device__ void track_coverage_all() const {
+    const int A = d.A, lane = AL().lane;
+    const int su = mgx_wk(d, MGX_S_CELL_UNIQUE), sm = mgx_wk(d, MGX_S_CELL_MAXDIST);
+    for (int i0 = 0; i0 < A; i0 += 8) {
+      uint16_t rc8[8], cov8[8];
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        const int i = min(i0 + q, A - 1);
+        rc8[q] = AL().rc[i * MGX_WAVE + lane];
+        cov8[q] = d.ag_covrc[ao(i)];
+      }
+      uint16_t sp8[8];
+      uint32_t w8[8], un8[8], md8[8];
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        const int i = i0 + q;
+        if (i < A && rc8[q] != cov8[q]) {
+          const int bit = (rc8[q] >> 8) * d.W + (rc8[q] & 0xFF);
+          sp8[q] = d.ag_spawn[ao(i)];
+          w8[q] = d.ag_seen[ao(i) * d.SEENW + (bit >> 5)];
+          un8[q] = d.ag_unique[ao(i)];
+          md8[q] = d.ag_maxdist[ao(i)];
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        const int i = i0 + q;
+        if (i < A && rc8[q] != cov8[q]) {
+          const int r = rc8[q] >> 8, c = rc8[q] & 0xFF;
+          const int bit = r * d.W + c;
+          d.ag_covrc[ao(i)] = rc8[q];
+          uint32_t uniq = un8[q];
+          if (!(w8[q] & (1u << (bit & 31)))) {
+            d.ag_seen[ao(i) * d.SEENW + (bit >> 5)] = w8[q] | (1u << (bit & 31));
+            d.ag_unique[ao(i)] = ++uniq;
+          }
+          if (su >= 0) d.ag_stats[ao(i) * d.NS + su] = (float)uniq;
+          const int dist = abs((int)(sp8[q] >> 8) - r) + abs(c - (int)(sp8[q] & 0xFF));
+          const uint32_t md = max(md8[q], (uint32_t)dist);
+          d.ag_maxdist[ao(i)] = md;
+          if (sm >= 0) d.ag_stats[ao(i) * d.NS + sm] = (float)md;
+        }
+      }
+    }
+  }
+
   __device__ __forceinline__ uint32_t rng_next() const {  // incremental twist: identical stream to the batch _M_gen_rand
     uint32_t i = d.mt_idx[envi()];
     uint32_t i1 = i + 1 == 624 ? 0 : i + 1;
@@ -1379,15 +1466,15 @@ __device__ __forceinline__ void mgx_world_body(const MgxDev& d, PP P, uint8_t* o
       a8[q] = d.actions[e.ao(i)];
       v8[q] = d.vibe_actions[e.ao(i)];
     }
-    uint16_t rc8[8];
+    uint16_t rc8[8], cls8[8];
 #pragma unroll
-    for (int q = 0; q < 8; q++) rc8[q] = d.obj_rc[e.so(slot8[q])];
+    for (int q = 0; q < 8; q++) { rc8[q] = d.obj_rc[e.so(slot8[q])]; cls8[q] = d.obj_cls[e.so(slot8[q])]; }
 #pragma unroll
     for (int q = 0; q < 8; q++) {
       int i = i0 + q;
       if (i < A) {
         int li = i * MGX_WAVE + lane;
-        al.slot[li] = slot8[q]; al.rc[li] = rc8[q]; al.prev[li] = prev8[q]; al.swm[li] = swm8[q];
+        al.slot[li] = slot8[q]; al.rc[li] = rc8[q]; al.prev[li] = prev8[q]; al.swm[li] = swm8[q]; al.cls[li] = cls8[q];
         al.act[li] = mgx_sat16(a8[q]); al.act[A * MGX_WAVE + li] = mgx_sat16(v8[q]);
         if (want_stepprev) d.ag_stepprev[e.ao(i)] = rc8[q];  // mettagrid_c.cpp:929-931
         order[li] = (uint8_t)i;
@@ -1396,20 +1483,38 @@ __device__ __forceinline__ void mgx_world_body(const MgxDev& d, PP P, uint8_t* o
   }
   e.al_ = al;
   MGX_TICK(0);
-  // std::shuffle (bits/stl_algo.h:3729-3795): one draw for an even n, then paired draws
+  // std::shuffle (bits/stl_algo.h:3729-3795): one draw for an even n, then paired draws.  The generator outputs
+  // are produced eight at a time (rng_block): one round trip for the state words of the whole shuffle instead of
+  // three dependent ones per draw.  A Lemire rejection (probability < 1e-7) simply consumes one more output.
   if (A >= 2) {
-    uint32_t i = 1;
-    if ((A & 1) == 0) {
-      uint32_t j = e.rng_below(2);
-      mgx_swap(order, lane, 1, (int)j);
-      i = 2;
-    }
-    while (i < (uint32_t)A) {
-      uint32_t s = i + 1;
-      uint32_t x = e.rng_below(s * (s + 1));
-      mgx_swap(order, lane, (int)i, (int)(x / (s + 1)));
-      mgx_swap(order, lane, (int)i + 1, (int)(x % (s + 1)));
-      i += 2;
+    const uint32_t ndraw = (uint32_t)A / 2;  // A even: 1 + (A - 2) / 2, A odd: (A - 1) / 2
+    uint32_t j = 0;                          // draws done
+    while (j < ndraw) {
+      uint32_t r[8];
+      const uint32_t cnt = min(8u, ndraw - j);
+      e.rng_block(r, cnt);
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        if ((uint32_t)q < cnt) {
+          const bool first_even = (A & 1) == 0 && j == 0;
+          const uint32_t i = (A & 1) == 0 ? 2 * j : 2 * j + 1;  // index of the pair's first element (paired draws)
+          const uint32_t sft = i + 1;
+          const uint32_t range = first_even ? 2u : sft * (sft + 1);
+          const unsigned long long pr = (unsigned long long)r[q] * range;
+          const uint32_t low = (uint32_t)pr;
+          const bool accept = low >= range || low >= (0u - range) % range;
+          if (accept) {
+            const uint32_t x = (uint32_t)(pr >> 32);
+            if (first_even) {
+              mgx_swap(order, lane, 1, (int)x);
+            } else {
+              mgx_swap(order, lane, (int)i, (int)(x / (sft + 1)));
+              mgx_swap(order, lane, (int)i + 1, (int)(x % (sft + 1)));
+            }
+            j++;
+          }
+        }
+      }
     }
   }
   // Action dispatch (mettagrid_c.cpp:966-999).  The reference loops over priority levels max..0 and, inside each,
@@ -1446,10 +1551,11 @@ __device__ __forceinline__ void mgx_world_body(const MgxDev& d, PP P, uint8_t* o
     if (d.n_schedule > 0) e.process_events();  // mettagrid_c.cpp:1009-1011
   }
   if (d.any_on_tick) {
-    for (int i = 0; i < A; i++) {  // per-agent on_tick (mettagrid_c.cpp:1019-1024)
-      int slot = d.ag_obj[e.ao(i)];
-      int h = e.cls_of(slot)[MGX_C_ON_TICK];
+    for (int i = 0; i < A; i++) {  // per-agent on_tick (mettagrid_c.cpp:1019-1024); slot and class come from LDS
+      const int li = i * MGX_WAVE + lane;
+      const int h = e.cls(al.cls[li])[MGX_C_ON_TICK];
       if (h >= 0) {
+        const int slot = al.slot[li];
         MgxCtx c = mgx_ctx(slot, slot);
         e.template apply_handler<3>(h, c);
       }
@@ -1473,7 +1579,7 @@ __device__ __forceinline__ void mgx_world_body(const MgxDev& d, PP P, uint8_t* o
     }
   }
   MGX_TICK(4);
-  for (int i = 0; i < A; i++) e.track_coverage(i);  // mettagrid_c.cpp:1054-1056
+  e.track_coverage_all();
   MGX_TICK(5);
 }
 
