@@ -17,6 +17,7 @@
 #define MGX_WAVE 64
 #define MGX_NO_AGENT 0xFF
 #define MGX_DEAD_CLASS 0xFFFF
+#define MGX_INV_PITCH 16  // u16 entries per inventory row: a row is two aligned 16-byte loads (R <= 13 resources)
 
 struct MgxDev {
   const int32_t* P;       // program blob (device copy)
@@ -41,7 +42,7 @@ struct MgxDev {
   uint8_t* obj_vibe;      // [E][S]
   uint8_t* obj_agent;     // [E][S]     agent index or MGX_NO_AGENT
   uint32_t* obj_visited;  // [E][S]     GridObject::visited (core/grid_object.hpp:113)
-  uint16_t* obj_inv;      // [E][S][R]  amount by resource id
+  uint16_t* obj_inv;      // [E][S][MGX_INV_PITCH]  amount by resource id (entries >= R unused)
   unsigned long long* obj_order;  // [E][S] inventory iteration order: 4-bit ids, begin() in the low nibble, 0xF ends
   uint32_t* num_objs;     // [E]
   // ---- env-major agent state ----

@@ -264,7 +264,7 @@ int mgx_create(const int32_t* program, size_t program_words, const uint16_t* cla
   A_(e->alloc_env(&d.obj_vibe, S));
   A_(e->alloc_env(&d.obj_agent, S, 0xFF));
   A_(e->alloc_env(&d.obj_visited, S));
-  A_(e->alloc_env(&d.obj_inv, S * d.R));
+  A_(e->alloc_env(&d.obj_inv, S * MGX_INV_PITCH));
   A_(e->alloc_env(&d.obj_order, S, 0xFF));
   A_(e->alloc_env(&d.num_objs, 1));
   A_(e->alloc_env(&d.ag_obj, A));
@@ -619,7 +619,7 @@ int mgx_get_objects(mgx_engine* e, int32_t env, int32_t* out, int32_t* n_objects
   if (!e || !out || !n_objects || env < 0 || env >= e->d.E) return fail(MGX_ERR_BAD_ARG, "mgx_get_objects: bad argument");
   const MgxDev& d = e->d;
   const size_t S = d.S;
-  std::vector<uint16_t> cls(S), rc(S), inv(S * d.R);
+  std::vector<uint16_t> cls(S), rc(S), inv(S * MGX_INV_PITCH);
   std::vector<uint8_t> vibe(S), agent(S), oflags(S, 0);
   std::vector<unsigned long long> ord(S);
   std::vector<uint32_t> tags(d.obj_tags ? S * MGX_TAG_WORDS : 0);
@@ -629,7 +629,7 @@ int mgx_get_objects(mgx_engine* e, int32_t env, int32_t* out, int32_t* n_objects
   if (!r) r = d2h(e, rc.data(), d.obj_rc + env * S, S * 2);
   if (!r) r = d2h(e, vibe.data(), d.obj_vibe + env * S, S);
   if (!r) r = d2h(e, agent.data(), d.obj_agent + env * S, S);
-  if (!r) r = d2h(e, inv.data(), d.obj_inv + env * S * d.R, S * d.R * 2);
+  if (!r) r = d2h(e, inv.data(), d.obj_inv + env * S * MGX_INV_PITCH, S * MGX_INV_PITCH * 2);
   if (!r) r = d2h(e, ord.data(), d.obj_order + env * S, S * 8);
   if (!r && d.obj_flags) r = d2h(e, oflags.data(), d.obj_flags + env * S, S);
   if (!r && d.obj_tags) r = d2h(e, tags.data(), d.obj_tags + env * S * MGX_TAG_WORDS, S * MGX_TAG_WORDS * 4);
@@ -646,7 +646,7 @@ int mgx_get_objects(mgx_engine* e, int32_t env, int32_t* out, int32_t* n_objects
       cnt++;
     }
     w[7] = cnt;
-    for (int k = 0; k < MGX_MAX_RESOURCES; k++) w[8 + MGX_MAX_RESOURCES + k] = k < d.R ? inv[s * d.R + k] : 0;
+    for (int k = 0; k < MGX_MAX_RESOURCES; k++) w[8 + MGX_MAX_RESOURCES + k] = k < d.R ? inv[s * MGX_INV_PITCH + k] : 0;
     for (int k = 0; k < MGX_TAG_WORDS; k++)
       w[8 + 2 * MGX_MAX_RESOURCES + k] = d.obj_tags ? (int32_t)tags[s * MGX_TAG_WORDS + k]
                                                     : (cls[s] != MGX_DEAD_CLASS ? e->prog[d.sec[MGX_SEC_CLASSES] + cls[s] * MGX_C_WORDS + MGX_C_TAGS + k] : 0);

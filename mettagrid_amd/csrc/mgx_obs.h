@@ -324,7 +324,7 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
         for (int k = 0; k < MGX_MAX_ITEMS; k++) {
           const int item = (int)((ord >> (4 * k)) & 0xF);
           live = live && item != 0xF;
-          amt[k] = live ? (uint32_t)d.obj_inv[o * d.R + item] : 0u;
+          amt[k] = live ? (uint32_t)d.obj_inv[o * MGX_INV_PITCH + item] : 0u;
           if (live) live_mask |= 1u << k;
         }
       }

@@ -156,7 +156,7 @@ struct MgxEnvT {  // per-lane view of one env
 
   __device__ __forceinline__ size_t so(int slot) const { return (size_t)envi() * d.S + slot; }
   __device__ __forceinline__ size_t ao(int agent) const { return (size_t)envi() * d.A + agent; }
-  __device__ __forceinline__ uint16_t& inv(int slot, int item) const { return d.obj_inv[so(slot) * d.R + item]; }
+  __device__ __forceinline__ uint16_t& inv(int slot, int item) const { return d.obj_inv[so(slot) * MGX_INV_PITCH + item]; }
   __device__ __forceinline__ int inv_of(int slot, int item) const { return slot >= 0 ? (int)inv(slot, item) : 0; }
   __device__ __forceinline__ PP cls_of(int slot) const { return cls(d.obj_cls[so(slot)]); }
   __device__ __forceinline__ int agent_of(int slot) const {
@@ -202,24 +202,47 @@ struct MgxEnvT {  // per-lane view of one env
   }
 
   // ---- inventory (cpp/src/mettagrid/objects/inventory.cpp) ----
-  __device__ __forceinline__ int effective_limit(int slot, PP L) const {  // objects/inventory.hpp:26-40
+  // One object's whole inventory row in registers: two independent 16-byte loads instead of one dependent load per
+  // resource a limit group or modifier list touches.
+  struct InvRow {
+    uint32_t w[MGX_INV_PITCH / 2];
+    __device__ __forceinline__ uint32_t pair(int i) const {  // w[i] for a run-time i without indexing the array
+      uint32_t a = (i & 1) ? w[1] : w[0], b = (i & 1) ? w[3] : w[2], c = (i & 1) ? w[5] : w[4], e = (i & 1) ? w[7] : w[6];
+      uint32_t ab = (i & 2) ? b : a, ce = (i & 2) ? e : c;
+      return (i & 4) ? ce : ab;
+    }
+    __device__ __forceinline__ int get(int item) const { uint32_t v = pair(item >> 1); return (int)((item & 1) ? v >> 16 : v & 0xFFFFu); }
+    template <int K> __device__ __forceinline__ int at() const { return (int)((K & 1) ? w[K >> 1] >> 16 : w[K >> 1] & 0xFFFFu); }
+  };
+  __device__ __forceinline__ InvRow inv_row(int slot) const {
+    const uint4* p = (const uint4*)(d.obj_inv + so(slot) * MGX_INV_PITCH);
+    const uint4 lo = p[0], hi = p[1];
+    InvRow r;
+    r.w[0] = lo.x; r.w[1] = lo.y; r.w[2] = lo.z; r.w[3] = lo.w; r.w[4] = hi.x; r.w[5] = hi.y; r.w[6] = hi.z; r.w[7] = hi.w;
+    return r;
+  }
+  __device__ __forceinline__ int effective_limit(const InvRow& row, PP L) const {  // objects/inventory.hpp:26-40
     int sum = 0;
     PP mods = prog() + d.sec[MGX_SEC_MODS] + L[MGX_L_MOD_START] * MGX_MOD_WORDS;
     for (int i = 0; i < L[MGX_L_MOD_COUNT]; i++)
-      sum += (int)inv(slot, mods[i * MGX_MOD_WORDS + MGX_MOD_ITEM]) * mods[i * MGX_MOD_WORDS + MGX_MOD_BONUS];
+      sum += row.get(mods[i * MGX_MOD_WORDS + MGX_MOD_ITEM]) * mods[i * MGX_MOD_WORDS + MGX_MOD_BONUS];
     int eff = min(L[MGX_L_MAX], max(L[MGX_L_MIN], sum));
     return min(max(eff, 0), 65535);
   }
-  __device__ __forceinline__ int group_amount(int slot, PP L) const {
+  __device__ __forceinline__ int group_amount(const InvRow& row, PP L) const {
+    const uint32_t mask = (uint32_t)L[MGX_L_RES_MASK];
     int s = 0;
-    uint32_t mask = (uint32_t)L[MGX_L_RES_MASK];
-    while (mask) {
-      int r = __ffs(mask) - 1;
-      mask &= mask - 1;
-      s += inv(slot, r);
-    }
+    s += (mask >> 0) & 1 ? row.template at<0>() : 0;   s += (mask >> 1) & 1 ? row.template at<1>() : 0;
+    s += (mask >> 2) & 1 ? row.template at<2>() : 0;   s += (mask >> 3) & 1 ? row.template at<3>() : 0;
+    s += (mask >> 4) & 1 ? row.template at<4>() : 0;   s += (mask >> 5) & 1 ? row.template at<5>() : 0;
+    s += (mask >> 6) & 1 ? row.template at<6>() : 0;   s += (mask >> 7) & 1 ? row.template at<7>() : 0;
+    s += (mask >> 8) & 1 ? row.template at<8>() : 0;   s += (mask >> 9) & 1 ? row.template at<9>() : 0;
+    s += (mask >> 10) & 1 ? row.template at<10>() : 0; s += (mask >> 11) & 1 ? row.template at<11>() : 0;
+    s += (mask >> 12) & 1 ? row.template at<12>() : 0;
     return s;
   }
+  __device__ __forceinline__ int effective_limit(int slot, PP L) const { return effective_limit(inv_row(slot), L); }
+  __device__ __forceinline__ int group_amount(int slot, PP L) const { return group_amount(inv_row(slot), L); }
   __device__ __forceinline__ PP limit_of(PP C, int item) const {
     int li = C[MGX_C_RES_LIMIT + item];
     return li < 0 ? (PP) nullptr : prog() + d.sec[MGX_SEC_LIMITS] + li * MGX_L_WORDS;
@@ -235,22 +258,25 @@ struct MgxEnvT {  // per-lane view of one env
   // Inventory::update (inventory.cpp:38-86).  DEPTH bounds the update -> enforce_all_limits -> update recursion.
   template <int DEPTH>
   __device__ MGX_BIG int inv_update(int slot, int item, int delta, bool ignore_limits = false, bool notify = true) const {
-    PP C = cls_of(slot);
-    int initial = inv(slot, item);
+    // class, inventory row and iteration order of the object: independent loads, one round trip
+    const uint16_t cls_id = d.obj_cls[so(slot)];
+    const InvRow row = inv_row(slot);
+    unsigned long long ord = d.obj_order[so(slot)];
+    PP C = cls(cls_id);
+    int initial = row.get(item);
     int new_amount = initial + delta;
     int mx = 65535;
     if (!ignore_limits) {
       PP L = limit_of(C, item);
       if (L) {
-        int used = group_amount(slot, L) - initial;
+        int used = group_amount(row, L) - initial;
         if (used < 0) used = 0;
-        int m = effective_limit(slot, L) - used;
+        int m = effective_limit(row, L) - used;
         mx = m < 0 ? 0 : m;
       }
     }
     int clamped = min(max(new_amount, 0), mx);
     if (clamped != initial) {
-      unsigned long long ord = d.obj_order[so(slot)];
       if (initial == 0) {  // new node goes to the list head (libstdc++ _M_insert_bucket_begin; mettagrid_amd/umap.py)
         ord = (ord << 4) | (unsigned long long)item;
         d.obj_order[so(slot)] = ord;
@@ -276,7 +302,8 @@ struct MgxEnvT {  // per-lane view of one env
     for (int li = 0; li < C[MGX_C_LIMIT_COUNT]; li++) {
       PP L = prog() + d.sec[MGX_SEC_LIMITS] + (C[MGX_C_LIMIT_START] + li) * MGX_L_WORDS;
       if (L[MGX_L_DROP_COUNT] == 0) continue;
-      int excess = group_amount(slot, L) - effective_limit(slot, L);
+      int excess;
+      { const InvRow row = inv_row(slot); excess = group_amount(row, L) - effective_limit(row, L); }
       if (excess <= 0) continue;
       PP drop = prog() + d.sec[MGX_SEC_DROP_ORDER] + L[MGX_L_DROP_START];
       for (int k = 0; k < L[MGX_L_DROP_COUNT]; k++) {
@@ -284,16 +311,19 @@ struct MgxEnvT {  // per-lane view of one env
         int to_drop = min((int)inv(slot, item), excess);
         if (to_drop > 0) {
           inv_update<DEPTH>(slot, item, -to_drop);
-          excess = group_amount(slot, L) - effective_limit(slot, L);
+          const InvRow row = inv_row(slot);
+          excess = group_amount(row, L) - effective_limit(row, L);
         }
         if (excess <= 0) break;
       }
     }
   }
   __device__ MGX_BIG int free_space(int slot, int item) const {  // inventory.cpp:97-110
-    PP L = limit_of(cls_of(slot), item);
-    if (!L) return 65535 - inv(slot, item);
-    int used = group_amount(slot, L), eff = effective_limit(slot, L);
+    const uint16_t cls_id = d.obj_cls[so(slot)];
+    const InvRow row = inv_row(slot);
+    PP L = limit_of(cls(cls_id), item);
+    if (!L) return 65535 - row.get(item);
+    int used = group_amount(row, L), eff = effective_limit(row, L);
     return eff > used ? eff - used : 0;
   }
   __device__ MGX_BIG int transfer(int src, int dst, int item, int delta) const {  // objects/has_inventory.cpp:76-108
