@@ -77,6 +77,16 @@ MGX_DBG_LINKAGE __device__ unsigned long long mgx_dbg_cycles[16];
 #ifndef MGX_BIG
 #define MGX_BIG
 #endif
+// MGX_WORLD_LPW: envs (active lanes) per wavefront of the world kernel.  A workgroup always owns 64 envs; with LPW < 64
+// they are spread over 64 / LPW wavefronts that use their first LPW lanes.  Fewer lanes per wavefront = fewer distinct
+// handler paths serialised inside one wavefront, more wavefronts per SIMD to overlap their memory latency.
+#ifndef MGX_WORLD_LPW
+#define MGX_WORLD_LPW 64
+#endif
+#define MGX_WORLD_THREADS (MGX_WAVE * (MGX_WAVE / MGX_WORLD_LPW))
+__device__ __forceinline__ int mgx_world_lane() {  // index of this lane's env inside the workgroup's 64-env group
+  return (int)((threadIdx.x >> 6) * MGX_WORLD_LPW + (threadIdx.x & (MGX_WAVE - 1)));
+}
 
 __host__ __device__ inline int mgx_world_alds_bytes(int A) { return A * MGX_WAVE * (2 + 2 + 2 + 2 + 4 + 4); }
 // Dynamic LDS of the world kernels: order u8[A][64] | swm u32[A][64] | act i16[2][A][64] | slot, rc, prev, cls u16[A][64] |
@@ -141,12 +151,12 @@ struct MgxEnvT {  // per-lane view of one env
   // live in the kernel's stack frame, and an out-of-line handler function has to re-load them through `this` after
   // every store that might alias it.
 #ifdef MGX_WORLD_IDS
-  __device__ __forceinline__ int envi() const { return (int)(blockIdx.x * MGX_WAVE + threadIdx.x); }
+  __device__ __forceinline__ int envi() const { return (int)(blockIdx.x * MGX_WAVE) + mgx_world_lane(); }
   __device__ __forceinline__ PP prog() const {
     if constexpr (std::is_same<PP, MgxLdsProg>::value) return (MgxLdsProg)(int32_t*)(mgx_dyn_lds + mgx_world_lds_fixed(d.A, X));
     else return d.P;
   }
-  __device__ __forceinline__ MgxALds AL() const { return mgx_world_alds(mgx_dyn_lds, d.A, (int)threadIdx.x); }
+  __device__ __forceinline__ MgxALds AL() const { return mgx_world_alds(mgx_dyn_lds, d.A, mgx_world_lane()); }
 #else
   __device__ __forceinline__ int envi() const { return env_; }
   __device__ __forceinline__ PP prog() const { return P_; }
@@ -1618,7 +1628,8 @@ __device__ __forceinline__ void mgx_world_body(const MgxDev& d, PP P, uint8_t* o
 template <bool PROG_LDS, bool X>
 __device__ __forceinline__ void mgx_world_entry(const MgxDev& d, int prog_words) {
   uint8_t* order = mgx_dyn_lds;
-  const int lane = threadIdx.x;
+  const int lane = mgx_world_lane();
+  const bool active = (threadIdx.x & (MGX_WAVE - 1)) < MGX_WORLD_LPW;
   const int env = blockIdx.x * MGX_WAVE + lane;
   MgxXLds xl;
   xl.lane = lane;
@@ -1640,10 +1651,10 @@ __device__ __forceinline__ void mgx_world_entry(const MgxDev& d, int prog_words)
     int4* dst = (int4*)lprog;
     for (int i = threadIdx.x; i < prog_words / 4; i += blockDim.x) dst[i] = src[i];
     __syncthreads();
-    if (env >= d.E) return;
+    if (!active || env >= d.E) return;
     mgx_world_body<MgxLdsProg, X>(d, (MgxLdsProg)lprog, order, xl, al, lane, env);
   } else {
-    if (env >= d.E) return;
+    if (!active || env >= d.E) return;
     mgx_world_body<MgxGlobalProg, X>(d, d.P, order, xl, al, lane, env);
   }
 }

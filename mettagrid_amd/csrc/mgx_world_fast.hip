@@ -7,6 +7,14 @@
 #define MGX_WORLD_FAST_TU 1
 #define MGX_CONST_DEV 1
 #define MGX_WORLD_IDS 1
+// Measured on MI355X (rung 3, 65 536 envs): 32 envs per wavefront, two wavefronts per SIMD is the best split —
+// 64 lanes serialise more distinct handler paths per wavefront, 16 or 8 multiply the instruction stream.
+#ifndef MGX_WORLD_LPW
+#define MGX_WORLD_LPW 32
+#endif
+#ifndef MGX_WORLD_WPE
+#define MGX_WORLD_WPE 2
+#endif
 #include <hip/hip_runtime.h>
 
 #include <cstring>
@@ -16,7 +24,12 @@
 #include "mgx_world.h"
 
 template <bool PROG_LDS>
-__global__ void __launch_bounds__(MGX_WAVE) mgx_world_kernel_fast(int prog_words) {
+#ifdef MGX_WORLD_WPE
+#define MGX_WPE_ATTR __attribute__((amdgpu_waves_per_eu(MGX_WORLD_WPE, MGX_WORLD_WPE)))
+#else
+#define MGX_WPE_ATTR
+#endif
+__global__ void __launch_bounds__(MGX_WORLD_THREADS) MGX_WPE_ATTR mgx_world_kernel_fast(int prog_words) {
   mgx_world_entry<PROG_LDS, false>(g_mgx_dev, prog_words);
 }
 
@@ -34,7 +47,7 @@ void mgx_launch_world_fast(bool prog_lds, size_t lds, hipStream_t stream, const 
     memcpy(&g_dev_host, &d, sizeof(MgxDev));
     g_dev_valid = true;
   }
-  dim3 grid((d.E + MGX_WAVE - 1) / MGX_WAVE), block(MGX_WAVE);
+  dim3 grid((d.E + MGX_WAVE - 1) / MGX_WAVE), block(MGX_WORLD_THREADS);
   if (prog_lds) hipLaunchKernelGGL((mgx_world_kernel_fast<true>), grid, block, lds, stream, prog_words);
   else hipLaunchKernelGGL((mgx_world_kernel_fast<false>), grid, block, lds, stream, prog_words);
 }
