@@ -1,23 +1,28 @@
 #!/bin/bash
-# PMC passes over a short bench run (one counter group per rocprofv3 process, kernel-trace only).
-# Usage (GPU box): bash scripts/pmc.sh <outdir-under-gpurun_out>
-set -e
+# rocprofv3 evidence for profiles/: kernel-trace statistics and PMC passes over a short bench run.  One counter group
+# per rocprofv3 process (kernel-trace only, never a sys/hip trace beside --pmc); FETCH_SIZE and WRITE_SIZE in their own
+# passes (together they exceed the hardware).  Every pass is bounded by `timeout` and reports as soon as it ends.
+# Usage (GPU box): bash scripts/pmc.sh <dir-under-gpurun_out>
 ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
 OUT="$ROOT/gpurun_out/${1:-pmc}"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
+echo "[pmc] kernel trace"
+timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o run -- python3 "$ROOT/bench.py" --steps 30 --warmup 5 --no-cpu > "$OUT/trace.log" 2>&1 || { echo "[pmc] kernel trace failed"; tail -5 "$OUT/trace.log"; exit 1; }
+grep -o '"value": [0-9.]*' "$OUT/trace.log" | head -1
 i=0
 while read -r group; do
   [ -z "$group" ] && continue
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $group -d "$OUT/g$i" -o run -- python3 "$ROOT/bench.py" --steps 6 --warmup 2 --no-cpu > "$OUT/g$i.log" 2>&1
-  echo "group $i done: $group"
+  if timeout -k 10 180 rocprofv3 --kernel-trace --pmc $group --output-format csv -d "$OUT/g$i" -o run -- python3 "$ROOT/bench.py" --steps 6 --warmup 2 --no-cpu > "$OUT/g$i.log" 2>&1; then
+    echo "[pmc] group $i ok: $group"
+  else
+    echo "[pmc] group $i FAILED: $group"; grep -m3 -i "error\|fail" "$OUT/g$i.log"
+  fi
 done <<'GROUPS'
-SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_SALU SQ_WAIT_INST_ANY
-SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_LDS_ADDR_CONFLICT SQ_INSTS_LDS_ATOMIC SQ_WAIT_ANY
-SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_WR_TA_DATA_FIFO_FULL SQ_ACTIVE_INST_ANY
-SQ_IFETCH SQ_INSTS_SMEM SQ_INST_CYCLES_SMEM SQ_ACTIVE_INST_SCA SQ_INST_LEVEL_SMEM SQ_INSTS_BRANCH SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_MISC
-FETCH_SIZE WRITE_SIZE
-TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum
+FETCH_SIZE
+WRITE_SIZE
+SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR
+SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_BRANCH SQ_INSTS_SMEM
 GROUPS
-python3 "$ROOT/scripts/pmc_summary.py" "$OUT" > "$OUT/summary.json"
+python3 "$ROOT/scripts/pmc_summary.py" "$OUT" > "$OUT/summary.json" && echo "[pmc] summary written"
