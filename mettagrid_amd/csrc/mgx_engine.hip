@@ -380,6 +380,23 @@ int mgx_create(const int32_t* program, size_t program_words, const uint16_t* cla
     e->obs_blk_words = b1 - b0;
     e->obs_blk_lds = !d.X && ordered && (b0 & 3) == 0 && (e->obs_blk_words & 3) == 0 && e->obs_blk_words * 4 <= 8 * 1024;
   }
+  {  // Per-action bookkeeping stats can be applied at the end of the tick unless some game value reads agent stats
+     // (a filter or SetStat evaluated mid-tick could then see them early or late).
+    bool reads_agent_stats = false;
+    const int n_code = P[MGX_H_SECTION_BASE + 2 * MGX_SEC_GV_CODE + 1];
+    const int32_t* code = P + d.sec[MGX_SEC_GV_CODE];
+    std::vector<char> reward_only(n_code, 0);  // reward expressions run in the observation kernel, after the flush
+    const int32_t* rwr = P + d.sec[MGX_SEC_REWARDS];
+    for (int k = 0; k < P[MGX_H_SECTION_BASE + 2 * MGX_SEC_REWARDS + 1]; k++)
+      for (int i = 0; i < rwr[k * MGX_RW_WORDS + MGX_RW_GV_COUNT]; i++) {
+        const int at = rwr[k * MGX_RW_WORDS + MGX_RW_GV_START] + i;
+        if (at >= 0 && at < n_code) reward_only[at] = 1;
+      }
+    for (int i = 0; i < n_code; i++)
+      if (!reward_only[i] && code[i * MGX_GV_WORDS + MGX_GV_OP] == MGX_GOP_STAT && code[i * MGX_GV_WORDS + MGX_GV_A0] != 1)
+        reads_agent_stats = true;
+    d.defer_book = reads_agent_stats ? 0 : 1;
+  }
   {  // reward code made only of inventory / constant arithmetic reads nothing the observation kernel writes
     bool pure = !d.X;
     const int32_t* rw = P + d.sec[MGX_SEC_REWARDS];

@@ -1299,7 +1299,7 @@ struct MgxEnvT {  // per-lane view of one env
     }
     return false;
   }
-  __device__ MGX_BIG bool handle_action(int ai, int action) const {  // actions/action_handler.hpp:78-105
+  __device__ MGX_BIG bool handle_action(int ai, int action, int stream) const {  // actions/action_handler.hpp:78-105
     PP ac = prog() + d.sec[MGX_SEC_ACTIONS] + action * MGX_AC_WORDS;
     int kind = ac[MGX_AC_KIND];
     const int li = ai * MGX_WAVE + AL().lane;
@@ -1311,6 +1311,18 @@ struct MgxEnvT {  // per-lane view of one env
     if (kind == MGX_AK_MOVE) ok = do_move(slot, ac[MGX_AC_ARG]);
     else if (kind == MGX_AK_VIBE) d.obj_vibe[so(slot)] = (uint8_t)ac[MGX_AC_ARG];  // actions/change_vibe.hpp:48-57
     MGX_TICK(6);
+    if (d.defer_book) {
+      // Bookkeeping touches only this agent's own counters.  Here: the LDS copies and a result byte (in place of the
+      // consumed action id); the HBM side — swm / prev_location write-back and the stat updates — is applied for all
+      // agents in one batched pass (bookkeeping_flush), off the serial chain.
+      const uint16_t rc = AL().rc[li], prev = AL().prev[li];
+      const bool moved = rc != prev;
+      if (moved) { AL().swm[li] = 0; AL().prev[li] = rc; }
+      else AL().swm[li] += 1;
+      AL().act[(stream * d.A + ai) * MGX_WAVE + AL().lane] = (int16_t)(1 | (kind << 1) | (ok ? 8 : 0) | (moved ? 16 : 0));
+      cur_agent = cur_slot = -1;
+      return ok;
+    }
     uint16_t rc = AL().rc ? AL().rc[li] : d.obj_rc[so(slot)];
     uint16_t prev = AL().prev ? AL().prev[li] : d.ag_prev[ao(ai)];
     if (rc == prev) {
@@ -1353,6 +1365,78 @@ struct MgxEnvT {  // per-lane view of one env
   }
 
   // ---- std::mt19937 + libstdc++ uniform_int_distribution / shuffle ----
+  // Deferred half of handle_action's bookkeeping (actions/action_handler.hpp:78-105) for every agent: replays the up to
+  // two calls of the tick (primary stream, vibe stream) from their result bytes.  Eight agents at a time, all loads
+  // of a chunk in flight together.  Per agent at most four stat cells change: the result counter of each stream
+  // (success or failed), action.failed (+1 per failed call, added one by one like the reference) and
+  // max_steps_without_motion (set when a call's incremented counter exceeds it).
+  __device__ void bookkeeping_flush() const {
+    const int A = d.A, lane = AL().lane;
+    const int s_max = mgx_wk(d, MGX_S_MAX_STEPS_WITHOUT_MOTION), s_failed = mgx_wk(d, MGX_S_ACTION_FAILED);
+    for (int i0 = 0; i0 < A; i0 += 8) {
+      int id0[8], id1[8], nfail[8];
+      uint32_t res0[8], res1[8], swm0[8], tw[8];
+      float v0[8], v1[8], vf[8], vm[8];
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        const int i = min(i0 + q, A - 1);
+        const int li = i * MGX_WAVE + lane;
+        res0[q] = (uint32_t)(uint16_t)AL().act[li];
+        res1[q] = (uint32_t)(uint16_t)AL().act[A * MGX_WAVE + li];
+        if (i0 + q >= A) res0[q] = res1[q] = 0;
+        // result bytes have bit 0 set; an action id that was never handled (invalid / wrong stream) is cleared by the caller
+        auto stat_of = [&](uint32_t r) {
+          if (!(r & 1)) return -1;
+          const int kind = (r >> 1) & 3;
+          const int s_ok = kind == MGX_AK_NOOP ? MGX_S_NOOP_SUCCESS : kind == MGX_AK_MOVE ? MGX_S_MOVE_SUCCESS : MGX_S_VIBE_SUCCESS;
+          return mgx_wk(d, (r & 8) ? s_ok : s_ok + 1);
+        };
+        id0[q] = stat_of(res0[q]);
+        id1[q] = stat_of(res1[q]);
+        nfail[q] = ((res0[q] & 9) == 1 ? 1 : 0) + ((res1[q] & 9) == 1 ? 1 : 0);
+        const size_t sb = ao(i) * d.NS;
+        swm0[q] = d.ag_swm[ao(i)];
+        v0[q] = id0[q] >= 0 ? d.ag_stats[sb + id0[q]] : 0.f;
+        v1[q] = id1[q] >= 0 ? d.ag_stats[sb + id1[q]] : 0.f;
+        vf[q] = (nfail[q] && s_failed >= 0) ? d.ag_stats[sb + s_failed] : 0.f;
+        const bool any = ((res0[q] | res1[q]) & 1) != 0;
+        vm[q] = (any && s_max >= 0) ? d.ag_stats[sb + s_max] : 0.f;
+        tw[q] = (any && s_max >= 0) ? d.ag_touched[ao(i) * d.NSW + (s_max >> 5)] : 0u;
+      }
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        const int i = i0 + q;
+        if (i >= A || !((res0[q] | res1[q]) & 1)) continue;
+        const int li = i * MGX_WAVE + lane;
+        const size_t sb = ao(i) * d.NS;
+        // replay the calls: a call that did not move increments the counter and may raise the max stat
+        uint32_t swm = swm0[q];
+        float mx = vm[q];
+        bool set_max = false;
+#pragma unroll
+        for (int call = 0; call < 2; call++) {
+          const uint32_t r = call ? res1[q] : res0[q];
+          if (!(r & 1)) continue;
+          if (r & 16) swm = 0;
+          else { swm += 1; if ((float)swm > mx) { mx = (float)swm; set_max = true; } }
+        }
+        d.ag_swm[ao(i)] = swm;
+        d.ag_prev[ao(i)] = AL().prev[li];
+        if (set_max && s_max >= 0) {
+          d.ag_stats[sb + s_max] = mx;
+          d.ag_touched[ao(i) * d.NSW + (s_max >> 5)] = tw[q] | (1u << (s_max & 31));
+        }
+        if (id0[q] >= 0) d.ag_stats[sb + id0[q]] = __fadd_rn(v0[q], 1.f);
+        if (id1[q] >= 0) d.ag_stats[sb + id1[q]] = __fadd_rn(v1[q], 1.f);
+        if (nfail[q] && s_failed >= 0) {
+          float f = __fadd_rn(vf[q], 1.f);
+          if (nfail[q] > 1) f = __fadd_rn(f, 1.f);
+          d.ag_stats[sb + s_failed] = f;
+        }
+      }
+    }
+  }
+
   // `cnt` (<= 8) consecutive generator outputs, same stream as cnt calls of rng_next: word i of the incremental twist
   // needs the OLD words i + 1 and i + 397, and none of the words this block rewrites is within 397 of another.
   __device__ __forceinline__ void rng_block(uint32_t (&r)[8], uint32_t cnt) const {
@@ -1576,11 +1660,12 @@ __device__ __forceinline__ void mgx_world_body(const MgxDev& d, PP P, uint8_t* o
           else e.flag(2u);
         }
         d.success[e.ao(ai)] = 0;
+        al.act[(stream * A + ai) * MGX_WAVE + lane] = 0;  // no handle_action call: empty result byte
         continue;
       }
       bool is_vibe = acts[a * MGX_AC_WORDS + MGX_AC_KIND] == MGX_AK_VIBE;
-      if (is_vibe != (stream == 1)) continue;
-      if (e.handle_action(ai, a)) {
+      if (is_vibe != (stream == 1)) { al.act[(stream * A + ai) * MGX_WAVE + lane] = 0; continue; }
+      if (e.handle_action(ai, a, stream)) {
         d.executed[e.ao(ai)] = a;
         d.success[e.ao(ai)] = 1;
       }
@@ -1619,6 +1704,7 @@ __device__ __forceinline__ void mgx_world_body(const MgxDev& d, PP P, uint8_t* o
     }
   }
   MGX_TICK(4);
+  if (d.defer_book) e.bookkeeping_flush();
   e.track_coverage_all();
   MGX_TICK(5);
 }
