@@ -1373,6 +1373,10 @@ struct MgxEnvT {  // per-lane view of one env
   __device__ void bookkeeping_flush() const {
     const int A = d.A, lane = AL().lane;
     const int s_max = mgx_wk(d, MGX_S_MAX_STEPS_WITHOUT_MOTION), s_failed = mgx_wk(d, MGX_S_ACTION_FAILED);
+    // the six result counters as scalars (a lane-varying index into d.wk would be a memory load per agent)
+    const int w_noop_ok = mgx_wk(d, MGX_S_NOOP_SUCCESS), w_noop_no = mgx_wk(d, MGX_S_NOOP_SUCCESS + 1);
+    const int w_move_ok = mgx_wk(d, MGX_S_MOVE_SUCCESS), w_move_no = mgx_wk(d, MGX_S_MOVE_SUCCESS + 1);
+    const int w_vibe_ok = mgx_wk(d, MGX_S_VIBE_SUCCESS), w_vibe_no = mgx_wk(d, MGX_S_VIBE_SUCCESS + 1);
     for (int i0 = 0; i0 < A; i0 += 8) {
       int id0[8], id1[8], nfail[8];
       uint32_t res0[8], res1[8], swm0[8], tw[8];
@@ -1386,22 +1390,24 @@ struct MgxEnvT {  // per-lane view of one env
         if (i0 + q >= A) res0[q] = res1[q] = 0;
         // result bytes have bit 0 set; an action id that was never handled (invalid / wrong stream) is cleared by the caller
         auto stat_of = [&](uint32_t r) {
-          if (!(r & 1)) return -1;
           const int kind = (r >> 1) & 3;
-          const int s_ok = kind == MGX_AK_NOOP ? MGX_S_NOOP_SUCCESS : kind == MGX_AK_MOVE ? MGX_S_MOVE_SUCCESS : MGX_S_VIBE_SUCCESS;
-          return mgx_wk(d, (r & 8) ? s_ok : s_ok + 1);
+          const bool ok = (r & 8) != 0;
+          const int id = kind == MGX_AK_NOOP ? (ok ? w_noop_ok : w_noop_no) : kind == MGX_AK_MOVE ? (ok ? w_move_ok : w_move_no)
+                                                                                                    : (ok ? w_vibe_ok : w_vibe_no);
+          return (r & 1) ? id : -1;
         };
         id0[q] = stat_of(res0[q]);
         id1[q] = stat_of(res1[q]);
         nfail[q] = ((res0[q] & 9) == 1 ? 1 : 0) + ((res1[q] & 9) == 1 ? 1 : 0);
         const size_t sb = ao(i) * d.NS;
+        // unconditional loads (a dummy in-range cell when there is nothing to update): no branch between them, so
+        // the whole chunk is in flight at once
         swm0[q] = d.ag_swm[ao(i)];
-        v0[q] = id0[q] >= 0 ? d.ag_stats[sb + id0[q]] : 0.f;
-        v1[q] = id1[q] >= 0 ? d.ag_stats[sb + id1[q]] : 0.f;
-        vf[q] = (nfail[q] && s_failed >= 0) ? d.ag_stats[sb + s_failed] : 0.f;
-        const bool any = ((res0[q] | res1[q]) & 1) != 0;
-        vm[q] = (any && s_max >= 0) ? d.ag_stats[sb + s_max] : 0.f;
-        tw[q] = (any && s_max >= 0) ? d.ag_touched[ao(i) * d.NSW + (s_max >> 5)] : 0u;
+        v0[q] = d.ag_stats[sb + max(id0[q], 0)];
+        v1[q] = d.ag_stats[sb + max(id1[q], 0)];
+        vf[q] = d.ag_stats[sb + max(s_failed, 0)];
+        vm[q] = d.ag_stats[sb + max(s_max, 0)];
+        tw[q] = d.ag_touched[ao(i) * d.NSW + (max(s_max, 0) >> 5)];
       }
 #pragma unroll
       for (int q = 0; q < 8; q++) {
