@@ -257,14 +257,25 @@ struct MgxEnvT {  // per-lane view of one env
     int li = C[MGX_C_RES_LIMIT + item];
     return li < 0 ? (PP) nullptr : prog() + d.sec[MGX_SEC_LIMITS] + li * MGX_L_WORDS;
   }
-  __device__ MGX_BIG void on_inventory_change(int slot, int item, int delta, int amount) const {  // objects/agent.cpp:106-121
-    int a = agent_of(slot);
+  // Agent::on_inventory_change (objects/agent.cpp:106-121); `a` = agent index of the object or -1 (the caller has it
+  // from the same round trip as the inventory row).  The three cells it updates are loaded together.
+  __device__ MGX_BIG void on_inventory_change(int a, int item, int delta, int amount) const {
     if (a < 0 || delta == 0) return;
-    if (delta > 0) astat_add(a, mgx_wk(d, MGX_S_RES_GAINED_BASE) + item, (float)delta);
-    else astat_add(a, mgx_wk(d, MGX_S_RES_LOST_BASE) + item, (float)(-delta));
-    astat_set(a, mgx_wk(d, MGX_S_RES_AMOUNT_BASE) + item, (float)amount);
-    if (amount == 0 && delta < 0 && item == d.hp_res) astat_add(a, mgx_wk(d, MGX_S_DEATH), 1.f);
+    const size_t sb = ao(a) * d.NS;
+    const int s_flow = (delta > 0 ? mgx_wk(d, MGX_S_RES_GAINED_BASE) : mgx_wk(d, MGX_S_RES_LOST_BASE)) + item;
+    const int s_amt = mgx_wk(d, MGX_S_RES_AMOUNT_BASE) + item;
+    const bool died = amount == 0 && delta < 0 && item == d.hp_res;
+    const int s_death = mgx_wk(d, MGX_S_DEATH);
+    const float flow = d.ag_stats[sb + s_flow];
+    uint32_t* tw = &d.ag_touched[ao(a) * d.NSW + (s_amt >> 5)];
+    const uint32_t tword = *tw;
+    const float deaths = d.ag_stats[sb + max(s_death, 0)];
+    d.ag_stats[sb + s_flow] = __fadd_rn(flow, (float)(delta > 0 ? delta : -delta));  // add(): value != 0 marks the key
+    d.ag_stats[sb + s_amt] = (float)amount;                                          // set(): key exists from now on
+    *tw = tword | (1u << (s_amt & 31));
+    if (died && s_death >= 0) d.ag_stats[sb + s_death] = __fadd_rn(deaths, 1.f);
   }
+
   // Inventory::update (inventory.cpp:38-86).  DEPTH bounds the update -> enforce_all_limits -> update recursion.
   template <int DEPTH>
   __device__ MGX_BIG int inv_update(int slot, int item, int delta, bool ignore_limits = false, bool notify = true) const {
@@ -272,6 +283,7 @@ struct MgxEnvT {  // per-lane view of one env
     const uint16_t cls_id = d.obj_cls[so(slot)];
     const InvRow row = inv_row(slot);
     unsigned long long ord = d.obj_order[so(slot)];
+    const uint8_t ag = d.obj_agent[so(slot)];
     PP C = cls(cls_id);
     int initial = row.get(item);
     int new_amount = initial + delta;
@@ -300,7 +312,7 @@ struct MgxEnvT {  // per-lane view of one env
       inv(slot, item) = (uint16_t)clamped;
     }
     int dl = clamped - initial;
-    if (notify && dl != 0) on_inventory_change(slot, item, dl, clamped);
+    if (notify && dl != 0) on_inventory_change(ag == MGX_NO_AGENT ? -1 : (int)ag, item, dl, clamped);
     if (dl < 0 && (C[MGX_C_MODIFIER_MASK] & (1 << item))) {
       if constexpr (DEPTH > 0) enforce_all_limits<DEPTH - 1>(slot, C);
       else flag(4u);
