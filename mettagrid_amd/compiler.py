@@ -192,16 +192,18 @@ class _Compiler:
             K.S_ACTION_FAILED: 0, K.S_NOOP_SUCCESS: 1, K.S_NOOP_FAILED: 2, K.S_MOVE_SUCCESS: 3, K.S_MOVE_FAILED: 4,
             K.S_VIBE_SUCCESS: 5, K.S_VIBE_FAILED: 6, K.S_INVALID_INDEX: 7,
         }
-        self.stat_well_known[K.S_INVALID_NEG_BASE] = len(a)
-        a += [f"action.invalid_index.{k}" for k in range(-K.INVALID_WINDOW, 0)]
-        self.stat_well_known[K.S_INVALID_POS_BASE] = len(a)
-        self._invalid_pos_slot = len(a)
-        a += [None] * K.INVALID_WINDOW  # names filled once n_actions is known
+        # the per-tick bookkeeping stats directly behind the action counters: all of them share the first cache line
+        # of an agent's stat row on the device (rows are 128-byte aligned there)
         for key, name in ((K.S_MAX_STEPS_WITHOUT_MOTION, "status.max_steps_without_motion"),
                           (K.S_SWAP, "actions.swap"), (K.S_DEATH, "death"), (K.S_CELL_VISITED, "cell.visited"),
                           (K.S_CELL_UNIQUE, "cell.unique_visited"), (K.S_CELL_MAXDIST, "cell.max_distance_from_spawn")):
             self.stat_well_known[key] = len(a)
             a.append(name)
+        self.stat_well_known[K.S_INVALID_NEG_BASE] = len(a)
+        a += [f"action.invalid_index.{k}" for k in range(-K.INVALID_WINDOW, 0)]
+        self.stat_well_known[K.S_INVALID_POS_BASE] = len(a)
+        self._invalid_pos_slot = len(a)
+        a += [None] * K.INVALID_WINDOW  # names filled once n_actions is known
         for key, suffix in ((K.S_RES_AMOUNT_BASE, "amount"), (K.S_RES_GAINED_BASE, "gained"),
                             (K.S_RES_LOST_BASE, "lost"), (K.S_RES_DEPOSITED_BASE, "deposited")):
             self.stat_well_known[key] = len(a)

@@ -24,6 +24,7 @@ struct MgxDev {
   int sec[MGX_SEC_COUNT]; // section offsets (words) — hoisted from the header
   int E, H, W, A, S, R, T;
   int NS, NG, NSW, NGW;   // agent/game stat counts and their touched-bit word counts
+  int NSP;                // pitch (floats) of one agent's stat row: NS rounded up to 32 = 128-byte aligned rows
   int NRW;                // reward "prev value" slots per agent (max over classes)
   int SEENW;              // words of the per-agent visited-cell bitmap
   int NOFF;               // observation offsets
@@ -57,7 +58,7 @@ struct MgxDev {
   uint32_t* ag_unique;    // [E][A]
   uint32_t* ag_seen;      // [E][A][SEENW]
   float* ag_rprev;        // [E][A][NRW]
-  float* ag_stats;        // [E][A][NS]
+  float* ag_stats;        // [E][A][NSP]
   uint32_t* ag_touched;   // [E][A][NSW]
   float* game_stats;      // [E][NG]
   uint32_t* game_touched; // [E][NGW]

@@ -188,6 +188,7 @@ int mgx_create(const int32_t* program, size_t program_words, const uint16_t* cla
   d.T = P[MGX_H_NUM_TOKENS];
   d.NS = P[MGX_H_NUM_AGENT_STATS]; d.NG = P[MGX_H_NUM_GAME_STATS];
   d.NSW = (d.NS + 31) / 32; d.NGW = (d.NG + 31) / 32;
+  d.NSP = d.NSW * 32;
   d.SEENW = (d.H * d.W + 31) / 32;
   d.NOFF = P[MGX_H_NUM_OBS_OFFSETS];
   d.base = P[MGX_H_TOKEN_BASE];
@@ -277,7 +278,7 @@ int mgx_create(const int32_t* program, size_t program_words, const uint16_t* cla
   A_(e->alloc_env(&d.ag_unique, A));
   A_(e->alloc_env(&d.ag_seen, A * d.SEENW));
   A_(e->alloc_env(&d.ag_rprev, A * d.NRW));
-  A_(e->alloc_env(&d.ag_stats, A * d.NS));
+  A_(e->alloc_env(&d.ag_stats, A * d.NSP));
   A_(e->alloc_env(&d.ag_touched, A * d.NSW));
   A_(e->alloc_env(&d.game_stats, (size_t)d.NG));
   A_(e->alloc_env(&d.game_touched, (size_t)d.NGW));
@@ -621,8 +622,12 @@ int mgx_get_stats(mgx_engine* e, int32_t env, float* game_values, uint8_t* game_
   if (rc) return rc;
   rc = d2h(e, gt.data(), d.game_touched + (size_t)env * d.NGW, (size_t)d.NGW * 4);
   if (rc) return rc;
-  rc = d2h(e, agent_values, d.ag_stats + (size_t)env * d.A * d.NS, (size_t)d.A * d.NS * 4);
-  if (rc) return rc;
+  {  // device rows have pitch NSP; the caller's array is [A][NS]
+    std::vector<float> rows((size_t)d.A * d.NSP);
+    rc = d2h(e, rows.data(), d.ag_stats + (size_t)env * d.A * d.NSP, rows.size() * 4);
+    if (rc) return rc;
+    for (int a = 0; a < d.A; a++) memcpy(agent_values + (size_t)a * d.NS, rows.data() + (size_t)a * d.NSP, (size_t)d.NS * 4);
+  }
   rc = d2h(e, at.data(), d.ag_touched + (size_t)env * d.A * d.NSW, (size_t)d.A * d.NSW * 4);
   if (rc) return rc;
   for (int i = 0; i < d.NG; i++) game_touched[i] = ((gt[i >> 5] >> (i & 31)) & 1u) | (game_values[i] != 0.f);

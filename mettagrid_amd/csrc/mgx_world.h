@@ -184,20 +184,20 @@ struct MgxEnvT {  // per-lane view of one env
   // 64 lanes adding into 64 different rows is their slowest shape (MI355X_MICROARCH.md "Global float atomics").
   __device__ __forceinline__ void astat_add(int agent, int id, float v) const {
     if (id < 0) return;
-    d.ag_stats[ao(agent) * d.NS + id] += v;
+    d.ag_stats[ao(agent) * d.NSP + id] += v;
   }
   __device__ __forceinline__ void astat_add_touch(int agent, int id, float v) const {  // for deltas that may be zero or negative
     if (id < 0) return;
-    d.ag_stats[ao(agent) * d.NS + id] += v;
+    d.ag_stats[ao(agent) * d.NSP + id] += v;
     astat_touch(agent, id);
   }
   __device__ __forceinline__ void astat_set(int agent, int id, float v) const {
     if (id < 0) return;
-    d.ag_stats[ao(agent) * d.NS + id] = v;
+    d.ag_stats[ao(agent) * d.NSP + id] = v;
     astat_touch(agent, id);
   }
   __device__ __forceinline__ float astat_get(int agent, int id) const {
-    return id < 0 ? 0.f : d.ag_stats[ao(agent) * d.NS + id];
+    return id < 0 ? 0.f : d.ag_stats[ao(agent) * d.NSP + id];
   }
   __device__ __forceinline__ void gstat_touch(int id) const { d.game_touched[(size_t)envi() * d.NGW + (id >> 5)] |= 1u << (id & 31); }
   __device__ __forceinline__ void gstat_set(int id, float v) const {
@@ -261,7 +261,7 @@ struct MgxEnvT {  // per-lane view of one env
   // from the same round trip as the inventory row).  The three cells it updates are loaded together.
   __device__ MGX_BIG void on_inventory_change(int a, int item, int delta, int amount) const {
     if (a < 0 || delta == 0) return;
-    const size_t sb = ao(a) * d.NS;
+    const size_t sb = ao(a) * d.NSP;
     const int s_flow = (delta > 0 ? mgx_wk(d, MGX_S_RES_GAINED_BASE) : mgx_wk(d, MGX_S_RES_LOST_BASE)) + item;
     const int s_amt = mgx_wk(d, MGX_S_RES_AMOUNT_BASE) + item;
     const bool died = amount == 0 && delta < 0 && item == d.hp_res;
@@ -1292,7 +1292,10 @@ struct MgxEnvT {  // per-lane view of one env
   }
 
   // ---- actions ----
-  __device__ MGX_BIG bool do_move(int slot, int orient) const {  // actions/move.hpp:81-115, orientation.hpp:28-48
+  __device__ MGX_BIG bool do_move(int slot, int orient) const {
+#ifdef MGX_EXP_NOMOVE
+    return false;
+#endif  // actions/move.hpp:81-115, orientation.hpp:28-48
     const int dx = (orient == 2 || orient == 4 || orient == 6) ? -1 : (orient == 3 || orient == 5 || orient == 7) ? 1 : 0;
     const int dy = (orient == 0 || orient == 4 || orient == 5) ? -1 : (orient == 1 || orient == 6 || orient == 7) ? 1 : 0;
     PP mh = prog() + d.sec[MGX_SEC_MOVE_HANDLERS];
@@ -1411,7 +1414,7 @@ struct MgxEnvT {  // per-lane view of one env
         id0[q] = stat_of(res0[q]);
         id1[q] = stat_of(res1[q]);
         nfail[q] = ((res0[q] & 9) == 1 ? 1 : 0) + ((res1[q] & 9) == 1 ? 1 : 0);
-        const size_t sb = ao(i) * d.NS;
+        const size_t sb = ao(i) * d.NSP;
         // unconditional loads (a dummy in-range cell when there is nothing to update): no branch between them, so
         // the whole chunk is in flight at once
         swm0[q] = d.ag_swm[ao(i)];
@@ -1426,7 +1429,7 @@ struct MgxEnvT {  // per-lane view of one env
         const int i = i0 + q;
         if (i >= A || !((res0[q] | res1[q]) & 1)) continue;
         const int li = i * MGX_WAVE + lane;
-        const size_t sb = ao(i) * d.NS;
+        const size_t sb = ao(i) * d.NSP;
         // replay the calls: a call that did not move increments the counter and may raise the max stat
         uint32_t swm = swm0[q];
         float mx = vm[q];
@@ -1530,11 +1533,11 @@ struct MgxEnvT {  // per-lane view of one env
             d.ag_seen[ao(i) * d.SEENW + (bit >> 5)] = w8[q] | (1u << (bit & 31));
             d.ag_unique[ao(i)] = ++uniq;
           }
-          if (su >= 0) d.ag_stats[ao(i) * d.NS + su] = (float)uniq;
+          if (su >= 0) d.ag_stats[ao(i) * d.NSP + su] = (float)uniq;
           const int dist = abs((int)(sp8[q] >> 8) - r) + abs(c - (int)(sp8[q] & 0xFF));
           const uint32_t md = max(md8[q], (uint32_t)dist);
           d.ag_maxdist[ao(i)] = md;
-          if (sm >= 0) d.ag_stats[ao(i) * d.NS + sm] = (float)md;
+          if (sm >= 0) d.ag_stats[ao(i) * d.NSP + sm] = (float)md;
         }
       }
     }
@@ -1693,6 +1696,7 @@ __device__ __forceinline__ void mgx_world_body(const MgxDev& d, PP P, uint8_t* o
   if constexpr (X) {
     if (d.n_schedule > 0) e.process_events();  // mettagrid_c.cpp:1009-1011
   }
+#ifndef MGX_EXP_NOTICK
   if (d.any_on_tick) {
     for (int i = 0; i < A; i++) {  // per-agent on_tick (mettagrid_c.cpp:1019-1024); slot and class come from LDS
       const int li = i * MGX_WAVE + lane;
@@ -1704,6 +1708,7 @@ __device__ __forceinline__ void mgx_world_body(const MgxDev& d, PP P, uint8_t* o
       }
     }
   }
+#endif
   if constexpr (X) {
     if (d.NF > 0 || d.NT > 0)
       for (int i = 0; i < A; i++) {  // mettagrid_c.cpp:1032-1035
@@ -1722,8 +1727,12 @@ __device__ __forceinline__ void mgx_world_body(const MgxDev& d, PP P, uint8_t* o
     }
   }
   MGX_TICK(4);
+#ifndef MGX_EXP_NOFLUSH
   if (d.defer_book) e.bookkeeping_flush();
+#endif
+#ifndef MGX_EXP_NOCOV
   e.track_coverage_all();
+#endif
   MGX_TICK(5);
 }
 
