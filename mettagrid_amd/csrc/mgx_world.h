@@ -139,10 +139,11 @@ struct MgxEnvT {  // per-lane view of one env
   MgxXLds xl;
   MgxALds al_;
   mutable int cur_agent, cur_slot;  // agent whose action is being executed (LDS write-through of its position)
+  mutable int grid_dirty;           // a grid cell was written since do_move last looked at the move target
 #ifdef MGX_CONST_DEV
-  __device__ MgxEnvT(const MgxDev&, PP prog, int e) : P_(prog), env_(e), step(0), cur_agent(-1), cur_slot(-1) {
+  __device__ MgxEnvT(const MgxDev&, PP prog, int e) : P_(prog), env_(e), step(0), cur_agent(-1), cur_slot(-1), grid_dirty(1) {
 #else
-  __device__ MgxEnvT(const MgxDev& dd, PP prog, int e) : d(dd), P_(prog), env_(e), step(0), cur_agent(-1), cur_slot(-1) {
+  __device__ MgxEnvT(const MgxDev& dd, PP prog, int e) : d(dd), P_(prog), env_(e), step(0), cur_agent(-1), cur_slot(-1), grid_dirty(1) {
 #endif
     al_.slot = nullptr; al_.rc = nullptr; al_.prev = nullptr; al_.swm = nullptr; al_.act = nullptr; al_.cls = nullptr; al_.lane = 0; al_.A = 0;
     xl.def_delta = nullptr; xl.terr_score = nullptr; xl.lane = 0; xl.stride = MGX_WAVE; }
@@ -712,15 +713,19 @@ struct MgxEnvT {  // per-lane view of one env
       }
     }
   }
-  __device__ MGX_BIG bool move_object(int slot, int r, int c) const {
+  // Grid::move_object.  known_empty: the caller saw (r, c) empty and no grid cell has been written since (the acting
+  // agent stepping into the cell its own line scan just read) — the target is then not read again.
+  __device__ MGX_BIG bool move_object(int slot, int r, int c, bool known_empty = false) const {
     if (r < 0 || c < 0 || r >= d.H || c >= d.W) return false;
-    if (cell(r, c) != 0) return false;
-    uint16_t rc = d.obj_rc[so(slot)];
+    if (!known_empty && cell(r, c) != 0) return false;
+    const bool own = slot == cur_slot && AL().rc != nullptr;
+    const uint16_t rc = own ? AL().rc[cur_agent * MGX_WAVE + AL().lane] : d.obj_rc[so(slot)];
     cell(r, c) = (uint16_t)(slot + 1);
     cell(rc >> 8, rc & 0xFF) = 0;
+    grid_dirty = 1;
     d.obj_rc[so(slot)] = (uint16_t)((r << 8) | c);
     if (AL().rc) {
-      if (slot == cur_slot) AL().rc[cur_agent * MGX_WAVE + AL().lane] = (uint16_t)((r << 8) | c);
+      if (own) AL().rc[cur_agent * MGX_WAVE + AL().lane] = (uint16_t)((r << 8) | c);
       else { int a = agent_of(slot); if (a >= 0) AL().rc[a * MGX_WAVE + AL().lane] = (uint16_t)((r << 8) | c); }
     }
     territory_moved(slot);
@@ -744,7 +749,7 @@ struct MgxEnvT {  // per-lane view of one env
       d.obj_order[so(slot)] = ~0ull;
       for (int k = 0; k < d.R; k++) inv(slot, k) = 0;
       d.obj_flags[so(slot)] = 2;  // no ObservationEncoder: inventory is not observable (grid_object.cpp:194)
-      cell(r, c) = (uint16_t)(slot + 1);
+      cell(r, c) = (uint16_t)(slot + 1); grid_dirty = 1;
       PP ii = prog() + d.sec[MGX_SEC_INIT_INV] + C[MGX_C_INIT_INV_START] * MGX_II_WORDS;
       for (int i = 0; i < C[MGX_C_INIT_INV_COUNT]; i++, ii += MGX_II_WORDS) inv_update<0>(slot, ii[MGX_II_ITEM], ii[MGX_II_AMOUNT], true, true);
       for (int w = 0; w < MGX_TAG_WORDS; w++) d.obj_tags[so(slot) * MGX_TAG_WORDS + w] = (uint32_t)C[MGX_C_TAGS + w];
@@ -805,7 +810,7 @@ struct MgxEnvT {  // per-lane view of one env
       }
     }
     uint16_t rc = d.obj_rc[so(slot)];
-    cell(rc >> 8, rc & 0xFF) = 0;
+    cell(rc >> 8, rc & 0xFF) = 0; grid_dirty = 1;
     d.obj_flags[so(slot)] |= 1;
     for (int t = 0; t < 256 && d.NL > 0; t++) {  // TagIndex::unregister_object (core/tag_index.cpp:21-31)
       if (!has_tag(slot, t)) continue;
@@ -882,13 +887,16 @@ struct MgxEnvT {  // per-lane view of one env
         break;
       }
       case MGX_MOP_CHANGE_VIBE: { int e = resolve(c, a0); if (e >= 0) d.obj_vibe[so(e)] = (uint8_t)a1; break; }
-      case MGX_MOP_RELOCATE: if (agent_of(c.actor) >= 0) move_object(c.actor, c.target_r, c.target_c); break;
+      case MGX_MOP_RELOCATE:  // relocate_mutation.hpp: agents only
+        if (c.actor == cur_slot || agent_of(c.actor) >= 0)
+          move_object(c.actor, c.target_r, c.target_c, c.target == MGX_SLOT_NONE && !grid_dirty);
+        break;
       case MGX_MOP_SWAP: {  // swap_mutation.hpp:15-21, core/grid.hpp:92-105
         int xa = agent_of(c.actor), ya = agent_of(c.target);
         if (xa < 0 || ya < 0) break;
         uint16_t rx = d.obj_rc[so(c.actor)], ry = d.obj_rc[so(c.target)];
         cell(rx >> 8, rx & 0xFF) = (uint16_t)(c.target + 1);
-        cell(ry >> 8, ry & 0xFF) = (uint16_t)(c.actor + 1);
+        cell(ry >> 8, ry & 0xFF) = (uint16_t)(c.actor + 1); grid_dirty = 1;
         d.obj_rc[so(c.actor)] = ry;
         d.obj_rc[so(c.target)] = rx;
         if (AL().rc) { AL().rc[xa * MGX_WAVE + AL().lane] = ry; AL().rc[ya * MGX_WAVE + AL().lane] = rx; }
@@ -1305,6 +1313,7 @@ struct MgxEnvT {  // per-lane view of one env
         int r = (rc >> 8) + dy * i, c = (rc & 0xFF) + dx * i;
         if (r < 0 || c < 0 || r >= d.H || c >= d.W) break;
         int t = (int)cell(r, c) - 1;
+        grid_dirty = 0;
         if (t < 0 && !mh[MGX_MH_ACCEPTS_EMPTY]) continue;
         MgxCtx ctx = mgx_ctx(slot, t);
         ctx.target_r = r; ctx.target_c = c; ctx.move_direction = orient;
