@@ -412,6 +412,19 @@ int mgx_create(const int32_t* program, size_t program_words, const uint16_t* cla
     e->rewards_early = pure;
   }
   if (e->lds_world > 64 * 1024) { mgx_destroy(e); return fail(MGX_ERR_PROGRAM, "mgx_create: world kernel LDS staging too large"); }
+  {  // Build sanity: with a private segment (stack frames of the out-of-line handler functions + spills) of 9 200 bytes
+     // per lane the extended world kernel produced wrong results on gfx950 / ROCm 7.2 without any error; at 6 736 it is
+     // correct.  Refuse to run a build that is past 8 KiB instead of stepping envs wrongly.
+    const void* ks[] = {(const void*)mgx_world_kernel_ext<true>, (const void*)mgx_world_kernel_ext<false>, (const void*)mgx_init_kernel};
+    for (const void* k : ks) {
+      hipFuncAttributes fa;
+      if (hipFuncGetAttributes(&fa, k) == hipSuccess && fa.localSizeBytes > 8192) {
+        mgx_destroy(e);
+        return fail(MGX_ERR_HIP, "mgx_create: a kernel of this build needs " + std::to_string(fa.localSizeBytes) +
+                                     " bytes of private memory per lane (> 8192): rebuild with smaller stack frames");
+      }
+    }
+  }
   rc = size_obs_lds(e);
   if (rc != MGX_OK) { mgx_destroy(e); return rc; }
   hipError_t he = hipSuccess;

@@ -888,7 +888,7 @@ struct MgxEnvT {  // per-lane view of one env
       }
       case MGX_MOP_CHANGE_VIBE: { int e = resolve(c, a0); if (e >= 0) d.obj_vibe[so(e)] = (uint8_t)a1; break; }
       case MGX_MOP_RELOCATE:  // relocate_mutation.hpp: agents only
-        if (c.actor == cur_slot || agent_of(c.actor) >= 0)
+        if (c.actor >= 0 && (c.actor == cur_slot || agent_of(c.actor) >= 0))
           move_object(c.actor, c.target_r, c.target_c, c.target == MGX_SLOT_NONE && !grid_dirty);
         break;
       case MGX_MOP_SWAP: {  // swap_mutation.hpp:15-21, core/grid.hpp:92-105
@@ -1317,7 +1317,9 @@ struct MgxEnvT {  // per-lane view of one env
         if (t < 0 && !mh[MGX_MH_ACCEPTS_EMPTY]) continue;
         MgxCtx ctx = mgx_ctx(slot, t);
         ctx.target_r = r; ctx.target_c = c; ctx.move_direction = orient;
-        if (apply_handler<3>(mh[MGX_MH_HANDLER], ctx)) return true;
+        const bool applied = apply_handler<3>(mh[MGX_MH_HANDLER], ctx);
+        grid_dirty = 1;  // the "target seen empty" shortcut is only valid inside this handler chain
+        if (applied) return true;
         break;
       }
     }
