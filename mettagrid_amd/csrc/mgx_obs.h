@@ -297,9 +297,13 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
   }
   __syncthreads();
 
-  // ---- phase 0c: per-step token lists, one thread per queued object (a fraction of one wavefront in most envs) ----
+  // ---- phase 0c: per-step token lists, one thread per queued object (a fraction of one wavefront in most envs).
+  // The wavefronts that get no objects ("free") take the whole window-map phase and the global tokens meanwhile, so
+  // the workgroup's critical path is the longer of the two jobs, not their sum. ----
+  const int ndyn = (int)s_misc[1];
+  const int nbw = min((ndyn + MGX_WAVE - 1) / MGX_WAVE, MGX_OBS_WAVES);  // wavefronts with list-building work
+  const int nfree = MGX_OBS_WAVES - nbw;
   {
-    const int ndyn = (int)s_misc[1];
     const int f_vibe = d.feat[MGX_F_VIBE], f_group = d.feat[MGX_F_GROUP], f_agent = d.feat[MGX_F_AGENT_ID], f_tag = d.feat[MGX_F_TAG];
     VP feat = vp + d.sec[MGX_SEC_INV_FEATURES];
     for (int i = tid; i < ndyn; i += MGX_OBS_THREADS) {
@@ -335,14 +339,10 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
 #pragma unroll
         for (int w = 0; w < MGX_TAG_WORDS; w++) { tagw[w] = d.obj_tags[o * MGX_TAG_WORDS + w]; ntags += __popc(tagw[w]); }
       }
+      // worst-case length reserves the pool space (the host sized the pool for exactly this bound); the real length
+      // is known once the list is written
       int n = ntags;
-      if (!is_static) {
-        if (vibe != 0) n++;
-#pragma unroll
-        for (int k = 0; k < MGX_MAX_ITEMS; k++)
-          if (live_mask & (1u << k)) n += B.digits(amt[k]);
-        if (is_agent) n += 2;  // group + agent_id
-      }
+      if (!is_static) n += 1 + __popc(live_mask) * B.digits(65535u) + (is_agent ? 2 : 0);
       uint32_t info = 0;
       const uint32_t start = atomicAdd(&s_misc[0], (uint32_t)n);
       if ((int)(start + n) <= pool_tokens) {
@@ -375,7 +375,7 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
             w.put(f_agent, agent_id);
           }
         }
-        info = start | ((uint32_t)n << 16);
+        info = start | ((uint32_t)(w.pos - (int)start) << 16);
       } else {
         d.err[env] |= 16u;  // token pool exhausted (sized by the host from the class maps)
       }
@@ -408,7 +408,7 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
   }
 
   // ---- phase 1: window -> slot map of every agent, and the first observer (lowest agent index) of every object ----
-  for (int a = wave; a < A; a += MGX_OBS_WAVES) {
+  for (int a = nfree > 0 ? (wave >= nbw ? wave - nbw : A) : wave; a < A; a += nfree > 0 ? nfree : MGX_OBS_WAVES) {
     const uint32_t ag = s_agents[a];
     const int r0 = (ag >> 24) & 0xFF, c0 = (ag >> 16) & 0xFF;
     for (int j = lane; j < CP; j += MGX_WAVE) {
@@ -421,8 +421,7 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
     }
   }
   // global tokens (location 0xFE), mettagrid_c.cpp:700-753: one thread per agent, all agents at once
-  if (tid < A) {
-    const int a = tid;
+  for (int a = (wave == (nfree > 0 ? nbw : 0)) ? lane : A; a < A; a += MGX_WAVE) {
     const uint32_t ag = s_agents[a];
     const int my_slot = ag & 0xFFFF;
     const int r0 = (ag >> 24) & 0xFF, c0 = (ag >> 16) & 0xFF;
