@@ -234,6 +234,15 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
   };
 
   MGX_TICK0();
+  // The classification of object slot `tid` (phase 0b) needs only global data: its loads are issued first, so they
+  // are in flight together with the staging loads below instead of one barrier later.
+  uint16_t pre_cls = MGX_DEAD_CLASS;
+  uint32_t pre_vis = 0, pre_cinfo = 0;
+  if (tid < S) {
+    pre_cls = d.obj_cls[e.so(tid)];
+    pre_vis = d.obj_visited[e.so(tid)];
+    if (pre_cls != MGX_DEAD_CLASS) pre_cinfo = d.cls_tokinfo[pre_cls];
+  }
   // ---- phase 0a: stage the env (coalesced) ----
   {
     const uint4* src = (const uint4*)(d.grid + (size_t)env * HW);
@@ -278,12 +287,13 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
   MGX_PHASE_END(1);
   for (int s = tid; s < S; s += MGX_OBS_THREADS) {
     const size_t o = e.so(s);
-    const uint16_t cls = d.obj_cls[o];
-    const uint32_t vis = d.obj_visited[o];
+    const bool pre = s == tid;  // first pass: loaded above
+    const uint16_t cls = pre ? pre_cls : d.obj_cls[o];
+    const uint32_t vis = pre ? pre_vis : d.obj_visited[o];
     s_minobs[s] = 0xFFFFFFFFu;
     uint32_t info = 0;
     if (cls != MGX_DEAD_CLASS) {
-      const uint32_t cinfo = d.cls_tokinfo[cls];  // start(16) | group(8) | ntags(6) | agent(1) | static(1)
+      const uint32_t cinfo = pre ? pre_cinfo : d.cls_tokinfo[cls];  // start(16) | group(8) | ntags(6) | agent(1) | static(1)
       s_visited[s] = vis;
       if ((cinfo >> 31) != 0 && !dyn_tags) {
         info = (cinfo & 0xFFFFu) | (((cinfo >> 24) & 0x3Fu) << 16);
