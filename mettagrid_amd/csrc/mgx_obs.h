@@ -86,13 +86,14 @@ struct MgxBase {
 //   visited u32[S] | tokinfo u32[S] (start | count << 16) | dyn u16[S] (slots whose token list is built per step) |
 //   agents u32[A] (slot | rc << 16) | aginfo u32[A] | spawn u16[A] | vstat f32[A] | written i32[A] |
 //   rwinfo u32[A] (reward start | count << 16) | misc u32[4] | pool u16[POOL+8] | rows u32[WAVES][Tpad+64] |
-//   cell u16[A][CP] (slot + 1 under window cell j of agent a, 0 = empty / outside) | X extras |
+//   cell u16[A][CP], vj u8[A][CP], vcount u32[A]: per agent the occupied window cells in window order (slot + 1 and
+//   window index j of each), compacted | X extras |
 //   blk i32[blk_words]: program sections INV_FEATURES..OBS_VALUES (PL variants only) | gtok u32[A][GT] global tokens
 // CP = NOFF rounded up to 128 (two window cells per lane and pass).
 __host__ __device__ inline int mgx_align16(int x) { return (x + 15) & ~15; }
 struct MgxObsLds {
   int grid, offs, loc, minobs, visited, tokinfo, dyn, agents, aginfo, spawn, vstat, written, rwinfo, misc, pool, rows, row_words,
-      row_pitch, cell, cp, blk, gtok, total;
+      row_pitch, cell, vj, vcount, cp, blk, gtok, total;
   int owner, obsval, tscore;  // X only: per-cell territory owner u16[HW], obs values u32[A][NOV], scores i64[8][256]
 };
 // Upper bound of the global (location 0xFE) tokens of one agent: completion, last action, last action move, last
@@ -126,6 +127,8 @@ __host__ __device__ inline MgxObsLds mgx_obs_lds_layout(int HW, int NOFF, int S,
   l.row_pitch = l.row_words + MGX_WAVE;  // + one trash word per lane: masked-off stores land there, conflict-free
   l.rows = o; o += MGX_OBS_WAVES * l.row_pitch * 4;
   l.cell = o; o += mgx_align16(A * l.cp * 2);
+  l.vj = o; o += mgx_align16(A * l.cp);
+  l.vcount = o; o += mgx_align16(A * 4);
   l.owner = l.obsval = l.tscore = 0;
   if (X) {
     l.owner = o; o += mgx_align16(HW * 2);
@@ -181,6 +184,8 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
   uint32_t* s_row = (uint32_t*)(smem + L.rows) + wave * L.row_pitch;  // one u32 per token: loc | f << 8 | v << 16
   const int TRASH = L.row_words + lane;                               // s_row[TRASH]: target of this lane's masked-off stores
   uint16_t* s_cell = (uint16_t*)(smem + L.cell);
+  uint8_t* s_vj = smem + L.vj;
+  uint32_t* s_vcount = (uint32_t*)(smem + L.vcount);
   uint32_t* s_gtok = (uint32_t*)(smem + L.gtok);
 
   typedef MgxEnvT<MgxGlobalProg, X> Env;
@@ -417,18 +422,31 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
     if (d.n_obs_values > 0) __syncthreads();  // obs values are read by the global-token threads below
   }
 
-  // ---- phase 1: window -> slot map of every agent, and the first observer (lowest agent index) of every object ----
+  // ---- phase 1: per agent the list of window cells that will emit tokens, in window order (ballot compaction), and
+  // the first observer (lowest agent index) of every object.  The encode loop then only walks real entries. ----
   for (int a = nfree > 0 ? (wave >= nbw ? wave - nbw : A) : wave; a < A; a += nfree > 0 ? nfree : MGX_OBS_WAVES) {
     const uint32_t ag = s_agents[a];
     const int r0 = (ag >> 24) & 0xFF, c0 = (ag >> 16) & 0xFF;
+    int count = 0;
     for (int j = lane; j < CP; j += MGX_WAVE) {
       const char2 o = s_offs[min(j, NOFF - 1)];
       const int r = r0 + o.x, c = c0 + o.y;
       const bool inb = j < NOFF && (unsigned)r < (unsigned)d.H && (unsigned)c < (unsigned)d.W;
       const uint32_t cs = inb ? (uint32_t)s_grid[inb ? r * d.W + c : 0] : 0u;
-      s_cell[a * CP + j] = (uint16_t)cs;
+      bool keep = cs != 0;
+      if constexpr (X) {
+        if (want_mask && inb) keep = keep || s_owner[r * d.W + c] != 0xFFFF;  // mask-only cells still emit one token
+      }
       if (step > 0 && cs) atomicMin(&s_minobs[cs - 1], (uint32_t)a);
+      const unsigned long long m = __ballot(keep);
+      if (keep) {
+        const int k = count + __popcll(m & ((1ull << lane) - 1ull));
+        s_cell[a * CP + k] = (uint16_t)cs;
+        s_vj[a * CP + k] = (uint8_t)j;
+      }
+      count += __popcll(m);
     }
+    if (lane == 0) s_vcount[a] = (uint32_t)count;
   }
   // global tokens (location 0xFE), mettagrid_c.cpp:700-753: one thread per agent, all agents at once
   for (int a = (wave == (nfree > 0 ? nbw : 0)) ? lane : A; a < A; a += MGX_WAVE) {
@@ -480,7 +498,6 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
   MGX_PHASE_END(3);
 
   // ---- phase 2: encode ----
-  const int NPASS = CP / (2 * MGX_WAVE);  // two window cells per lane and pass
   for (int a = wave; a < A; a += MGX_OBS_WAVES) {
     const uint32_t ag = s_agents[a];
     const int my_slot = ag & 0xFFFF;
@@ -490,94 +507,79 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
     for (int k = lane; k < n_global && k < T; k += MGX_WAVE) s_row[k] = s_gtok[a * GT + k];
     int base_pos = n_global;
 
-    // window cells in reference order: lane handles cells j and j + 64 of each 128-cell pass; everything is LDS and
-    // every read is unconditional (empty / outside cells read slot 0 and are masked by a select)
+    // the agent's visible cells in reference (window) order, 64 per pass — one pass unless the window is crowded;
+    // everything is LDS and every read is unconditional (lanes past the list read entry 0 and are masked by a select)
     float visited_acc = s_vstat[a];
     bool visited_any = false;
-    for (int p = 0; p < NPASS; p++) {
-      int n[2], start[2];
-      uint32_t loc[2], mask[2] = {0, 0}, stale[2];
-#pragma unroll
-      for (int h = 0; h < 2; h++) {
-        const int j = p * 2 * MGX_WAVE + h * MGX_WAVE + lane;
-        const uint32_t cs = s_cell[a * CP + j];
-        const bool has = cs != 0;
-        const int slot = has ? (int)cs - 1 : 0;
-        const uint32_t info = s_tokinfo[slot];
-        loc[h] = s_loc[j];
-        start[h] = info & 0xFFFF;
-        n[h] = has ? (int)(info >> 16) : 0;
-        stale[h] = 0;
-        if (step > 0) {  // uniform
-          const uint32_t mo = s_minobs[slot], pv = s_visited[slot];
-          stale[h] = (has && mo == (uint32_t)a && pv < step) ? step - pv : 0u;
-        }
-        if constexpr (X) {
-          if (want_mask) {  // _emit_tile_observability_tokens (:337-362): before the cell's object tokens
-            const char2 o = s_offs[min(j, NOFF - 1)];
-            const int r = (int)((ag >> 24) & 0xFF) + o.x, c = (int)((ag >> 16) & 0xFF) + o.y;
-            if (j < NOFF && (unsigned)r < (unsigned)d.H && (unsigned)c < (unsigned)d.W) {
-              uint16_t ow = s_owner[r * d.W + c];
-              if (ow != 0xFFFF) { mask[h] = e.has_tag(my_slot, ow) ? 1u : 2u; n[h] += 1; }
-            }
-          }
+    const int nvis = (int)s_vcount[a];
+    for (int k0 = 0; k0 < nvis; k0 += MGX_WAVE) {
+      const int kk = k0 + lane;
+      const bool valid = kk < nvis;
+      const uint32_t cs = valid ? (uint32_t)s_cell[a * CP + kk] : 0u;
+      const int j = s_vj[a * CP + (valid ? kk : 0)];
+      const bool has = cs != 0;
+      const int slot = has ? (int)cs - 1 : 0;
+      const uint32_t info = s_tokinfo[slot];
+      const uint32_t loc = s_loc[j];
+      const int start = info & 0xFFFF;
+      int n = has ? (int)(info >> 16) : 0;
+      uint32_t stale = 0, mask = 0;
+      if (step > 0) {  // uniform
+        const uint32_t mo = s_minobs[slot], pv = s_visited[slot];
+        stale = (has && mo == (uint32_t)a && pv < step) ? step - pv : 0u;
+      }
+      if constexpr (X) {
+        if (want_mask && valid) {  // _emit_tile_observability_tokens (:337-362): before the cell's object tokens
+          const char2 o = s_offs[j];
+          const int r = (int)((ag >> 24) & 0xFF) + o.x, c = (int)((ag >> 16) & 0xFF) + o.y;
+          const uint16_t ow = s_owner[r * d.W + c];
+          if (ow != 0xFFFF) { mask = e.has_tag(my_slot, ow) ? 1u : 2u; n += 1; }
         }
       }
-      // one packed scan gives both halves' prefix sums (counts stay far below 65 536)
-      const int packed = n[0] | (n[1] << 16);
-      const int incl = mgx_wave_incl_scan(packed);
+      const int incl = mgx_wave_incl_scan(n);
       const int tot = __builtin_amdgcn_readlane(incl, MGX_WAVE - 1);
-      const int excl = incl - packed;
-      int pos0 = base_pos + (excl & 0xFFFF);
-      int pos1 = base_pos + (tot & 0xFFFF) + (excl >> 16);
+      int pos = base_pos + incl - n;
       if constexpr (X) {
-        if (mask[0]) { if (pos0 < T) s_row[pos0] = loc[0] | ((uint32_t)d.aoe_mask_feat << 8) | (mask[0] << 16); pos0++; n[0]--; }
-        if (mask[1]) { if (pos1 < T) s_row[pos1] = loc[1] | ((uint32_t)d.aoe_mask_feat << 8) | (mask[1] << 16); pos1++; n[1]--; }
+        if (mask) { if (pos < T) s_row[pos] = loc | ((uint32_t)d.aoe_mask_feat << 8) | (mask << 16); pos++; n--; }
       }
       // Token lists of up to MGX_SMALL_LIST entries (walls, plain objects) are copied by the cell's own lane; longer
       // ones (agents carrying an inventory: the observer itself is always one) by the whole wavefront, one list at
       // a time, so the copy loop's trip count is not set by the longest list in the window.
 #define MGX_SMALL_LIST 3
-#pragma unroll
-      for (int h = 0; h < 2; h++) {
-        const int ph = h ? pos1 : pos0;
-        const bool big = n[h] > MGX_SMALL_LIST;
-        const int ns = big ? 0 : n[h];
+      {
+        const bool big = n > MGX_SMALL_LIST;
+        const int ns = big ? 0 : n;
 #pragma unroll
         for (int k = 0; k < MGX_SMALL_LIST; k++) {  // pool has 8 spare entries: the read is always in range
-          const uint32_t tok = loc[h] | ((uint32_t)s_pool[start[h] + k] << 8);
-          s_row[(k < ns && ph + k < T) ? ph + k : TRASH] = tok;
+          const uint32_t tok = loc | ((uint32_t)s_pool[start + k] << 8);
+          s_row[(k < ns && pos + k < T) ? pos + k : TRASH] = tok;
         }
         unsigned long long bm = __ballot(big);
         while (bm) {
           const int l = __ffsll((long long)bm) - 1;
           bm &= bm - 1;
-          const int bp = __builtin_amdgcn_readlane(ph, l), bs = __builtin_amdgcn_readlane(start[h], l);
-          const int bn = __builtin_amdgcn_readlane(n[h], l);
-          const uint32_t bl = (uint32_t)__builtin_amdgcn_readlane((int)loc[h], l);
+          const int bp = __builtin_amdgcn_readlane(pos, l), bs = __builtin_amdgcn_readlane(start, l);
+          const int bn = __builtin_amdgcn_readlane(n, l);
+          const uint32_t bl = (uint32_t)__builtin_amdgcn_readlane((int)loc, l);
           for (int k = lane; k < bn; k += MGX_WAVE)
             if (bp + k < T) s_row[bp + k] = bl | ((uint32_t)s_pool[bs + k] << 8);
         }
       }
-      base_pos += (tot & 0xFFFF) + (tot >> 16);
+      base_pos += tot;
       // cell.visited staleness (:789-796): the reference adds the values one by one in cell order.  All of them are
       // integers, so while the running sum is an integer below 2^24 every partial sum is exact and the order does not
       // matter: one wavefront sum.  Otherwise replay the serial order.
-      const unsigned long long fm0 = __ballot(stale[0] != 0), fm1 = __ballot(stale[1] != 0);
-      if (fm0 | fm1) {
+      unsigned long long fm = __ballot(stale != 0);
+      if (fm) {
         visited_any = true;
-        const uint32_t ssum = mgx_wave_sum(stale[0] + stale[1]);
+        const uint32_t ssum = mgx_wave_sum(stale);
         if (visited_acc == truncf(visited_acc) && visited_acc >= 0.f && visited_acc + (float)ssum <= 16777216.f && ssum < 16777216u) {
           visited_acc += (float)ssum;
         } else {
-#pragma unroll
-          for (int h = 0; h < 2; h++) {
-            unsigned long long m = h ? fm1 : fm0;
-            while (m) {
-              const int l = __ffsll((long long)m) - 1;
-              m &= m - 1;
-              visited_acc = __fadd_rn(visited_acc, (float)(uint32_t)__builtin_amdgcn_readlane((int)stale[h], l));
-            }
+          while (fm) {
+            const int l = __ffsll((long long)fm) - 1;
+            fm &= fm - 1;
+            visited_acc = __fadd_rn(visited_acc, (float)(uint32_t)__builtin_amdgcn_readlane((int)stale, l));
           }
         }
       }
