@@ -1085,6 +1085,104 @@ struct MgxEnvT {  // per-lane view of one env
     }
     return any;
   }
+  // Iterative form of apply_handler<3> for the lean variant (no tag handlers, no queries: the only nested handler
+  // applications are a multi-handler's children and UseTarget's on_use / on_after_use).  An explicit stack of at most
+  // four frames (the template depth of the recursive form) lives in registers; there is ONE copy of the filter and
+  // mutation interpreters and no recursion, so the whole VM can be inlined into the kernel.
+  // The only ctx field a lean handler chain changes is mutation_failed, and on_use runs on a COPY of the ctx
+  // (use_target_mutation.hpp:17-29): ctx copies are therefore one `failed` bit per ctx slot, the rest is shared.
+  __device__ __forceinline__ bool run_handler(int h0, MgxCtx& c) const {
+    enum { ST_ENTER = 0, ST_KIDS = 1, ST_MUTS = 2, ST_USE_RET = 3, ST_AFTER_RET = 4 };
+    int fh0 = h0, fh1 = 0, fh2 = 0, fh3 = 0;  // handler of frame k
+    int fs0 = 0, fs1 = 0, fs2 = 0, fs3 = 0;   // i | stage << 16 | any << 20 | ctx slot << 24
+    int sp = 0;
+    bool rv = false;
+    uint32_t failed = 0;
+    PP handlers = prog() + d.sec[MGX_SEC_HANDLERS];
+    while (sp >= 0) {
+      const int h = sp == 0 ? fh0 : sp == 1 ? fh1 : sp == 2 ? fh2 : fh3;
+      const int fs = sp == 0 ? fs0 : sp == 1 ? fs1 : sp == 2 ? fs2 : fs3;
+      int i = fs & 0xFFFF, stage = (fs >> 16) & 0xF, any = (fs >> 20) & 1;
+      const int cs = (fs >> 24) & 3;
+      PP hd = handlers + h * MGX_HD_WORDS;
+      int push_h = -1, push_cs = 0;  // handler to apply next (new frame), if any
+      bool pop = false;
+      if (stage == ST_ENTER) {
+        if (hd[MGX_HD_KIND] == MGX_HK_LEAF) {
+          if (!check_filters<0>(hd[MGX_HD_FILTER_PC], c, 0)) { rv = false; pop = true; }
+          else { failed &= ~(1u << cs); stage = ST_MUTS; i = 0; }
+        } else if (sp == 3) {  // a multi-handler at the last level: recursive form flags and returns "none applied"
+          flag(4u);
+          rv = false;
+          pop = true;
+        } else {
+          stage = ST_KIDS; i = 0; any = 0;
+        }
+      } else if (stage == ST_KIDS) {
+        bool done = false;
+        if (i > 0 && rv) {
+          any = 1;
+          if (hd[MGX_HD_KIND] == MGX_HK_FIRST_MATCH) { rv = true; pop = true; done = true; }
+        }
+        if (!done) {
+          if (i < hd[MGX_HD_CHILD_COUNT]) {
+            push_h = (prog() + d.sec[MGX_SEC_CHILDREN] + hd[MGX_HD_CHILD_START])[i];
+            push_cs = cs;
+            i++;
+          } else {
+            rv = any != 0;
+            pop = true;
+          }
+        }
+      } else if (stage == ST_MUTS) {
+        if (i > 0 && ((failed >> cs) & 1u)) { rv = false; pop = true; }
+        else if (i >= hd[MGX_HD_MUT_COUNT]) { rv = true; pop = true; }
+        else {
+          PP m = prog() + d.sec[MGX_SEC_MUTS] + (hd[MGX_HD_MUT_START] + i) * MGX_MU_WORDS;
+          i++;
+          if (m[MGX_MU_OP] == MGX_MOP_USE_TARGET) {  // use_target_mutation.hpp:17-29, core/grid_object.cpp:72-80
+            int h2 = -1;
+            const bool valid = c.target >= 0 && c.actor >= 0 && (c.actor == cur_slot || agent_of(c.actor) >= 0);
+            if (valid) {
+              if (sp == 3) flag(4u);
+              else h2 = cls_of(c.target)[MGX_C_ON_USE];
+            }
+            if (h2 < 0) failed |= 1u << cs;
+            else { stage = ST_USE_RET; push_h = h2; push_cs = cs + 1; }
+          } else {
+            c.mutation_failed = false;
+            mutate<0>(m, c);
+            if (c.mutation_failed) failed |= 1u << cs;
+          }
+        }
+      } else if (stage == ST_USE_RET) {
+        stage = ST_MUTS;
+        if (!rv) failed |= 1u << cs;
+        else {
+          const int after = cls_of(c.actor)[MGX_C_ON_AFTER_USE];
+          if (after >= 0) { stage = ST_AFTER_RET; push_h = after; push_cs = cs; }
+        }
+      } else {  // ST_AFTER_RET: the result of on_after_use is ignored
+        stage = ST_MUTS;
+      }
+      if (pop) { sp--; continue; }
+      const int nfs = i | (stage << 16) | (any << 20) | (cs << 24);
+      if (sp == 0) fs0 = nfs; else if (sp == 1) fs1 = nfs; else if (sp == 2) fs2 = nfs; else fs3 = nfs;
+      if (push_h >= 0) {
+        sp++;
+        const int pfs = (ST_ENTER << 16) | (push_cs << 24);
+        if (sp == 1) { fh1 = push_h; fs1 = pfs; } else if (sp == 2) { fh2 = push_h; fs2 = pfs; } else { fh3 = push_h; fs3 = pfs; }
+      }
+    }
+    c.mutation_failed = (failed & 1u) != 0;
+    return rv;
+  }
+  // apply a top-level handler: iterative VM in the lean variant, recursive templates in the extended one
+  __device__ __forceinline__ bool apply_top(int h, MgxCtx& c) const {
+    if constexpr (X) return apply_handler<3>(h, c);
+    else return run_handler(h, c);
+  }
+
   // Filters + every mutation, no stop on mutation_failed (events, AoE sources, territory handlers:
   // handler/event.cpp:86-92, core/aoe_tracker.cpp:99-113, core/territory_tracker.cpp:62-66).
   __device__ MGX_BIG bool apply_all(int filter_pc, int mut_start, int mut_count, MgxCtx& c) const {
@@ -1317,7 +1415,7 @@ struct MgxEnvT {  // per-lane view of one env
         if (t < 0 && !mh[MGX_MH_ACCEPTS_EMPTY]) continue;
         MgxCtx ctx = mgx_ctx(slot, t);
         ctx.target_r = r; ctx.target_c = c; ctx.move_direction = orient;
-        const bool applied = apply_handler<3>(mh[MGX_MH_HANDLER], ctx);
+        const bool applied = apply_top(mh[MGX_MH_HANDLER], ctx);
         grid_dirty = 1;  // the "target seen empty" shortcut is only valid inside this handler chain
         if (applied) return true;
         break;
@@ -1715,7 +1813,7 @@ __device__ __forceinline__ void mgx_world_body(const MgxDev& d, PP P, uint8_t* o
       if (h >= 0) {
         const int slot = al.slot[li];
         MgxCtx c = mgx_ctx(slot, slot);
-        e.template apply_handler<3>(h, c);
+        e.apply_top(h, c);
       }
     }
   }
