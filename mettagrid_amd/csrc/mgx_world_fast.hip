@@ -1,9 +1,7 @@
-// mgx_world_fast.hip — the non-extended world-update kernels (games without rung-4 features: no dynamic tags,
-// queries, events, AoE, territory, run-time object creation).  Own translation unit so that the handler VM can be
-// compiled with MGX_BIG=__forceinline__: one flat kernel, MgxDev in SGPRs, global_load/ds_read only, no calls.
-#ifdef MGX_FAST_INLINE
-#define MGX_BIG __forceinline__
-#endif
+// mgx_world_fast.hip — the lean world-update kernels (games without rung-4 features: no dynamic tags, queries,
+// events, AoE, territory, run-time object creation).  Own translation unit: MgxDev in constant memory, the iterative
+// handler VM, and MGX_BIG=__forceinline__ — one flat kernel, global_load/ds_read only, no calls but mgx_logf.
+#define MGX_BIG __forceinline__  // safe here: the lean variant's handler VM is iterative (MgxEnvT::run_handler)
 #define MGX_WORLD_FAST_TU 1
 #define MGX_CONST_DEV 1
 #define MGX_WORLD_IDS 1
