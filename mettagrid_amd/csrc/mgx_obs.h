@@ -44,6 +44,15 @@ __device__ __forceinline__ int mgx_wave_incl_scan(int x) {
   return x;
 }
 
+// Inclusive scan inside each 16-lane DPP row (Hillis-Steele, four row shifts, zero fill at the row start).
+__device__ __forceinline__ int mgx_row_incl_scan(int x) {
+  x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);  // row_shr:1
+  x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);  // row_shr:2
+  x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);  // row_shr:4
+  x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);  // row_shr:8
+  return x;
+}
+
 __device__ __forceinline__ int mgx_digits(uint32_t v, uint32_t base) {  // encoding_utils.hpp:39-62
   int n = 1;
   v /= base;
@@ -85,7 +94,7 @@ struct MgxBase {
 //   grid u16[HW] | offsets i8x2[NOFF] | loc u8[CP] (packed window coordinate of offset j) | minobs u32[S+1] |
 //   visited u32[S] | tokinfo u32[S] (start | count << 16) | dyn u16[S] (slots whose token list is built per step) |
 //   agents u32[A] (slot | rc << 16) | aginfo u32[A] | spawn u16[A] | vstat f32[A] | written i32[A] |
-//   rwinfo u32[A] (reward start | count << 16) | misc u32[4] | pool u16[POOL+8] | rows u32[WAVES][Tpad+64] |
+//   rwinfo u32[A] (reward start | count << 16) | misc u32[4] | pool u16[POOL+8] | rows u32[WAVES*4][Tpad+16] |
 //   cell u16[A][CP], vj u8[A][CP], vcount u32[A]: per agent the occupied window cells in window order (slot + 1 and
 //   window index j of each), compacted | X extras |
 //   blk i32[blk_words]: program sections INV_FEATURES..OBS_VALUES (PL variants only) | gtok u32[A][GT] global tokens
@@ -124,8 +133,8 @@ __host__ __device__ inline MgxObsLds mgx_obs_lds_layout(int HW, int NOFF, int S,
   l.misc = o; o += 16;
   l.pool = o; o += mgx_align16((pool_tokens + 8) * 2);
   l.row_words = (T + 3) & ~3;
-  l.row_pitch = l.row_words + MGX_WAVE;  // + one trash word per lane: masked-off stores land there, conflict-free
-  l.rows = o; o += MGX_OBS_WAVES * l.row_pitch * 4;
+  l.row_pitch = l.row_words + 16;  // + one trash word per lane of a 16-lane row: masked-off stores land there
+  l.rows = o; o += MGX_OBS_WAVES * 4 * l.row_pitch * 4;  // one staging row per DPP row of every wavefront
   l.cell = o; o += mgx_align16(A * l.cp * 2);
   l.vj = o; o += mgx_align16(A * l.cp);
   l.vcount = o; o += mgx_align16(A * 4);
@@ -181,8 +190,9 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
   uint32_t* s_rwinfo = (uint32_t*)(smem + L.rwinfo);
   uint32_t* s_misc = (uint32_t*)(smem + L.misc);
   uint16_t* s_pool = (uint16_t*)(smem + L.pool);
-  uint32_t* s_row = (uint32_t*)(smem + L.rows) + wave * L.row_pitch;  // one u32 per token: loc | f << 8 | v << 16
-  const int TRASH = L.row_words + lane;                               // s_row[TRASH]: target of this lane's masked-off stores
+  const int row = lane >> 4, rl = lane & 15;  // encode: one agent per 16-lane DPP row
+  uint32_t* s_row = (uint32_t*)(smem + L.rows) + (wave * 4 + row) * L.row_pitch;  // one u32 per token: loc | f << 8 | v << 16
+  const int TRASH = L.row_words + rl;  // s_row[TRASH]: target of this lane's masked-off stores
   uint16_t* s_cell = (uint16_t*)(smem + L.cell);
   uint8_t* s_vj = smem + L.vj;
   uint32_t* s_vcount = (uint32_t*)(smem + L.vcount);
@@ -497,26 +507,32 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
   MGX_TICK(10);
   MGX_PHASE_END(3);
 
-  // ---- phase 2: encode ----
-  for (int a = wave; a < A; a += MGX_OBS_WAVES) {
-    const uint32_t ag = s_agents[a];
+  // ---- phase 2: encode.  One agent per 16-lane DPP row, four agents per wavefront at a time: an agent sees ~15-20
+  // occupied cells, so a whole wavefront per agent left three quarters of the lanes idle.  Scans are row scans (four
+  // DPP steps), row-wide values travel by ds_bpermute, long token lists are copied by the 16 lanes of their row. ----
+  for (int a0 = wave * 4; a0 < A; a0 += MGX_OBS_WAVES * 4) {
+    const int a = a0 + row;
+    const bool av = a < A;          // this row has an agent
+    const int ac = av ? a : A - 1;  // clamped for the unconditional reads
+    const uint32_t ag = s_agents[ac];
     const int my_slot = ag & 0xFFFF;
-    for (int i = lane; i < L.row_words / 4; i += MGX_WAVE) ((uint4*)s_row)[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
+    for (int i = rl; i < L.row_words / 4; i += 16) ((uint4*)s_row)[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
     // global tokens were assembled once per env above; copy this agent's
-    const int n_global = (int)s_aginfo[a];
-    for (int k = lane; k < n_global && k < T; k += MGX_WAVE) s_row[k] = s_gtok[a * GT + k];
+    const int n_global = av ? (int)s_aginfo[ac] : 0;
+    for (int k = rl; k < n_global && k < T; k += 16) s_row[k] = s_gtok[ac * GT + k];
     int base_pos = n_global;
-
-    // the agent's visible cells in reference (window) order, 64 per pass — one pass unless the window is crowded;
-    // everything is LDS and every read is unconditional (lanes past the list read entry 0 and are masked by a select)
-    float visited_acc = s_vstat[a];
+    float visited_acc = s_vstat[ac];
     bool visited_any = false;
-    const int nvis = (int)s_vcount[a];
-    for (int k0 = 0; k0 < nvis; k0 += MGX_WAVE) {
-      const int kk = k0 + lane;
+    const int nvis = av ? (int)s_vcount[ac] : 0;
+    const int nmax = max(max(__builtin_amdgcn_readlane(nvis, 0), __builtin_amdgcn_readlane(nvis, 16)),
+                         max(__builtin_amdgcn_readlane(nvis, 32), __builtin_amdgcn_readlane(nvis, 48)));
+    // the agent's visible cells in reference (window) order, 16 per pass; everything is LDS and every read is
+    // unconditional (lanes past the list read entry 0 and are masked by a select)
+    for (int k0 = 0; k0 < nmax; k0 += 16) {
+      const int kk = k0 + rl;
       const bool valid = kk < nvis;
-      const uint32_t cs = valid ? (uint32_t)s_cell[a * CP + kk] : 0u;
-      const int j = s_vj[a * CP + (valid ? kk : 0)];
+      const uint32_t cs = valid ? (uint32_t)s_cell[ac * CP + kk] : 0u;
+      const int j = s_vj[ac * CP + (valid ? kk : 0)];
       const bool has = cs != 0;
       const int slot = has ? (int)cs - 1 : 0;
       const uint32_t info = s_tokinfo[slot];
@@ -536,15 +552,15 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
           if (ow != 0xFFFF) { mask = e.has_tag(my_slot, ow) ? 1u : 2u; n += 1; }
         }
       }
-      const int incl = mgx_wave_incl_scan(n);
-      const int tot = __builtin_amdgcn_readlane(incl, MGX_WAVE - 1);
+      const int incl = mgx_row_incl_scan(n);
+      const int tot = __shfl(incl, lane | 15);
       int pos = base_pos + incl - n;
       if constexpr (X) {
         if (mask) { if (pos < T) s_row[pos] = loc | ((uint32_t)d.aoe_mask_feat << 8) | (mask << 16); pos++; n--; }
       }
       // Token lists of up to MGX_SMALL_LIST entries (walls, plain objects) are copied by the cell's own lane; longer
-      // ones (agents carrying an inventory: the observer itself is always one) by the whole wavefront, one list at
-      // a time, so the copy loop's trip count is not set by the longest list in the window.
+      // ones (agents carrying an inventory: the observer itself is always one) by the 16 lanes of the row, one list
+      // at a time, so the copy loop's trip count is not set by the longest list in the window.
 #define MGX_SMALL_LIST 3
       {
         const bool big = n > MGX_SMALL_LIST;
@@ -554,44 +570,48 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
           const uint32_t tok = loc | ((uint32_t)s_pool[start + k] << 8);
           s_row[(k < ns && pos + k < T) ? pos + k : TRASH] = tok;
         }
-        unsigned long long bm = __ballot(big);
-        while (bm) {
-          const int l = __ffsll((long long)bm) - 1;
-          bm &= bm - 1;
-          const int bp = __builtin_amdgcn_readlane(pos, l), bs = __builtin_amdgcn_readlane(start, l);
-          const int bn = __builtin_amdgcn_readlane(n, l);
-          const uint32_t bl = (uint32_t)__builtin_amdgcn_readlane((int)loc, l);
-          for (int k = lane; k < bn; k += MGX_WAVE)
+        uint32_t rm = (uint32_t)(__ballot(big) >> (row * 16)) & 0xFFFFu;  // this row's long lists
+        while (__ballot(rm != 0)) {
+          const bool mine = rm != 0;
+          const int src = row * 16 + (mine ? __ffs(rm) - 1 : 0);
+          rm &= rm - 1;
+          const int bp = __shfl(pos, src), bs = __shfl(start, src), bn = mine ? __shfl(n, src) : 0;
+          const uint32_t bl = (uint32_t)__shfl((int)loc, src);
+          for (int k = rl; k < bn; k += 16)
             if (bp + k < T) s_row[bp + k] = bl | ((uint32_t)s_pool[bs + k] << 8);
         }
       }
       base_pos += tot;
       // cell.visited staleness (:789-796): the reference adds the values one by one in cell order.  All of them are
       // integers, so while the running sum is an integer below 2^24 every partial sum is exact and the order does not
-      // matter: one wavefront sum.  Otherwise replay the serial order.
-      unsigned long long fm = __ballot(stale != 0);
-      if (fm) {
-        visited_any = true;
-        const uint32_t ssum = mgx_wave_sum(stale);
-        if (visited_acc == truncf(visited_acc) && visited_acc >= 0.f && visited_acc + (float)ssum <= 16777216.f && ssum < 16777216u) {
-          visited_acc += (float)ssum;
-        } else {
-          while (fm) {
-            const int l = __ffsll((long long)fm) - 1;
-            fm &= fm - 1;
-            visited_acc = __fadd_rn(visited_acc, (float)(uint32_t)__builtin_amdgcn_readlane((int)stale, l));
+      // matter: one row sum.  Otherwise replay the serial order.
+      uint32_t fm = (uint32_t)(__ballot(stale != 0) >> (row * 16)) & 0xFFFFu;
+      if (__ballot(fm != 0)) {
+        const uint32_t ssum = (uint32_t)__shfl(mgx_row_incl_scan((int)stale), lane | 15);
+        if (fm != 0) {
+          visited_any = true;
+          if (visited_acc == truncf(visited_acc) && visited_acc >= 0.f && visited_acc + (float)ssum <= 16777216.f && ssum < 16777216u) {
+            visited_acc += (float)ssum;
+            fm = 0;
           }
+        }
+        while (__ballot(fm != 0)) {  // serial replay for the rows that could not take the exact shortcut
+          const bool mine = fm != 0;
+          const int src = row * 16 + (mine ? __ffs(fm) - 1 : 0);
+          fm &= fm - 1;
+          const uint32_t sv = (uint32_t)__shfl((int)stale, src);
+          if (mine) visited_acc = __fadd_rn(visited_acc, (float)sv);
         }
       }
     }
-    if (lane == 0) {
+    if (rl == 0 && av) {
       if (visited_any) e.astat_set(a, sid_visited, visited_acc);
       s_written[a] = base_pos;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // LDS row complete before it is read back
-    // ---- pack 4 tokens (4 x u32, low 3 bytes valid) into 12 bytes and store them: one coalesced pass per row ----
-    uint8_t* out = d.obs + ((size_t)env * A + a) * (size_t)T * 3;
-    for (int q = lane; q * 4 < T; q += MGX_WAVE) {
+    // ---- pack 4 tokens (4 x u32, low 3 bytes valid) into 12 bytes and store them: the row's 16 lanes sweep it ----
+    uint8_t* out = d.obs + ((size_t)env * A + ac) * (size_t)T * 3;
+    for (int q = rl; q * 4 < T && av; q += 16) {
       uint4 t = ((const uint4*)s_row)[q];
       uint32_t w0 = (t.x & 0xFFFFFFu) | (t.y << 24);
       uint32_t w1 = ((t.y >> 8) & 0xFFFFu) | (t.z << 16);
