@@ -98,7 +98,7 @@ struct MgxBase {
 //   cell u16[A][CP], vj u8[A][CP], vcount u32[A]: per agent the occupied window cells in window order (slot + 1 and
 //   window index j of each), compacted | X extras |
 //   blk i32[blk_words]: program sections INV_FEATURES..OBS_VALUES (PL variants only) | gtok u32[A][GT] global tokens
-// CP = NOFF rounded up to 128 (two window cells per lane and pass).
+// CP = NOFF rounded up to 16: stride of the per-agent lists.
 __host__ __device__ inline int mgx_align16(int x) { return (x + 15) & ~15; }
 struct MgxObsLds {
   int grid, offs, loc, minobs, visited, tokinfo, dyn, agents, aginfo, spawn, vstat, written, rwinfo, misc, pool, rows, row_words,
@@ -116,7 +116,7 @@ __host__ __device__ inline MgxObsLds mgx_obs_lds_layout(int HW, int NOFF, int S,
                                                         bool X = false, int NOV = 0, int blk_words = 0, int GT = 6) {
   MgxObsLds l;
   int o = 0;
-  l.cp = ((NOFF + 2 * MGX_WAVE - 1) / (2 * MGX_WAVE)) * 2 * MGX_WAVE;
+  l.cp = (NOFF + 15) & ~15;
   l.grid = o; o += mgx_align16(HW * 2);
   l.offs = o; o += mgx_align16(NOFF * 2);
   l.loc = o; o += mgx_align16(l.cp);
@@ -438,7 +438,7 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
     const uint32_t ag = s_agents[a];
     const int r0 = (ag >> 24) & 0xFF, c0 = (ag >> 16) & 0xFF;
     int count = 0;
-    for (int j = lane; j < CP; j += MGX_WAVE) {
+    for (int j = lane; j < ((NOFF + MGX_WAVE - 1) & ~(MGX_WAVE - 1)); j += MGX_WAVE) {  // whole wavefront in every pass (ballots)
       const char2 o = s_offs[min(j, NOFF - 1)];
       const int r = r0 + o.x, c = c0 + o.y;
       const bool inb = j < NOFF && (unsigned)r < (unsigned)d.H && (unsigned)c < (unsigned)d.W;
