@@ -117,8 +117,14 @@ __host__ __device__ inline MgxObsLds mgx_obs_lds_layout(int HW, int NOFF, int S,
   MgxObsLds l;
   int o = 0;
   l.cp = (NOFF + 15) & ~15;
-  l.grid = o; o += mgx_align16(HW * 2);
-  l.offs = o; o += mgx_align16(NOFF * 2);
+  // The grid and the window offsets are dead once the visible-cell lists exist (barrier before the encode phase), the
+  // staging rows are first written after it: in the lean variant the rows overlay them (the extended encode still
+  // reads the offsets for the territory mask).
+  const bool overlay = !X;
+  if (!overlay) {
+    l.grid = o; o += mgx_align16(HW * 2);
+    l.offs = o; o += mgx_align16(NOFF * 2);
+  }
   l.loc = o; o += mgx_align16(l.cp);
   l.minobs = o; o += mgx_align16((S + 1) * 4);
   l.visited = o; o += mgx_align16(S * 4);
@@ -134,7 +140,18 @@ __host__ __device__ inline MgxObsLds mgx_obs_lds_layout(int HW, int NOFF, int S,
   l.pool = o; o += mgx_align16((pool_tokens + 8) * 2);
   l.row_words = (T + 3) & ~3;
   l.row_pitch = l.row_words + 16;  // + one trash word per lane of a 16-lane row: masked-off stores land there
-  l.rows = o; o += MGX_OBS_WAVES * 4 * l.row_pitch * 4;  // one staging row per DPP row of every wavefront
+  l.rows = o;
+  {
+    const int rows_bytes = MGX_OBS_WAVES * 4 * l.row_pitch * 4;  // one staging row per DPP row of every wavefront
+    const int early_bytes = mgx_align16(HW * 2) + mgx_align16(NOFF * 2);
+    if (overlay) {
+      l.grid = o;
+      l.offs = o + mgx_align16(HW * 2);
+      o += rows_bytes > early_bytes ? rows_bytes : early_bytes;
+    } else {
+      o += rows_bytes;
+    }
+  }
   l.cell = o; o += mgx_align16(A * l.cp * 2);
   l.vj = o; o += mgx_align16(A * l.cp);
   l.vcount = o; o += mgx_align16(A * 4);
