@@ -73,6 +73,7 @@ struct mgx_engine {
     }
     return best;
   }
+  bool verbose = false;
   bool rewards_early = false;  // reward expressions have no stat operands: evaluated beside the token-cache phase
   uint16_t* dmaps = nullptr;
   uint32_t* dseeds = nullptr;
@@ -110,9 +111,13 @@ struct mgx_engine {
 static int size_obs_lds(mgx_engine* e) {
   const MgxDev& d = e->d;
   e->lds_obs = (size_t)mgx_obs_lds_layout(d.H * d.W, d.NOFF, d.S, d.A, d.T, e->pool_tokens, d.X != 0, d.n_obs_values,
-                                          e->obs_blk_lds ? e->obs_blk_words : 0, mgx_obs_gt(d.n_obs_values, d.base)).total;
+                                          e->obs_blk_lds ? e->obs_blk_words : 0, mgx_obs_gt(d.n_obs_values, d.base),
+                                          e->rewards_early).total;
   if (e->lds_obs > 160 * 1024)
     return fail(MGX_ERR_PROGRAM, "map/object count too large for the LDS staging of the observation kernel");
+  if (e->verbose || getenv("MGX_VERBOSE"))
+    fprintf(stderr, "[mgx] obs: lds=%zu B pool=%d tokens (prefix %d) blk_lds=%d rewards_early=%d\n", e->lds_obs, e->pool_tokens,
+            e->pool_prefix, (int)e->obs_blk_lds, (int)e->rewards_early);
   const void* fns[] = {(const void*)mgx_obs_kernel<true, false, false>, (const void*)mgx_obs_kernel<false, false, false>,
                        (const void*)mgx_obs_kernel<true, false, true>,  (const void*)mgx_obs_kernel<false, false, true>,
                        (const void*)mgx_obs_kernel<true, true, false>,  (const void*)mgx_obs_kernel<false, true, false>};
@@ -326,6 +331,7 @@ int mgx_create(const int32_t* program, size_t program_words, const uint16_t* cla
   if (getenv("MGX_VERBOSE"))
     fprintf(stderr, "[mgx] E=%d A=%d S=%d program=%zu B world: X=%d prog_in_lds=%d lds=%zu B\n", d.E, d.A, d.S,
             program_words * 4, d.X, (int)e->prog_in_lds, e->lds_world);
+  e->verbose = getenv("MGX_VERBOSE") != nullptr;
   {  // per-class static tag tokens (ascending tag id, core/grid_object.cpp:181-186)
     std::vector<uint32_t> info(P[MGX_H_NUM_CLASSES]);
     std::vector<uint16_t> toks;

@@ -113,12 +113,14 @@ __host__ __device__ inline int mgx_obs_gt(int NOV, int base) {
   return 6 + NOV * digits;
 }
 __host__ __device__ inline MgxObsLds mgx_obs_lds_layout(int HW, int NOFF, int S, int A, int T, int pool_tokens,
-                                                        bool X = false, int NOV = 0, int blk_words = 0, int GT = 6) {
+                                                        bool X = false, int NOV = 0, int blk_words = 0, int GT = 6,
+                                                        bool blk_early = false) {
   MgxObsLds l;
   int o = 0;
   l.cp = (NOFF + 15) & ~15;
-  // The grid and the window offsets are dead once the visible-cell lists exist (barrier before the encode phase), the
-  // staging rows are first written after it: in the lean variant the rows overlay them (the extended encode still
+  // The grid, the window offsets, the list-builder queue and (when the rewards are evaluated early, blk_early) the
+  // program block are dead once the visible-cell lists and the global tokens exist (barrier before the encode phase);
+  // the staging rows are first written after it: in the lean variant the rows overlay them (the extended encode still
   // reads the offsets for the territory mask).
   const bool overlay = !X;
   if (!overlay) {
@@ -129,7 +131,7 @@ __host__ __device__ inline MgxObsLds mgx_obs_lds_layout(int HW, int NOFF, int S,
   l.minobs = o; o += mgx_align16((S + 1) * 4);
   l.visited = o; o += mgx_align16(S * 4);
   l.tokinfo = o; o += mgx_align16(S * 4);
-  l.dyn = o; o += mgx_align16(S * 2);
+  if (!overlay) { l.dyn = o; o += mgx_align16(S * 2); }
   l.agents = o; o += mgx_align16(A * 4);
   l.aginfo = o; o += mgx_align16(A * 4);
   l.spawn = o; o += mgx_align16(A * 2);
@@ -143,10 +145,13 @@ __host__ __device__ inline MgxObsLds mgx_obs_lds_layout(int HW, int NOFF, int S,
   l.rows = o;
   {
     const int rows_bytes = MGX_OBS_WAVES * 4 * l.row_pitch * 4;  // one staging row per DPP row of every wavefront
-    const int early_bytes = mgx_align16(HW * 2) + mgx_align16(NOFF * 2);
     if (overlay) {
-      l.grid = o;
-      l.offs = o + mgx_align16(HW * 2);
+      int eo = o;
+      l.grid = eo; eo += mgx_align16(HW * 2);
+      l.offs = eo; eo += mgx_align16(NOFF * 2);
+      l.dyn = eo; eo += mgx_align16(S * 2);
+      if (blk_early) { l.blk = eo; eo += mgx_align16(blk_words * 4); }
+      const int early_bytes = eo - o;
       o += rows_bytes > early_bytes ? rows_bytes : early_bytes;
     } else {
       o += rows_bytes;
@@ -161,7 +166,7 @@ __host__ __device__ inline MgxObsLds mgx_obs_lds_layout(int HW, int NOFF, int S,
     l.obsval = o; o += mgx_align16((A * NOV + 1) * 4);
     l.tscore = o; o += 8 * MGX_OBS_THREADS * 8;
   }
-  l.blk = o; o += mgx_align16(blk_words * 4);
+  if (!(overlay && blk_early)) { l.blk = o; o += mgx_align16(blk_words * 4); }
   l.gtok = o; o += mgx_align16(A * GT * 4);
   l.total = o;
   return l;
@@ -190,7 +195,8 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
   const int wave = __builtin_amdgcn_readfirstlane(tid / MGX_WAVE);  // wave-uniform: per-agent values and branches go scalar
   const int HW = d.H * d.W, A = d.A, S = d.S, T = d.T, NOFF = d.NOFF;
   const int GT = mgx_obs_gt(d.n_obs_values, d.base);
-  const MgxObsLds L = mgx_obs_lds_layout(HW, NOFF, S, A, T, pool_tokens, X, d.n_obs_values, PL ? blk_words : 0, GT);
+  const MgxObsLds L = mgx_obs_lds_layout(HW, NOFF, S, A, T, pool_tokens, X, d.n_obs_values, PL ? blk_words : 0, GT,
+                                         rewards_early != 0);
   const int CP = L.cp;
   uint16_t* s_grid = (uint16_t*)(smem + L.grid);
   char2* s_offs = (char2*)(smem + L.offs);
