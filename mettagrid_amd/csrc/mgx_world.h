@@ -5,11 +5,13 @@
 // (noop / move with the handler-chain line scan / change_vibe), timestep events, per-agent on_tick handlers, fixed and
 // mobile AoE, territory effects, the game-level on_tick handler and coverage tracking.
 // The order of agents inside one env is a true sequential dependence (collisions, first-come resources), so an env
-// is executed serially by ONE lane; 64 envs advance in lock-step per wavefront and every lane runs the same
-// compiled program, which bounds divergence.  Observations, rewards and termination are mgx_obs.h.
+// is executed serially by ONE lane; 32 (lean) or 64 (extended) envs advance in lock-step per wavefront and every lane
+// runs the same compiled program, which bounds divergence.  Observations, rewards and termination are mgx_obs.h.
 //
-// Two instantiations exist: X = false (rungs 1-3: static tags, no queries/events/AoE/territory — the benchmarked
-// configuration) and X = true (everything).  The X-only code is compiled out of the fast variant.
+// Two instantiations exist: X = false ("lean", rungs 1-3: static tags, no queries/events/AoE/territory — the
+// benchmarked configuration; iterative handler VM run_handler, one flat kernel, built in mgx_world_fast.hip) and
+// X = true ("extended", everything; recursive handler templates, out-of-line functions, built in mgx_engine.hip).
+// The X-only code is compiled out of the lean variant.
 #ifndef MGX_WORLD_H_
 #define MGX_WORLD_H_
 
@@ -70,10 +72,10 @@ MGX_DBG_LINKAGE __device__ unsigned long long mgx_dbg_cycles[16];
 #define MGX_TICK0()
 #endif
 
-// MGX_BIG: inlining policy of the large interpreter functions.  The benchmarked (non-extended) world kernel is built
-// in its own translation unit with MGX_BIG=__forceinline__ so the whole handler VM collapses into the kernel: MgxDev
-// stays in SGPRs and every state access is a global_load off an SGPR base.  The extended variant keeps real calls
-// (full inlining of its four nesting levels does not finish compiling in reasonable time).
+// MGX_BIG: inlining policy of the large interpreter functions.  The lean world kernel is built in its own translation
+// unit with MGX_BIG=__forceinline__: its handler VM is iterative, so everything collapses into one flat kernel.  The
+// extended variant keeps real calls (its four template levels have three nested call sites each; fully inlined the
+// kernel is ~1 M instructions).
 #ifndef MGX_BIG
 #define MGX_BIG
 #endif

@@ -80,3 +80,45 @@ def test_batched_env_surface_and_auto_reset():
     with pytest.raises(ValueError, match="out of range"):
         env.step(np.full(E * A, 999, np.int64))
     env.close()
+
+
+def test_reset_with_denser_maps_grows_the_token_pool():
+    """mgx_reset_envs with maps that hold more non-static objects than any map at construction: the LDS token pool of
+    the observation kernel (sized from the class maps) has to grow, and the restarted envs must equal fresh ones."""
+    from mettagrid_amd import presets
+    from mettagrid_amd.mapgen import random_class_maps
+    spec = presets.rung3_spec()
+    prog = compile_spec(spec, 32, 32, max_objects=192)
+    E, A = 8, prog.num_agents
+    sparse = random_class_maps(prog, 32, 32, {"wall": 40, "extractor": 2, "chest": 1}, {"red": 8, "blue": 8}, range(E))
+    dense = random_class_maps(prog, 32, 32, {"wall": 5, "extractor": 25, "chest": 15}, {"red": 8, "blue": 8}, range(100, 100 + E))
+    seeds = np.arange(E, dtype=np.uint32) + 5
+    eng = BatchedMettaGrid(prog, sparse, seeds, buffers="device")
+    rng = np.random.default_rng(3)
+    n_act = len(prog.action_names)
+
+    def step(engine, a, v):
+        import torch
+        engine.actions.copy_(torch.from_numpy(a)); engine.vibe_actions.copy_(torch.from_numpy(v)); torch.cuda.synchronize()
+        engine.step()
+
+    for _ in range(3):
+        step(eng, rng.integers(0, n_act, E * A).astype(np.int32), rng.integers(0, n_act, E * A).astype(np.int32))
+    mask = np.zeros(E, np.uint8); mask[[1, 4, 7]] = 1
+    new_maps = sparse.copy(); new_maps[mask.astype(bool)] = dense[mask.astype(bool)]
+    new_seeds = seeds.copy(); new_seeds[mask.astype(bool)] += 100
+    eng.reset_envs(mask, new_maps, new_seeds)
+    fresh = BatchedMettaGrid(prog, new_maps[mask.astype(bool)], new_seeds[mask.astype(bool)], buffers="device")
+    snap, ref = eng.snapshot(), fresh.snapshot()
+    for k, i in enumerate(np.flatnonzero(mask)):
+        for key in ("obs", "rewards", "terminals", "truncations"):
+            assert np.array_equal(snap[key][i * A:(i + 1) * A], ref[key][k * A:(k + 1) * A]), (key, i)
+    for _ in range(4):  # and they keep evolving identically
+        a = rng.integers(0, n_act, E * A).astype(np.int32); v = rng.integers(0, n_act, E * A).astype(np.int32)
+        step(eng, a, v)
+        sel = np.concatenate([np.arange(i * A, (i + 1) * A) for i in np.flatnonzero(mask)])
+        step(fresh, a[sel], v[sel])
+        snap, ref = eng.snapshot(), fresh.snapshot()
+        for k, i in enumerate(np.flatnonzero(mask)):
+            assert np.array_equal(snap["obs"][i * A:(i + 1) * A], ref["obs"][k * A:(k + 1) * A]), i
+    assert eng.poll_errors()[0] == 0 and fresh.poll_errors()[0] == 0
