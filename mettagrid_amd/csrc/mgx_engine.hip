@@ -561,8 +561,10 @@ int mgx_step(mgx_engine* e) {
     HIP_TRY(hipMemcpyAsync(e->own_act, e->h_act, rows * 4, hipMemcpyHostToDevice, e->stream));
     HIP_TRY(hipMemcpyAsync(e->own_vact, e->h_vact, rows * 4, hipMemcpyHostToDevice, e->stream));
   }
-  HIP_TRY(hipMemsetAsync(d.executed, 0, rows * 4, e->stream));  // executed_actions / _action_success cleared (:944,962-964)
-  HIP_TRY(hipMemsetAsync(d.success, 0, rows, e->stream));
+  if (d.X) {  // executed_actions / _action_success cleared (:944,962-964); the lean world kernel clears its own rows
+    HIP_TRY(hipMemsetAsync(d.executed, 0, rows * 4, e->stream));
+    HIP_TRY(hipMemsetAsync(d.success, 0, rows, e->stream));
+  }
   if (e->profiling) HIP_TRY(hipEventRecord(e->ev[0], e->stream));
   {
     const int pw = (int)e->prog.size();

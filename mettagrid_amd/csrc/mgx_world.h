@@ -1705,6 +1705,17 @@ __device__ __forceinline__ void mgx_world_body(const MgxDev& d, PP P, uint8_t* o
   const int A = d.A;
   MGX_TICK0();
   e.step = ++d.step[env];
+  if constexpr (!X) {  // executed_actions / _action_success cleared (mettagrid_c.cpp:944,962-964): the lean variant does
+                       // it here (five 16-byte stores per env) instead of two memset launches per step
+    if ((A & 3) == 0) {
+      uint4* ex = (uint4*)(d.executed + e.ao(0));
+      for (int i = 0; i < A / 4; i++) ex[i] = make_uint4(0u, 0u, 0u, 0u);
+      uint32_t* su = (uint32_t*)(d.success + e.ao(0));
+      for (int i = 0; i < A / 4; i++) su[i] = 0u;
+    } else {
+      for (int i = 0; i < A; i++) { d.executed[e.ao(i)] = 0; d.success[e.ao(i)] = 0; }
+    }
+  }
 
   // ---- stage every agent's own state + both action streams in LDS.  The loads of one chunk are independent, so
   // they are all in flight together instead of one HBM round trip per agent inside the serial loop below. ----
