@@ -658,19 +658,35 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
   if (step > 0)
     for (int s = tid; s < S; s += MGX_OBS_THREADS)
       if (s_minobs[s] != 0xFFFFFFFFu && s_visited[s] < step) d.obj_visited[e.so(s)] = step;
-  if (tid == 0) {  // sequential f32 adds in agent order, as the reference does (:659-661, 821-823)
+  if (wave == 0) {  // tokens_written / tokens_free_space (:659-661, 821-823): the reference adds agent by agent in f32
     float* gs = d.game_stats + (size_t)env * d.NG;
-    float tw = gs[mgx_wk(d, MGX_S_GAME_TOKENS_WRITTEN)], tf = gs[mgx_wk(d, MGX_S_GAME_TOKENS_FREE)];
-    bool overflow = false;
-    for (int a = 0; a < A && !overflow; a++) {
-      int n = s_written[a];
-      if (n > T) { overflow = true; break; }  // reference: std::runtime_error (:813-819)
-      tw = __fadd_rn(tw, (float)n);
-      tf = __fadd_rn(tf, (float)(T - n));
+    float tw = 0.f, tf = 0.f;
+    if (lane == 0) { tw = gs[mgx_wk(d, MGX_S_GAME_TOKENS_WRITTEN)]; tf = gs[mgx_wk(d, MGX_S_GAME_TOKENS_FREE)]; }
+    // All addends are integers: while both running sums stay integers below 2^24 every partial sum is exact and the
+    // order does not matter -> one wavefront sum.  Otherwise (or on a token overflow) replay the serial order.
+    const int nw = lane < A ? s_written[lane] : 0;
+    const bool over = __ballot(lane < A && nw > T) != 0;
+    const uint32_t sum_w = mgx_wave_sum((uint32_t)nw);
+    if (lane == 0) {
+      const uint32_t sum_f = (uint32_t)A * (uint32_t)T - sum_w;
+      const bool exact = A <= MGX_WAVE && !over && tw == truncf(tw) && tf == truncf(tf) && tw >= 0.f && tf >= 0.f &&
+                         tw + (float)sum_w <= 16777216.f && tf + (float)sum_f <= 16777216.f;
+      bool overflow = false;
+      if (exact) {
+        tw += (float)sum_w;
+        tf += (float)sum_f;
+      } else {
+        for (int a = 0; a < A && !overflow; a++) {
+          int n = s_written[a];
+          if (n > T) { overflow = true; break; }  // reference: std::runtime_error (:813-819)
+          tw = __fadd_rn(tw, (float)n);
+          tf = __fadd_rn(tf, (float)(T - n));
+        }
+      }
+      gs[mgx_wk(d, MGX_S_GAME_TOKENS_WRITTEN)] = tw;
+      gs[mgx_wk(d, MGX_S_GAME_TOKENS_FREE)] = tf;
+      if (overflow) d.err[env] |= 1u;
     }
-    gs[mgx_wk(d, MGX_S_GAME_TOKENS_WRITTEN)] = tw;
-    gs[mgx_wk(d, MGX_S_GAME_TOKENS_FREE)] = tf;
-    if (overflow) d.err[env] |= 1u;
   }
   MGX_TICK(13);
   if (WITH_REWARDS && !rewards_early) {
