@@ -1400,10 +1400,7 @@ struct MgxEnvT {  // per-lane view of one env
   }
 
   // ---- actions ----
-  __device__ MGX_BIG bool do_move(int slot, int orient) const {
-#ifdef MGX_EXP_NOMOVE
-    return false;
-#endif  // actions/move.hpp:81-115, orientation.hpp:28-48
+  __device__ MGX_BIG bool do_move(int slot, int orient) const {  // actions/move.hpp:81-115, orientation.hpp:28-48
     const int dx = (orient == 2 || orient == 4 || orient == 6) ? -1 : (orient == 3 || orient == 5 || orient == 7) ? 1 : 0;
     const int dy = (orient == 0 || orient == 4 || orient == 5) ? -1 : (orient == 1 || orient == 6 || orient == 7) ? 1 : 0;
     PP mh = prog() + d.sec[MGX_SEC_MOVE_HANDLERS];
@@ -1818,7 +1815,6 @@ __device__ __forceinline__ void mgx_world_body(const MgxDev& d, PP P, uint8_t* o
   if constexpr (X) {
     if (d.n_schedule > 0) e.process_events();  // mettagrid_c.cpp:1009-1011
   }
-#ifndef MGX_EXP_NOTICK
   if (d.any_on_tick) {
     for (int i = 0; i < A; i++) {  // per-agent on_tick (mettagrid_c.cpp:1019-1024); slot and class come from LDS
       const int li = i * MGX_WAVE + lane;
@@ -1830,7 +1826,6 @@ __device__ __forceinline__ void mgx_world_body(const MgxDev& d, PP P, uint8_t* o
       }
     }
   }
-#endif
   if constexpr (X) {
     if (d.NF > 0 || d.NT > 0)
       for (int i = 0; i < A; i++) {  // mettagrid_c.cpp:1032-1035
@@ -1849,12 +1844,8 @@ __device__ __forceinline__ void mgx_world_body(const MgxDev& d, PP P, uint8_t* o
     }
   }
   MGX_TICK(4);
-#ifndef MGX_EXP_NOFLUSH
   if (d.defer_book) e.bookkeeping_flush();
-#endif
-#ifndef MGX_EXP_NOCOV
   e.track_coverage_all();
-#endif
   MGX_TICK(5);
 }
 
