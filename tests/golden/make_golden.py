@@ -24,12 +24,15 @@ from mettagrid_amd import signature as sg  # noqa: E402
 from mettagrid_amd.compiler import compile_spec  # noqa: E402
 
 SEEDS = {"rung1": [42], "rung1_invalid": [43], "rung2": [0, 1], "rung3": [0, 1], "rung3_flat_damage": [10],
-         "torture": [0, 1], "torture_terminal": [2], "rung4": [0, 1], "rung4_truncating": [2], "dynamic": [0, 1]}
+         "torture": [0, 1], "torture_terminal": [2], "rung4": [0, 1], "rung4_truncating": [2], "dynamic": [0, 1], "wide": [0]}
 
 
 def main() -> None:
     gxx = subprocess.run(["g++", "--version"], capture_output=True, text=True).stdout.splitlines()[0]
+    only = set(sys.argv[1:])  # optional: regenerate just these scenarios
     for name, seeds in SEEDS.items():
+        if only and name not in only:
+            continue
         spec_f, map_f, steps, invalid = hp.SCENARIOS[name]
         for seed in seeds:
             spec = spec_f()

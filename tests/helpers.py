@@ -272,3 +272,23 @@ def dynamic_map(seed: int) -> np.ndarray:
 
 
 SCENARIOS["dynamic"] = (dynamic_spec, dynamic_map, 60, False)
+
+
+def wide_spec() -> S.GameSpec:
+    """Rung-3 rules with shapes the other scenarios do not reach: 24 agents (two encode passes of 16, the second one
+    half empty), a 13x13 window, and a token budget that is not a multiple of four (ragged row tail, unaligned row
+    pitch in the observation buffer)."""
+    import copy
+    from mettagrid_amd import presets
+    sp = presets.rung3_spec()
+    red, blue = sp.agents[0], sp.agents[-1]
+    sp.agents = [copy.deepcopy(red) for _ in range(12)] + [copy.deepcopy(blue) for _ in range(12)]
+    sp.obs = S.ObsSpec(width=13, height=13, num_tokens=243)
+    return sp
+
+
+def wide_map(seed: int) -> np.ndarray:
+    return random_map(20, 20, {"wall": 20, "extractor": 10, "chest": 6}, {"red": 12, "blue": 12}, seed)
+
+
+SCENARIOS["wide"] = (wide_spec, wide_map, 25, True)
