@@ -417,7 +417,18 @@ int mgx_create(const int32_t* program, size_t program_words, const uint16_t* cla
     }
     e->rewards_early = pure;
   }
-  if (e->lds_world > 64 * 1024) { mgx_destroy(e); return fail(MGX_ERR_PROGRAM, "mgx_create: world kernel LDS staging too large"); }
+  // The world kernel stages 17 (+ extended: 176) bytes per agent and env in LDS, 64 envs per workgroup: up to 160 KB,
+  // i.e. about 147 agents per env in the lean variant.  Past 64 KB the kernels need the opt-in attribute.
+  if (e->lds_world > 160 * 1024) {
+    mgx_destroy(e);
+    return fail(MGX_ERR_PROGRAM, "mgx_create: too many agents per env for the world kernel's LDS staging (160 KB per 64 envs)");
+  }
+  {
+    hipError_t la = hipFuncSetAttribute((const void*)mgx_world_kernel_ext<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_world);
+    if (la == hipSuccess) la = hipFuncSetAttribute((const void*)mgx_world_kernel_ext<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_world);
+    if (la == hipSuccess) la = mgx_world_fast_set_lds(e->lds_world) ? hipSuccess : hipErrorInvalidValue;
+    if (la != hipSuccess) { mgx_destroy(e); return fail(MGX_ERR_HIP, "mgx_create: cannot raise the world kernel's dynamic LDS limit"); }
+  }
   {  // Build sanity: with a private segment (stack frames of the out-of-line handler functions + spills) of 9 200 bytes
      // per lane the extended world kernel produced wrong results on gfx950 / ROCm 7.2 without any error; at 6 736 it is
      // correct.  Refuse to run a build that is past 8 KiB instead of stepping envs wrongly.

@@ -1888,6 +1888,7 @@ __device__ __forceinline__ void mgx_world_entry(const MgxDev& d, int prog_words)
 
 // Host launcher of the non-extended world kernels (defined in mgx_world_fast.hip).
 void mgx_launch_world_fast(bool prog_lds, size_t lds, hipStream_t stream, const MgxDev& d, int prog_words);
+bool mgx_world_fast_set_lds(size_t lds);  // raises the kernels' dynamic LDS limit (needed past 64 KB)
 
 #ifndef MGX_WORLD_FAST_TU
 // Construction: MettaGrid ctor + _init_grid (mettagrid_c.cpp:42-191, 200-269).  One lane per env scans the class

@@ -37,6 +37,11 @@ static std::mutex g_dev_mutex;
 static MgxDev g_dev_host;
 static bool g_dev_valid = false;
 
+bool mgx_world_fast_set_lds(size_t lds) {
+  return hipFuncSetAttribute((const void*)mgx_world_kernel_fast<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
+         hipFuncSetAttribute((const void*)mgx_world_kernel_fast<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
+}
+
 void mgx_launch_world_fast(bool prog_lds, size_t lds, hipStream_t stream, const MgxDev& d, int prog_words) {
   std::lock_guard<std::mutex> lock(g_dev_mutex);
   if (!g_dev_valid || memcmp(&g_dev_host, &d, sizeof(MgxDev)) != 0) {

@@ -292,3 +292,22 @@ def wide_map(seed: int) -> np.ndarray:
 
 
 SCENARIOS["wide"] = (wide_spec, wide_map, 25, True)
+
+
+def crowd_spec() -> S.GameSpec:
+    """Rung-3 rules with more agents than a wavefront has lanes (70): agent loops that stride by 64, five encode
+    passes, the serial fallback of the token statistics."""
+    import copy
+    from mettagrid_amd import presets
+    sp = presets.rung3_spec()
+    red, blue = sp.agents[0], sp.agents[-1]
+    sp.agents = [copy.deepcopy(red) for _ in range(35)] + [copy.deepcopy(blue) for _ in range(35)]
+    sp.obs = S.ObsSpec(width=9, height=9, num_tokens=200)
+    return sp
+
+
+def crowd_map(seed: int) -> np.ndarray:
+    return random_map(30, 30, {"wall": 30, "extractor": 12, "chest": 6}, {"red": 35, "blue": 35}, seed)
+
+
+SCENARIOS["crowd"] = (crowd_spec, crowd_map, 12, False)
