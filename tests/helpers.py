@@ -311,3 +311,14 @@ def crowd_map(seed: int) -> np.ndarray:
 
 
 SCENARIOS["crowd"] = (crowd_spec, crowd_map, 12, False)
+
+
+def torture_base10_spec() -> S.GameSpec:
+    """The torture rules with a token value base that is not a power of two (division path of the digit encoder)."""
+    sp = torture_spec()
+    sp.obs.token_value_base = 10
+    sp.obs.num_tokens = 200
+    return sp
+
+
+SCENARIOS["torture_base10"] = (torture_base10_spec, torture_map, 30, False)
