@@ -80,3 +80,32 @@ def test_full_size_sampled_parity_and_row_wellformedness():
     # every agent sees at least its global tokens and itself
     assert (~empty[:, 0]).all().item()
     assert torch.isfinite(eng.rewards).all().item()
+
+
+def test_large_rectangular_map():
+    """80 x 96 map (grid larger than one staging pass of the observation kernel, H != W), 600 object slots."""
+    import torch
+    spec = presets.rung3_spec()
+    H, W = 80, 96
+    prog = compile_spec(spec, H, W, max_objects=600)
+    A = prog.num_agents
+    E = 3
+    cms = random_class_maps(prog, H, W, {"wall": 150, "extractor": 30, "chest": 10}, {"red": 8, "blue": 8}, range(E))
+    seeds = np.arange(E, dtype=np.uint32) + 11
+    eng = BatchedMettaGrid(prog, cms, seeds, buffers="device")
+    oracles = [op.OracleSim(prog, cms[i], int(seeds[i])) for i in range(E)]
+    for o in oracles:
+        o.reinit_buffers()
+    rng = np.random.default_rng(5)
+    n_act = len(prog.action_names)
+    for t in range(8):
+        snap = eng.snapshot()
+        for i, o in enumerate(oracles):
+            hp.compare_snapshots(o.snapshot(), {k: v[i * A:(i + 1) * A] for k, v in snap.items()}, f"large map env {i} step {t}")
+        a = rng.integers(0, n_act, E * A).astype(np.int32)
+        v = rng.integers(0, n_act, E * A).astype(np.int32)
+        eng.actions.copy_(torch.from_numpy(a)); eng.vibe_actions.copy_(torch.from_numpy(v)); torch.cuda.synchronize()
+        eng.step()
+        for i, o in enumerate(oracles):
+            o.step(a[i * A:(i + 1) * A], v[i * A:(i + 1) * A])
+    assert eng.poll_errors()[0] == 0
