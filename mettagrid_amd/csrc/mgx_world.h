@@ -1109,7 +1109,18 @@ struct MgxEnvT {  // per-lane view of one env
       PP hd = handlers + h * MGX_HD_WORDS;
       int push_h = -1, push_cs = 0;  // handler to apply next (new frame), if any
       bool pop = false;
-      if (stage == ST_ENTER) {
+      // stages in sequence (not else-if): a lane chains return -> enter -> kids / mutation within one trip
+      if (stage == ST_USE_RET) {
+        stage = ST_MUTS;
+        if (!rv) failed |= 1u << cs;
+        else {
+          const int after = cls_of(c.actor)[MGX_C_ON_AFTER_USE];
+          if (after >= 0) { stage = ST_AFTER_RET; push_h = after; push_cs = cs; }
+        }
+      } else if (stage == ST_AFTER_RET) {  // the result of on_after_use is ignored
+        stage = ST_MUTS;
+      }
+      if (stage == ST_ENTER && push_h < 0) {
         if (hd[MGX_HD_KIND] == MGX_HK_LEAF) {
           if (!check_filters<0>(hd[MGX_HD_FILTER_PC], c, 0)) { rv = false; pop = true; }
           else { failed &= ~(1u << cs); stage = ST_MUTS; i = 0; }
@@ -1120,7 +1131,8 @@ struct MgxEnvT {  // per-lane view of one env
         } else {
           stage = ST_KIDS; i = 0; any = 0;
         }
-      } else if (stage == ST_KIDS) {
+      }
+      if (stage == ST_KIDS && !pop && push_h < 0) {
         bool done = false;
         if (i > 0 && rv) {
           any = 1;
@@ -1136,7 +1148,8 @@ struct MgxEnvT {  // per-lane view of one env
             pop = true;
           }
         }
-      } else if (stage == ST_MUTS) {
+      }
+      if (stage == ST_MUTS && !pop && push_h < 0) {
         if (i > 0 && ((failed >> cs) & 1u)) { rv = false; pop = true; }
         else if (i >= hd[MGX_HD_MUT_COUNT]) { rv = true; pop = true; }
         else {
@@ -1157,15 +1170,6 @@ struct MgxEnvT {  // per-lane view of one env
             if (c.mutation_failed) failed |= 1u << cs;
           }
         }
-      } else if (stage == ST_USE_RET) {
-        stage = ST_MUTS;
-        if (!rv) failed |= 1u << cs;
-        else {
-          const int after = cls_of(c.actor)[MGX_C_ON_AFTER_USE];
-          if (after >= 0) { stage = ST_AFTER_RET; push_h = after; push_cs = cs; }
-        }
-      } else {  // ST_AFTER_RET: the result of on_after_use is ignored
-        stage = ST_MUTS;
       }
       if (pop) { sp--; continue; }
       const int nfs = i | (stage << 16) | (any << 20) | (cs << 24);
