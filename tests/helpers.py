@@ -322,3 +322,40 @@ def torture_base10_spec() -> S.GameSpec:
 
 
 SCENARIOS["torture_base10"] = (torture_base10_spec, torture_map, 30, False)
+
+
+def keyhole_spec() -> S.GameSpec:
+    """Rung-3 rules seen through the smallest window (3x3: five in-mask cells) with an odd agent count."""
+    import copy
+    from mettagrid_amd import presets
+    sp = presets.rung3_spec()
+    red, blue = sp.agents[0], sp.agents[-1]
+    sp.agents = [copy.deepcopy(red) for _ in range(3)] + [copy.deepcopy(blue) for _ in range(2)]
+    sp.obs = S.ObsSpec(width=3, height=3, num_tokens=60)
+    return sp
+
+
+def keyhole_map(seed: int) -> np.ndarray:
+    return random_map(7, 10, {"wall": 6, "extractor": 4, "chest": 3}, {"red": 3, "blue": 2}, seed)
+
+
+SCENARIOS["keyhole"] = (keyhole_spec, keyhole_map, 40, True)
+
+
+def letterbox_spec() -> S.GameSpec:
+    """Rung-3 rules with the widest window the reference allows in one direction and a narrow one in the other
+    (15x7), on a map smaller than the window: most window cells are out of bounds for every agent."""
+    import copy
+    from mettagrid_amd import presets
+    sp = presets.rung3_spec()
+    red, blue = sp.agents[0], sp.agents[-1]
+    sp.agents = [copy.deepcopy(red) for _ in range(3)] + [copy.deepcopy(blue) for _ in range(3)]
+    sp.obs = S.ObsSpec(width=15, height=7, num_tokens=250)
+    return sp
+
+
+def letterbox_map(seed: int) -> np.ndarray:
+    return random_map(9, 12, {"wall": 10, "extractor": 5, "chest": 3}, {"red": 3, "blue": 3}, seed)
+
+
+SCENARIOS["letterbox"] = (letterbox_spec, letterbox_map, 40, False)
