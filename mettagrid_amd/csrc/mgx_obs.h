@@ -432,8 +432,52 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
   }
   // Rewards that read nothing this kernel writes (no stat operands; host flag) are evaluated here by the last
   // wavefront, which has little or no list-building work, instead of serially at the end of the workgroup.
-  if (WITH_REWARDS && rewards_early && wave == MGX_OBS_WAVES - 1)
-    for (int a = lane; a < A; a += MGX_WAVE) agent_rewards(a);
+  if (WITH_REWARDS && rewards_early && wave == MGX_OBS_WAVES - 1) {
+    // One lane per (agent, reward entry): the entries of an agent are evaluated side by side (their loads in flight
+    // together) and then summed in entry order by the agent's first lane, exactly like the serial loop of
+    // agent_rewards (reward.hpp:56-77: total += val or val - prev, entry by entry).
+    const int NRW = d.NRW;
+    if (NRW <= MGX_WAVE) {
+      const int per = MGX_WAVE / NRW;  // agents per pass
+      for (int a0 = 0; a0 < A; a0 += per) {
+        const int a = a0 + lane / NRW, k = lane % NRW;
+        const bool have = lane < per * NRW && a < A;
+        float contrib = 0.f, ep = 0.f;
+        int nrw = 0;
+        if (have) {
+          if (k == 0) ep = d.episode_rewards[e.ao(a)];
+          const uint32_t rwi = s_rwinfo[a];
+          nrw = (int)(rwi >> 16);
+          if (k < nrw) {
+            const int slot = s_agents[a] & 0xFFFF;
+            VP rw = vp + d.sec[MGX_SEC_REWARDS] + ((int)(rwi & 0xFFFF) + k) * MGX_RW_WORDS;
+            float* prev = &d.ag_rprev[e.ao(a) * NRW + k];
+            const float pv = *prev;
+            MgxCtx vc = mgx_ctx(slot, slot);
+            const float val = ev.template eval_code<Env::TOPQ>(rw[MGX_RW_GV_START], rw[MGX_RW_GV_COUNT], slot, vc, 0);
+            contrib = rw[MGX_RW_ACCUMULATE] ? val : __fsub_rn(val, pv);
+            *prev = val;
+          }
+        }
+        float total = 0.f;
+        for (int j = 0; j < NRW; j++) {  // uniform trip count; lanes past their agent's entry count add nothing
+          const float cj = __shfl(contrib, lane + j);
+          if (j < nrw) total = __fadd_rn(total, cj);
+        }
+        if (have && k == 0) {
+          const float reward = total != 0.f ? total : 0.f;  // rewards were zeroed at the top of the step; += total
+          d.rewards[e.ao(a)] = reward;
+          d.episode_rewards[e.ao(a)] = __fadd_rn(ep, reward);
+          if (d.max_steps > 0 && step >= (uint32_t)d.max_steps) {
+            if (d.truncates) d.truncations[e.ao(a)] = 1;
+            else d.terminals[e.ao(a)] = 1;
+          }
+        }
+      }
+    } else {
+      for (int a = lane; a < A; a += MGX_WAVE) agent_rewards(a);
+    }
+  }
   if constexpr (X) {
     if (want_mask) {  // TerritoryTracker::compute_observability_at (:254-273): first territory with an owner decides
       for (int cellidx = tid; cellidx < HW; cellidx += MGX_OBS_THREADS) {
@@ -457,7 +501,10 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
 
   // ---- phase 1: per agent the list of window cells that will emit tokens, in window order (ballot compaction), and
   // the first observer (lowest agent index) of every object.  The encode loop then only walks real entries. ----
-  for (int a = nfree > 0 ? (wave >= nbw ? wave - nbw : A) : wave; a < A; a += nfree > 0 ? nfree : MGX_OBS_WAVES) {
+  // (the wavefront that evaluates the early rewards is left out when another free one exists: its job is as long as
+  // half of this phase)
+  const int np1 = nfree - ((WITH_REWARDS && rewards_early && nfree >= 2) ? 1 : 0);  // free wavefronts taking agents
+  for (int a = nfree > 0 ? (wave >= nbw && wave < nbw + np1 ? wave - nbw : A) : wave; a < A; a += nfree > 0 ? np1 : MGX_OBS_WAVES) {
     const uint32_t ag = s_agents[a];
     const int r0 = (ag >> 24) & 0xFF, c0 = (ag >> 16) & 0xFF;
     int count = 0;
