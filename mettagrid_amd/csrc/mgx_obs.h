@@ -529,7 +529,8 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
     if (lane == 0) s_vcount[a] = (uint32_t)count;
   }
   // global tokens (location 0xFE), mettagrid_c.cpp:700-753: one thread per agent, all agents at once
-  for (int a = (wave == (nfree > 0 ? nbw : 0)) ? lane : A; a < A; a += MGX_WAVE) {
+  const int gwave = np1 < nfree ? MGX_OBS_WAVES - 1 : (nfree > 0 ? nbw : 0);  // after the early rewards when that wavefront skipped the lists
+  for (int a = (wave == gwave) ? lane : A; a < A; a += MGX_WAVE) {
     const uint32_t ag = s_agents[a];
     const int my_slot = ag & 0xFFFF;
     const int r0 = (ag >> 24) & 0xFF, c0 = (ag >> 16) & 0xFF;
