@@ -504,12 +504,14 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
   // (the wavefront that evaluates the early rewards is left out when another free one exists: its job is as long as
   // half of this phase)
   const int np1 = nfree - ((WITH_REWARDS && rewards_early && nfree >= 2) ? 1 : 0);  // free wavefronts taking agents
+  // a lane's window offsets of the first two passes are the same for every agent: read once, not once per agent
+  const char2 offs_p0 = s_offs[min(lane, NOFF - 1)], offs_p1 = s_offs[min(lane + MGX_WAVE, NOFF - 1)];
   for (int a = nfree > 0 ? (wave >= nbw && wave < nbw + np1 ? wave - nbw : A) : wave; a < A; a += nfree > 0 ? np1 : MGX_OBS_WAVES) {
     const uint32_t ag = s_agents[a];
     const int r0 = (ag >> 24) & 0xFF, c0 = (ag >> 16) & 0xFF;
     int count = 0;
     for (int j = lane; j < ((NOFF + MGX_WAVE - 1) & ~(MGX_WAVE - 1)); j += MGX_WAVE) {  // whole wavefront in every pass (ballots)
-      const char2 o = s_offs[min(j, NOFF - 1)];
+      const char2 o = j == lane ? offs_p0 : j == lane + MGX_WAVE ? offs_p1 : s_offs[min(j, NOFF - 1)];
       const int r = r0 + o.x, c = c0 + o.y;
       const bool inb = j < NOFF && (unsigned)r < (unsigned)d.H && (unsigned)c < (unsigned)d.W;
       const uint32_t cs = inb ? (uint32_t)s_grid[inb ? r * d.W + c : 0] : 0u;
