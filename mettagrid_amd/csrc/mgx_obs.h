@@ -514,7 +514,7 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
       const char2 o = j == lane ? offs_p0 : j == lane + MGX_WAVE ? offs_p1 : s_offs[min(j, NOFF - 1)];
       const int r = r0 + o.x, c = c0 + o.y;
       const bool inb = j < NOFF && (unsigned)r < (unsigned)d.H && (unsigned)c < (unsigned)d.W;
-      const uint32_t cs = inb ? (uint32_t)s_grid[inb ? r * d.W + c : 0] : 0u;
+      const uint32_t cs = inb ? (uint32_t)s_grid[inb ? __mul24(r, d.W) + c : 0] : 0u;  // map <= 255 x 255
       bool keep = cs != 0;
       if constexpr (X) {
         if (want_mask && inb) keep = keep || s_owner[r * d.W + c] != 0xFFFF;  // mask-only cells still emit one token
