@@ -276,6 +276,14 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
   // are in flight together with the staging loads below instead of one barrier later.
   uint16_t pre_cls = MGX_DEAD_CLASS;
   uint32_t pre_vis = 0, pre_cinfo = 0;
+  // the two game stats the tail adds to (nothing else in this kernel writes them): loaded now, so the last thing a
+  // workgroup does is not an HBM round trip that keeps its LDS occupied
+  float pre_tw = 0.f, pre_tf = 0.f;
+  if (tid == 0) {
+    const float* gs0 = d.game_stats + (size_t)env * d.NG;
+    pre_tw = gs0[mgx_wk(d, MGX_S_GAME_TOKENS_WRITTEN)];
+    pre_tf = gs0[mgx_wk(d, MGX_S_GAME_TOKENS_FREE)];
+  }
   if (tid < S) {
     pre_cls = d.obj_cls[e.so(tid)];
     pre_vis = d.obj_visited[e.so(tid)];
@@ -710,8 +718,7 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
       if (s_minobs[s] != 0xFFFFFFFFu && s_visited[s] < step) d.obj_visited[e.so(s)] = step;
   if (wave == 0) {  // tokens_written / tokens_free_space (:659-661, 821-823): the reference adds agent by agent in f32
     float* gs = d.game_stats + (size_t)env * d.NG;
-    float tw = 0.f, tf = 0.f;
-    if (lane == 0) { tw = gs[mgx_wk(d, MGX_S_GAME_TOKENS_WRITTEN)]; tf = gs[mgx_wk(d, MGX_S_GAME_TOKENS_FREE)]; }
+    float tw = pre_tw, tf = pre_tf;  // lane 0 (= thread 0) holds the values
     // All addends are integers: while both running sums stay integers below 2^24 every partial sum is exact and the
     // order does not matter -> one wavefront sum.  Otherwise (or on a token overflow) replay the serial order.
     const int nw = lane < A ? s_written[lane] : 0;
