@@ -686,7 +686,9 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
       }
     }
     if (rl == 0 && av) {
-      if (visited_any) e.astat_set(a, sid_visited, visited_acc);
+      // every addend is >= 1, so the value is non-zero and "key exists" follows from it (see astat_add): a plain
+      // store, not a store plus a read-modify-write of the touched word that stalls the row for a round trip
+      if (visited_any && sid_visited >= 0) d.ag_stats[e.ao(a) * d.NSP + sid_visited] = visited_acc;
       s_written[a] = base_pos;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // LDS row complete before it is read back
