@@ -514,29 +514,83 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
   const int np1 = nfree - ((WITH_REWARDS && rewards_early && nfree >= 2) ? 1 : 0);  // free wavefronts taking agents
   // a lane's window offsets of the first two passes are the same for every agent: read once, not once per agent
   const char2 offs_p0 = s_offs[min(lane, NOFF - 1)], offs_p1 = s_offs[min(lane + MGX_WAVE, NOFF - 1)];
-  for (int a = nfree > 0 ? (wave >= nbw && wave < nbw + np1 ? wave - nbw : A) : wave; a < A; a += nfree > 0 ? np1 : MGX_OBS_WAVES) {
-    const uint32_t ag = s_agents[a];
-    const int r0 = (ag >> 24) & 0xFF, c0 = (ag >> 16) & 0xFF;
-    int count = 0;
-    for (int j = lane; j < ((NOFF + MGX_WAVE - 1) & ~(MGX_WAVE - 1)); j += MGX_WAVE) {  // whole wavefront in every pass (ballots)
-      const char2 o = j == lane ? offs_p0 : j == lane + MGX_WAVE ? offs_p1 : s_offs[min(j, NOFF - 1)];
-      const int r = r0 + o.x, c = c0 + o.y;
-      const bool inb = j < NOFF && (unsigned)r < (unsigned)d.H && (unsigned)c < (unsigned)d.W;
-      const uint32_t cs = inb ? (uint32_t)s_grid[inb ? __mul24(r, d.W) + c : 0] : 0u;  // map <= 255 x 255
-      bool keep = cs != 0;
-      if constexpr (X) {
-        if (want_mask && inb) keep = keep || s_owner[r * d.W + c] != 0xFFFF;  // mask-only cells still emit one token
+  const int a_first = nfree > 0 ? (wave >= nbw && wave < nbw + np1 ? wave - nbw : A) : wave;
+  const int a_step = nfree > 0 ? np1 : MGX_OBS_WAVES;
+  // A window of 65..96 cells (11x11: 89) leaves the second pass of an agent at most half full: two agents share it,
+  // one per 32-lane half, so a pair costs three passes instead of four.
+  bool pair_tail = false;
+  if constexpr (!X) pair_tail = NOFF > MGX_WAVE && NOFF <= MGX_WAVE + 32;
+  if (pair_tail) {
+    if constexpr (!X) {
+      const int hl = lane & 31, half = lane >> 5;
+      const int jt = MGX_WAVE + hl;
+      const char2 offs_t = s_offs[min(jt, NOFF - 1)];
+      // one window cell of agent x: its grid entry (0 = nothing to emit) + first-observer bookkeeping
+      auto probe = [&](int x, char2 o, bool ok) -> uint32_t {
+        const uint32_t ag = s_agents[x];
+        const int r = (int)((ag >> 24) & 0xFF) + o.x, c = (int)((ag >> 16) & 0xFF) + o.y;
+        const bool inb = ok && (unsigned)r < (unsigned)d.H && (unsigned)c < (unsigned)d.W;
+        const uint32_t cs = inb ? (uint32_t)s_grid[inb ? __mul24(r, d.W) + c : 0] : 0u;
+        if (step > 0 && cs) atomicMin(&s_minobs[cs - 1], (uint32_t)x);
+        return cs;
+      };
+      auto full_pass = [&](int x) -> int {  // cells 0..63 of agent x
+        const uint32_t cs = probe(x, offs_p0, true);
+        const unsigned long long m = __ballot(cs != 0);
+        if (cs) {
+          const int k = __popcll(m & ((1ull << lane) - 1ull));
+          s_cell[x * CP + k] = (uint16_t)cs;
+          s_vj[x * CP + k] = (uint8_t)lane;
+        }
+        return __popcll(m);
+      };
+      for (int a = a_first; a < A; a += 2 * a_step) {
+        const int b = a + a_step;
+        const bool hb = b < A;
+        int ca = full_pass(a);
+        int cb = hb ? full_pass(b) : 0;
+        const int x = (half && hb) ? b : a;
+        const uint32_t cs = probe(x, offs_t, (half == 0 || hb) && jt < NOFF);
+        const unsigned long long m = __ballot(cs != 0);
+        const uint32_t mh = half ? (uint32_t)(m >> 32) : (uint32_t)m;
+        if (cs) {
+          const int k = (half ? cb : ca) + __popc(mh & ((1u << hl) - 1u));
+          s_cell[x * CP + k] = (uint16_t)cs;
+          s_vj[x * CP + k] = (uint8_t)jt;
+        }
+        ca += __popc((uint32_t)m);
+        cb += __popc((uint32_t)(m >> 32));
+        if (lane == 0) {
+          s_vcount[a] = (uint32_t)ca;
+          if (hb) s_vcount[b] = (uint32_t)cb;
+        }
       }
-      if (step > 0 && cs) atomicMin(&s_minobs[cs - 1], (uint32_t)a);
-      const unsigned long long m = __ballot(keep);
-      if (keep) {
-        const int k = count + __popcll(m & ((1ull << lane) - 1ull));
-        s_cell[a * CP + k] = (uint16_t)cs;
-        s_vj[a * CP + k] = (uint8_t)j;
-      }
-      count += __popcll(m);
     }
-    if (lane == 0) s_vcount[a] = (uint32_t)count;
+  } else {
+    for (int a = a_first; a < A; a += a_step) {
+      const uint32_t ag = s_agents[a];
+      const int r0 = (ag >> 24) & 0xFF, c0 = (ag >> 16) & 0xFF;
+      int count = 0;
+      for (int j = lane; j < ((NOFF + MGX_WAVE - 1) & ~(MGX_WAVE - 1)); j += MGX_WAVE) {  // whole wavefront in every pass (ballots)
+        const char2 o = j == lane ? offs_p0 : j == lane + MGX_WAVE ? offs_p1 : s_offs[min(j, NOFF - 1)];
+        const int r = r0 + o.x, c = c0 + o.y;
+        const bool inb = j < NOFF && (unsigned)r < (unsigned)d.H && (unsigned)c < (unsigned)d.W;
+        const uint32_t cs = inb ? (uint32_t)s_grid[inb ? __mul24(r, d.W) + c : 0] : 0u;  // map <= 255 x 255
+        bool keep = cs != 0;
+        if constexpr (X) {
+          if (want_mask && inb) keep = keep || s_owner[r * d.W + c] != 0xFFFF;  // mask-only cells still emit one token
+        }
+        if (step > 0 && cs) atomicMin(&s_minobs[cs - 1], (uint32_t)a);
+        const unsigned long long m = __ballot(keep);
+        if (keep) {
+          const int k = count + __popcll(m & ((1ull << lane) - 1ull));
+          s_cell[a * CP + k] = (uint16_t)cs;
+          s_vj[a * CP + k] = (uint8_t)j;
+        }
+        count += __popcll(m);
+      }
+      if (lane == 0) s_vcount[a] = (uint32_t)count;
+    }
   }
   // global tokens (location 0xFE), mettagrid_c.cpp:700-753: one thread per agent, all agents at once
   const int gwave = np1 < nfree ? MGX_OBS_WAVES - 1 : (nfree > 0 ? nbw : 0);  // after the early rewards when that wavefront skipped the lists
