@@ -69,7 +69,7 @@ def main() -> None:
     ap.add_argument("--envs", type=int, default=65536, help="envs per GPU")
     ap.add_argument("--gather", choices=["none", "scalars", "obs"], default="none",
                     help="optional per-step RCCL all_gather of rewards/terminals/truncations (+obs)")
-    ap.add_argument("--cpu-steps", type=int, default=60000)
+    ap.add_argument("--cpu-steps", type=int, default=300000, help="CPU baseline sample: about 10 s of one host core")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 
