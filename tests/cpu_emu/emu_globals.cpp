@@ -1,0 +1,5 @@
+// TEST INFRASTRUCTURE ONLY — storage for the names the HIP runtime provides on a GPU (see hip/hip_runtime.h here).
+#include <hip/hip_runtime.h>
+thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
+alignas(16) uint8_t mgx_dyn_lds[160 * 1024];  // dynamic LDS of the world kernels
+alignas(16) uint8_t smem[160 * 1024];         // dynamic LDS of the (not emulated) observation kernel

@@ -89,6 +89,14 @@ SCENARIOS = {
 }
 
 
+# object slots per env where the default (H * W) is not what the preset ships with
+MAX_OBJECTS = {"rung4_full": presets.RUNG4_MAX_OBJECTS}
+
+
+def compile_scenario(name: str, spec, height: int, width: int):
+    return compile_spec(spec, height, width, max_objects=MAX_OBJECTS.get(name))
+
+
 def make_actions(prog, seed: int, steps: int, invalid: bool) -> tuple:
     rng = np.random.RandomState(1000 + seed)
     n = len(prog.action_names)
@@ -223,6 +231,8 @@ def rung4_map(seed: int) -> np.ndarray:
 
 
 SCENARIOS["rung4"] = (rung4_spec, rung4_map, 70, False)
+# BASELINE.json configs[3] at its own shape (64x64, 64 agents / 4 teams): events fire at 50, 75 and 100
+SCENARIOS["rung4_full"] = (presets.rung4_spec, presets.rung4_map, 104, False)
 SCENARIOS["rung4_truncating"] = (lambda: rung4_spec(33), rung4_map, 36, True)
 
 

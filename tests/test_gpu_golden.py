@@ -22,7 +22,7 @@ def test_hip_reproduces_reference_trace(path):
     payload = json.loads(bytes(z["payload"]).decode())
     spec = hp.SCENARIOS[meta["scenario"]][0]()
     cm = z["class_map"]
-    prog = compile_spec(spec, *cm.shape)
+    prog = hp.compile_scenario(meta["scenario"], spec, *cm.shape)
     # engine-internal buffers: exactly one initial-observation pass, like a bare reference MettaGrid(cfg, map, seed)
     eng = BatchedMettaGrid.__new__(BatchedMettaGrid)
     BatchedMettaGrid.__init__(eng, prog, cm[None], [meta["seed"]], buffers="host")

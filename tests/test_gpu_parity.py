@@ -23,7 +23,7 @@ def test_step_parity(name, buffers):
     spec = spec_f()
     E = 6
     maps = [map_f(s) for s in range(E)]
-    prog = compile_spec(spec, *maps[0].shape)
+    prog = hp.compile_scenario(name, spec, *maps[0].shape)
     cms = np.stack([prog.class_map(m) for m in maps])
     seeds = np.arange(E, dtype=np.uint32) * 7 + 3
     eng = BatchedMettaGrid(prog, cms, seeds, buffers=buffers)

@@ -17,7 +17,7 @@ pytestmark = pytest.mark.skipif(not rd.ref_available(), reason="oracle/_ref not 
 def test_oracle_equals_reference(name, seed):
     spec_f, map_f, steps, invalid = hp.SCENARIOS[name]
     spec, cells = spec_f(), map_f(seed)
-    prog = compile_spec(spec, *cells.shape)
+    prog = hp.compile_scenario(name, spec, *cells.shape)
     ref = rd.RefSim(spec, cells, seed, prog)
     ora = op.OracleSim(prog, prog.class_map(cells), seed)
     acts, vibes = hp.make_actions(prog, seed, steps, invalid)
