@@ -23,12 +23,36 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 
-def cpu_baseline(spec, prog, steps: int) -> dict:
+def workload(rung: int):
+    """(spec, H, W, max_objects, object counts, agent counts, map factory, description, algorithmic bytes per agent-step
+    of the whole tick / of the observation kernel / of the world update) for BASELINE.json configs[rung - 1]."""
+    from mettagrid_amd import presets
+    if rung == 3:
+        spec, H, W, S = presets.rung3_spec(), 32, 32, 192
+        objs, agents, mapf = {"wall": 40, "extractor": 8, "chest": 4}, {"red": 8, "blue": 8}, presets.rung3_map
+        desc = ("rung3: 65536 envs/GPU x 32x32 random map x 16 agents, 8-dir move + 4 vibes, attack/on-use handler "
+                "chains, 11x11 token obs T=200")
+        A, T = 16, spec.obs.num_tokens
+        s_env = 2 * H * W + A * 87 + 12 * 32 + 8                      # SURVEY.md §8d
+    elif rung == 4:
+        spec, H, W, S = presets.rung4_spec(), 64, 64, presets.RUNG4_MAX_OBJECTS
+        objs, agents, mapf = dict(presets.RUNG4_OBJECTS), dict(presets.RUNG4_AGENTS), presets.rung4_map
+        desc = ("rung4: 65536 envs/GPU x 64x64 random map x 64 agents (4 teams), rung-3 rules + 16 static AoE + mobile "
+                "AoE per agent + territory (8 sources) + aoe_mask obs + 3 events + materialized closure query, T=200")
+        A, T = 64, spec.obs.num_tokens
+        R, n_rw, n_dyn = len(spec.resource_names), 3, sum(v for k, v in objs.items() if k != "wall")
+        s_agent = 4 + 1 + 32 + 2 * R + R + 16 + 4 * n_rw             # SURVEY.md §8d S_agent
+        s_env = 2 * H * W + A * s_agent + n_dyn * 32 + 8
+    else:
+        raise SystemExit("--rung must be 3 or 4")
+    per = {"tick": 3 * T + 14 + 2 * s_env / A, "obs": 3 * T + 6 + s_env / A, "world": 8 + s_env / A}
+    return spec, H, W, S, objs, agents, mapf, desc, per
+
+
+def cpu_baseline(spec, prog, steps: int, cells) -> dict:
     """Reference C++ engine (oracle/_ref, kind "reference") or the CPU restatement (kind "port") on ONE env of the same
     workload on one host core — a reported baseline, never the measured product."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    from mettagrid_amd import presets
-    cells = presets.rung3_map(0)
     rng = np.random.RandomState(42)
     n, A = len(prog.action_names), prog.num_agents
     acts = rng.randint(0, n, (steps, A)).astype(np.int32)
@@ -58,7 +82,7 @@ def cpu_baseline(spec, prog, steps: int) -> dict:
         step(t)
     dt = time.perf_counter() - t0
     return {"value": steps * A / dt, "unit": "agent-steps/s", "cores": 1, "kind": kind,
-            "sample": f"1 env (map seed 0) of the same rung-3 workload, {steps} steps, random actions, 1 host core"}
+            "sample": f"1 env (map seed 0) of the same workload, {steps} steps, random actions, 1 host core"}
 
 
 def main() -> None:
@@ -67,9 +91,10 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--envs", type=int, default=65536, help="envs per GPU")
+    ap.add_argument("--rung", type=int, default=3, help="3 = BASELINE.json configs[2] (the headline metric), 4 = configs[3]")
     ap.add_argument("--gather", choices=["none", "scalars", "obs"], default="none",
                     help="optional per-step RCCL all_gather of rewards/terminals/truncations (+obs)")
-    ap.add_argument("--cpu-steps", type=int, default=300000, help="CPU baseline sample: about 10 s of one host core")
+    ap.add_argument("--cpu-steps", type=int, default=0, help="CPU baseline sample (default: about 10 s of one host core)")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 
@@ -85,18 +110,15 @@ def main() -> None:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    from mettagrid_amd import presets
     from mettagrid_amd.compiler import compile_spec
     from mettagrid_amd.engine import BatchedMettaGrid
     from mettagrid_amd.mapgen import random_class_maps
 
-    spec = presets.rung3_spec()
-    H = W = 32
-    prog = compile_spec(spec, H, W, max_objects=192)
+    spec, H, W, S, objs, agents, mapf, desc, per = workload(args.rung)
+    prog = compile_spec(spec, H, W, max_objects=S)
     E, A, T = args.envs, prog.num_agents, prog.num_tokens
     env0 = rank * E
-    cms = random_class_maps(prog, H, W, {"wall": 40, "extractor": 8, "chest": 4}, {"red": 8, "blue": 8},
-                            range(env0, env0 + E))
+    cms = random_class_maps(prog, H, W, objs, agents, range(env0, env0 + E))
     seeds = np.arange(env0, env0 + E, dtype=np.uint32)
     eng = BatchedMettaGrid(prog, cms, seeds, device=local_rank, buffers="device")
     del cms
@@ -159,29 +181,30 @@ def main() -> None:
 
     # per-kernel durations for the roofline line: HIP events between the two kernels on the engine stream
     eng.set_profiling(True)
-    k_world, k_obs, nprof = 0.0, 0.0, min(50, max(5, args.steps))
+    nprof = min(50, max(5, args.steps))
+    seg = {}
     for t in range(nprof):
         one_step(t)
-        w_ms, o_ms = eng.step_timing_ms()
-        k_world += w_ms
-        k_obs += o_ms
+        for k, v in eng.step_timing_segments_ms().items():
+            seg[k] = seg.get(k, 0.0) + v / nprof
     eng.set_profiling(False)
-    k_world /= nprof
-    k_obs /= nprof
+    k_obs = seg["obs"]
 
     if rank == 0:
         agent_steps = world * E * A * args.steps
         value = agent_steps / wall
-        # algorithmic bytes of the dominant (observation) kernel per agent-step, DESIGN.md "Roofline accounting":
-        # obs out 3T + reward 4 + terminal 1 + truncation 1 + one read of the env state S_env/A.
-        s_env = 2 * H * W + A * 87 + 12 * 32 + 8
-        bytes_per_agent_step = 3 * T + 6 + s_env / A
-        achieved = E * A * bytes_per_agent_step / (k_obs * 1e-3) / 1e9
+        # Roofline of the dominant kernel (DESIGN.md "Roofline accounting").  Algorithmic bytes per agent-step: the
+        # observation kernel owns obs out 3T + reward 4 + terminal 1 + truncation 1 + one read of the env state
+        # S_env/A; the world-update kernel owns the two action streams (8) + one pass over S_env/A.
+        names = {"obs": "mgx_obs_kernel", "actions": "mgx_world_kernel_x" if args.rung == 4 else "mgx_world_kernel_fast"}
+        dom = "obs" if seg["obs"] >= seg["actions"] else "actions"
+        bytes_per_agent_step = per["obs"] if dom == "obs" else per["world"]
+        achieved = E * A * bytes_per_agent_step / (seg[dom] * 1e-3) / 1e9
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get("mgx_obs_kernel_bytes_per_launch")
+                traffic = json.load(open(pmc)).get(f"rung{args.rung}", {}).get(names[dom] + "_bytes_per_launch")
             except Exception:
                 traffic = None
         out = {
@@ -189,18 +212,20 @@ def main() -> None:
             "value": value, "unit": "agent-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": wall * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "rung3: 65536 envs/GPU x 32x32 random map x 16 agents, 8-dir move + 4 vibes, "
-                                   "attack/on-use handler chains, 11x11 token obs T=200",
+            "config": {"workload": desc, "baseline_config": f"configs[{args.rung - 1}]",
                        "envs_per_gpu": E, "agents_per_env": A, "obs_tokens": T, "gather": args.gather,
                        "parallelism": f"env-shard x{world}"},
             "device_ms_per_step": dev_ms / args.steps,
-            "kernels_ms": {"mgx_world_kernel": k_world, "mgx_obs_kernel": k_obs},
-            "roofline": {"bound": "hbm", "kernel": "mgx_obs_kernel", "achieved": achieved, "peak": 8000.0,
+            "kernels_ms": {"world_actions": seg["actions"], "aoe": seg["aoe"], "world_tail": seg["tail"],
+                           "mgx_obs_kernel": seg["obs"], "rewards_ext": seg["rewards"]},
+            "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": 8000.0,
                          "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
-                         "bytes_per_agent_step": bytes_per_agent_step},
+                         "bytes_per_agent_step": bytes_per_agent_step,
+                         "tick_bytes_per_agent_step": per["tick"]},
         }
         if not args.no_cpu and world == 1:
-            out["cpu_baseline"] = cpu_baseline(spec, prog, args.cpu_steps)
+            cpu_steps = args.cpu_steps or (300000 if args.rung == 3 else 25000)
+            out["cpu_baseline"] = cpu_baseline(spec, prog, cpu_steps, mapf(0))
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

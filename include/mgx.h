@@ -101,11 +101,21 @@ int mgx_get_reward_state(mgx_engine* e, int32_t env, float* out);
  * Replaces the exceptions thrown from inside step() in the reference. */
 int mgx_poll_errors(mgx_engine* e, uint32_t* bits, int32_t* first_env);
 
-/* Device time of the most recent mgx_step in milliseconds, per kernel: [0] world-update kernel, [1] observation
- * kernel (hipEvents on the engine stream; replaces MettaGrid.step_timing, cpp/bindings/profiling_py.cpp:8-30).
- * Only recorded after mgx_set_profiling(e, 1). */
+/* Device time of the most recent mgx_step in milliseconds, per segment of the tick (hipEvents on the engine stream;
+ * replaces MettaGrid.step_timing / last_obs_time_ns, cpp/bindings/profiling_py.cpp:8-30, whose fields are named beside
+ * each segment).  Only recorded after mgx_set_profiling(e, 1). */
+enum {
+  MGX_T_ACTIONS = 0, /* world kernel: snapshot, shuffle, actions, events, per-agent on_tick (actions_ns + events_ns +
+                        on_tick_ns); for lean games and the serial AoE form: the whole world update */
+  MGX_T_AOE,         /* ownership map refresh + lane-per-agent area effects (aoe_ns); 0 when folded into MGX_T_ACTIONS */
+  MGX_T_TAIL,        /* game on_tick + coverage tracking; 0 when folded into MGX_T_ACTIONS */
+  MGX_T_OBS,         /* observation kernel incl. rewards / truncation for plain values (observations_ns + rewards_ns +
+                        truncation_ns), preceded by the ownership map refresh and query-backed obs values */
+  MGX_T_REWARDS,     /* reward entries with query operands (rewards_ns), else 0 */
+  MGX_T_COUNT
+};
 int mgx_set_profiling(mgx_engine* e, int32_t enabled);
-int mgx_get_step_timing(mgx_engine* e, float* ms_out /* [2] */);
+int mgx_get_step_timing(mgx_engine* e, float* ms_out /* [MGX_T_COUNT] */);
 
 /* Shape queries. */
 int32_t mgx_num_envs(const mgx_engine* e);

@@ -18,7 +18,7 @@
 #include <stdint.h>
 
 #define MGX_MAGIC 0x3158474d /* "MGX1" little-endian */
-#define MGX_VERSION 6
+#define MGX_VERSION 7
 
 #define MGX_MAX_RESOURCES 13 /* inventory order list = 4-bit ids in one u64, 0xF terminator; see DESIGN.md */
 #define MGX_TAG_WORDS 8      /* 256 tags = 8 x u32 (reference kMaxTags, core/types.hpp:62) */
@@ -62,6 +62,9 @@ enum {
   MGX_H_NUM_INDEXED_TAGS,/* tags that own a TagIndex list (referenced by a TagQuery) */
   MGX_H_QUERY_DEPTH,     /* max nesting of queries */
   MGX_H_SPAWNS,          /* 1: the program can create objects at run time (Spawn / RaycastSpawn) */
+  MGX_H_TAG_MUTATIONS,   /* 1: some handler adds / removes tags (any object's tag set may change); 0 with DYNAMIC_TAGS set:
+                            only materialized queries change tags, and only on classes whose MGX_C_STATIC is 0 */
+  MGX_H_NUM_MATQ_TAGS,   /* distinct tags materialized queries can add to an object (bound of its extra tag tokens) */
   MGX_H_FEAT_BASE = 40, /* MGX_F_* feature ids follow */
   MGX_H_STAT_BASE = 56, /* MGX_S_* well-known stat ids follow */
   MGX_H_SECTION_BASE = 104, /* section s: offset at BASE+2s, record count at BASE+2s+1 */

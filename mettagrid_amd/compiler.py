@@ -156,6 +156,7 @@ class _Compiler:
         self.query_depth = 0
         self._qdepth = 0          # nesting level of the query currently being emitted (filters/values inherit it)
         self.dynamic_tags = False
+        self.tag_mutations = False       # AddTag / RemoveTag / RemoveTagsWithPrefix somewhere in the program
 
     # ---- id tables -------------------------------------------------------------------------------------------
     def build_ids(self) -> None:
@@ -446,10 +447,12 @@ class _Compiler:
             return [K.MOP_CHANGE_VIBE, self.ent(m.entity), self.vibe_id[m.vibe], 0, 0, 0]
         if isinstance(m, (S.AddTag, S.RemoveTag)):
             self.dynamic_tags = True
+            self.tag_mutations = True
             op = K.MOP_ADD_TAG if isinstance(m, S.AddTag) else K.MOP_REMOVE_TAG
             return [op, self.ent(m.entity), self.tag_id[m.tag], 0, 0, 0]
         if isinstance(m, S.RemoveTagsWithPrefix):
             self.dynamic_tags = True
+            self.tag_mutations = True
             ids = self.prefix_tags(m.prefix)
             return [K.MOP_REMOVE_TAGS_PREFIX, self.ent(m.entity), self.emit_words(ids) if ids else 0, len(ids), 0, 0]
         if isinstance(m, S.GameValueMutation):
@@ -630,6 +633,46 @@ class _Compiler:
             if src.aoes or src.territory_controls:
                 rec[K.C_STATIC] = 0
         return self.emit(K.SEC_CLASSES, rec)
+
+    def _matq_mutable_classes(self) -> set:
+        """Classes whose objects a materialized query can tag: fixpoint over 'carries a leaf tag of the query'."""
+        def leaves(q, out):
+            if isinstance(q, str):
+                out.add(q)
+            elif isinstance(q, S.MaterializedQuery):
+                out.add(q.tag)
+            elif isinstance(q, S.TagQuery):
+                out.add(q.tag)
+            else:
+                for attr in ("source", "candidates"):
+                    sub = getattr(q, attr, None)
+                    if sub is not None:
+                        leaves(sub, out)
+        cw = self.sections[K.SEC_CLASSES]
+        n = self.counts[K.SEC_CLASSES]
+
+        def has(c, t):
+            return (cw[c * K.C_WORDS + K.C_TAGS + (t >> 5)] >> (t & 31)) & 1
+
+        mutable: set = set()
+        given: dict = {}   # class -> tags a query may add
+        changed = True
+        while changed:
+            changed = False
+            for mq in self.spec.materialize_queries:
+                lv: set = set()
+                leaves(mq.query, lv)
+                ids = [self.tag_id[t] for t in lv if t in self.tag_id]
+                tid = self.tag_id[mq.tag]
+                for c in range(n):
+                    if any(has(c, t) or t in given.get(c, ()) for t in ids) and tid not in given.setdefault(c, set()):
+                        given[c].add(tid)
+                        mutable.add(c)
+                        changed = True
+        for c in range(n):  # a class that carries a materialized tag from the start can lose it
+            if any(has(c, self.tag_id[mq.tag]) for mq in self.spec.materialize_queries):
+                mutable.add(c)
+        return mutable
 
     # ---- top level -------------------------------------------------------------------------------------------
     def compile(self) -> Program:
@@ -908,9 +951,17 @@ class _Compiler:
         h[K.H_NUM_INDEXED_TAGS] = len(self.indexed_tags)
         self.sections[K.SEC_TAG_LISTS] = tag_lists
         self.counts[K.SEC_TAG_LISTS] = 256
-        if self.dynamic_tags:   # nothing is immutable once tags can change under an object
+        h[K.H_TAG_MUTATIONS] = 1 if self.tag_mutations else 0
+        h[K.H_NUM_MATQ_TAGS] = len({mq.tag for mq in sp.materialize_queries})
+        if self.dynamic_tags:
             cw = self.sections[K.SEC_CLASSES]
-            for c in range(self.counts[K.SEC_CLASSES]):
+            if self.tag_mutations:   # nothing is immutable once handlers can change tags under any object
+                mutable = set(range(self.counts[K.SEC_CLASSES]))
+            else:
+                # Only materialized queries change tags: a query result is a subset of the objects its leaf tag
+                # queries list, so only classes that carry (or can be given) one of those tags can change.
+                mutable = self._matq_mutable_classes()
+            for c in mutable:
                 cw[c * K.C_WORDS + K.C_STATIC] = 0
         fb = K.H_FEAT_BASE
         h[fb + K.F_GROUP] = feats["agent:group"]

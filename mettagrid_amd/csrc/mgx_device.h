@@ -82,16 +82,21 @@ struct MgxDev {
   uint16_t* fx_aoe;       // [E][NF]
   uint16_t* fx_rc;        // [E][NF] location at registration
   uint32_t* fx_inside;    // [E][NF][AW]
+  uint32_t* fx_pack;      // [E][NF] rc | radius << 16 | live << 24, rebuilt every step for the lane-per-agent AoE kernel
   uint16_t* fx_count;     // [E]
   uint16_t* mb_obj;       // [E][NM] mobile AoE sources
   uint16_t* mb_aoe;       // [E][NM]
   uint32_t* mb_inside;    // [E][NM][AW]
+  uint32_t* mb_pack;      // [E][NM] like fx_pack, with the source's CURRENT location
   uint16_t* mb_count;     // [E]
   uint16_t* ts_obj;       // [E][NTS] territory sources in registration order
   uint16_t* ts_ctrl;      // [E][NTS]
   uint16_t* ts_rc;        // [E][NTS] registered location
   uint16_t* ts_count;     // [E]
   int16_t* terr_prev;     // [E][A][NT] previous owner tag or -1
+  uint32_t* obsval;       // [E][A][n_obs_values] query-backed global obs values (mgx_values_kernel), else nullptr
+  uint16_t* terr_owner;   // [E][NT][H*W] cached cell ownership (winning tag, 0xFFFF = none), rebuilt by mgx_terr_kernel
+  uint8_t* terr_dirty;    // [E] 1: a territory source moved / changed tags since the map was built
   uint32_t* next_event;   // [E]
   uint8_t* obj_flags;     // [E][S] bit0 removed from the grid, bit1 created at run time (no inventory tokens)
   uint16_t* def_aoe;      // [E][S] objects spawned this tick whose AoEs register at flush_deferred
@@ -110,25 +115,33 @@ struct MgxDev {
   const int32_t* vibe_actions;  // [E*A]
 };
 
-// MGX_CONST_DEV: the translation unit keeps the engine's MgxDev in constant memory instead of passing it as a kernel
-// argument.  Every function of the handler VM then reads it by name: scalar, invariant loads (s_load from the
-// constant cache) even inside out-of-line callees, where a by-reference MgxDev would be flat-loaded through `this`
-// and re-loaded after every store that might alias it.  The host keeps the symbol in step with the engine that
-// launches (mgx_world_fast.hip).
+// How device code reaches the engine's MgxDev: every kernel takes it BY VALUE (it lives in the kernarg segment, so inside
+// the kernel and everything inlined into it each field is a scalar, invariant s_load) and MgxEnvT keeps a reference to
+// that argument.  Per launch, per engine: there is no process-wide __constant__ copy to keep in step (round 1 had one
+// and had to drain the device whenever two engines alternated).
+// NOTE (measured, gfx950 / ROCm 7.2): __builtin_amdgcn_kernarg_segment_ptr() must not be used to reach it from
+// functions that may stay out of line — outside the kernel function itself the compiler folds that intrinsic to a null
+// pointer (the callee is never passed the kernarg pointer), and the first field access faults at address 0.
+#define MGX_KERNARG_ENTRY(dv) ((void)0)
+// MGX_CONST_DEV (the lean world kernel's translation unit only): that kernel keeps the engine's MgxDev in constant
+// memory instead — measured 0.44 ms against 0.67 ms per step with the by-value argument (rung 3, 65 536 envs: the
+// argument form keeps ~70 fields live in SGPRs across a 30 000-instruction kernel and spills them).  The unit is
+// compiled once per MGX_SLOT (two slots), engines take slots round-robin, and the host keeps a slot's symbol equal to
+// the launching engine's table (content compare; a change first waits for the kernels still reading the old content),
+// so two engines alive in one process (train + eval) do not disturb each other.
 #ifdef MGX_CONST_DEV
 static __constant__ MgxDev g_mgx_dev;
 #endif
 
-__device__ __forceinline__ const int32_t* mgx_cls(const MgxDev& d, int cls) {
+template <class D> __device__ __forceinline__ const int32_t* mgx_cls(const D& d, int cls) {
   return d.P + d.sec[MGX_SEC_CLASSES] + cls * MGX_C_WORDS;
 }
-__device__ __forceinline__ int mgx_wk(const MgxDev& d, int s) { return d.wk[s]; }
 
 // glibc 2.35 logf restated (sysdeps/ieee754/flt-32/e_logf.c; table e_logf_data.c).  The reference calls
 // std::log(float) in SumValue(log=True) (cpp/src/mettagrid/core/game_value.cpp:77-79) and the parity signature
 // exposes every bit of it.  tests/golden/logf_check.c proves this restatement equal to the host libm for all
 // 2 139 095 039 positive finite floats.  Double arithmetic with contraction disabled.
-__device__ __noinline__ float mgx_logf(float x) {
+static __device__ __noinline__ float mgx_logf(float x) {
 #pragma clang fp contract(off)
   static const double INVC[16] = {0x1.661ec79f8f3bep+0, 0x1.571ed4aaf883dp+0, 0x1.49539f0f010bp+0,  0x1.3c995b0b80385p+0,
                            0x1.30d190c8864a5p+0, 0x1.25e227b0b8eap+0,  0x1.1bb4a4a1a343fp+0, 0x1.12358f08ae5bap+0,

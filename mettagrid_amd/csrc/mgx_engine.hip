@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -14,11 +15,36 @@
 #include "mgx_obs.h"
 #include "mgx_world.h"
 
-template <bool PROG_LDS>
-__global__ void __launch_bounds__(MGX_WAVE) mgx_world_kernel_ext(MgxDev d, int prog_words) {
-  mgx_world_entry<PROG_LDS, true>(d, prog_words);
+
+// Territory ownership map (TerritoryTracker::compute_cell_ownership, core/territory_tracker.cpp:215-252) of every cell,
+// per territory type: one workgroup per env, rebuilt only for envs whose sources moved or changed tags since the last
+// build (terr_dirty).  Static sources (flags) make this a once-per-episode cost; the observation kernel's aoe_mask
+// token and the per-agent territory effects then read one u16 per cell instead of re-deriving the influence sums.
+__global__ void __launch_bounds__(256) mgx_terr_kernel(MgxDev d) {
+  MGX_KERNARG_ENTRY(d);
+  extern __shared__ __align__(16) uint8_t smem[];
+  const int env = blockIdx.x;
+  if (!d.terr_dirty[env]) return;
+  MgxEnvX e(d, d.P, env);
+  e.xl.terr_score = (long long*)smem;
+  e.xl.lane = (int)threadIdx.x;
+  e.xl.stride = 256;
+  const int HW = d.H * d.W;
+  for (int ti = 0; ti < d.NT; ti++)
+    for (int cellidx = (int)threadIdx.x; cellidx < HW; cellidx += 256) {
+      const int owner = e.cell_owner(cellidx / d.W, cellidx % d.W, ti);
+      d.terr_owner[((size_t)env * d.NT + ti) * (size_t)HW + cellidx] = owner < 0 ? (uint16_t)0xFFFF : (uint16_t)owner;
+    }
+  __syncthreads();
+  if (threadIdx.x == blockDim.x - 1) d.terr_dirty[env] = 0;
 }
 
+// MGX_TRACE=1: name every launch on stderr and wait for it, so that a faulting kernel is the last one named.
+static bool g_trace = getenv("MGX_TRACE") != nullptr;
+#define MGX_TRACE_POINT(e, what)                                                   \
+  do {                                                                             \
+    if (g_trace) { (void)hipStreamSynchronize((e)->stream); fprintf(stderr, "[mgx] done: %s\n", what); fflush(stderr); } \
+  } while (0)
 static thread_local std::string g_err;
 static int fail(int code, const std::string& msg) {
   g_err = msg;
@@ -75,14 +101,16 @@ struct mgx_engine {
   }
   bool verbose = false;
   bool rewards_early = false;  // reward expressions have no stat operands: evaluated beside the token-cache phase
+  int slot = 0;                // constant-memory slot of the lean world kernel (mgx_world_fast.hip, MGX_SLOT)
+  bool aoe_local = false;      // area effects only touch their target: one lane per agent (mgx_aoe_kernel)
+  bool rewards_ext = false;    // reward expressions have query operands: evaluated by mgx_values_kernel after the obs kernel
   uint16_t* dmaps = nullptr;
   uint32_t* dseeds = nullptr;
   uint8_t* dmask = nullptr;
   struct Row { void* base; size_t row_bytes; int fill; };
   std::vector<Row> rows_state;  // per-env state arrays (env-major) that an episode restart clears
   bool profiling = false;
-  hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
-  float last_ms[2] = {0.f, 0.f};
+  hipEvent_t ev[MGX_T_COUNT + 1] = {};  // boundaries of the timing segments of the most recent step (profiling only)
 
   template <class T>
   int alloc_env(T** p, size_t per_env, int fill = 0) {  // env-major array: remembered for episode restarts
@@ -118,10 +146,18 @@ static int size_obs_lds(mgx_engine* e) {
   if (e->verbose || getenv("MGX_VERBOSE"))
     fprintf(stderr, "[mgx] obs: lds=%zu B pool=%d tokens (prefix %d) blk_lds=%d rewards_early=%d\n", e->lds_obs, e->pool_tokens,
             e->pool_prefix, (int)e->obs_blk_lds, (int)e->rewards_early);
-  const void* fns[] = {(const void*)mgx_obs_kernel<true, false, false>, (const void*)mgx_obs_kernel<false, false, false>,
-                       (const void*)mgx_obs_kernel<true, false, true>,  (const void*)mgx_obs_kernel<false, false, true>,
-                       (const void*)mgx_obs_kernel<true, true, false>,  (const void*)mgx_obs_kernel<false, true, false>};
-  for (const void* f : fns) HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_obs));
+  // The attribute is per kernel and process-wide: keep one maximum and only ever raise it, so that a second engine
+  // with a smaller requirement cannot lower the limit under a live one.
+  static std::mutex mu;
+  static size_t cur_max = 0;
+  std::lock_guard<std::mutex> lock(mu);
+  if (e->lds_obs > cur_max) {
+    const void* fns[] = {(const void*)mgx_obs_kernel<true, false, false>, (const void*)mgx_obs_kernel<false, false, false>,
+                         (const void*)mgx_obs_kernel<true, false, true>,  (const void*)mgx_obs_kernel<false, false, true>,
+                         (const void*)mgx_obs_kernel<true, true, false>,  (const void*)mgx_obs_kernel<false, true, false>};
+    for (const void* f : fns) HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_obs));
+    cur_max = e->lds_obs;
+  }
   return MGX_OK;
 }
 
@@ -136,7 +172,24 @@ static void launch_obs_t(mgx_engine* e, bool with_rewards, const uint8_t* mask) 
   else
     hipLaunchKernelGGL((mgx_obs_kernel<false, X, PL>), grid, block, e->lds_obs, e->stream, dd, e->pool_tokens, e->pool_prefix, mask, e->obs_blk_start, e->obs_blk_words, (int)e->rewards_early);
 }
+static int launch_terr(mgx_engine* e) {  // refresh the ownership maps of the envs whose territory sources changed
+  if (e->d.X && e->d.NT > 0 && e->d.terr_owner) {
+    hipLaunchKernelGGL(mgx_terr_kernel, dim3(e->d.E), dim3(256), 8 * 256 * 8, e->stream, e->d);
+    HIP_TRY(hipGetLastError());
+  }
+  return MGX_OK;
+}
 static int launch_obs(mgx_engine* e, bool with_rewards, const uint8_t* mask = nullptr) {
+#ifdef MGX_CPU_EMU
+  (void)with_rewards; (void)mask;
+  return launch_terr(e);  // sanitizer build: the wavefront-cooperative observation kernel is not emulated
+#endif
+  int trc = launch_terr(e);
+  if (trc) return trc;
+  MGX_TRACE_POINT(e, "terr kernel");
+  if (e->d.obsval) mgx_launch_values(e->stream, e->d, 0, mask);
+  MGX_TRACE_POINT(e, "values kernel");
+  if (e->rewards_ext) with_rewards = false;
   if (e->d.X) launch_obs_t<true, false>(e, with_rewards, mask);
   else if (e->obs_blk_lds) launch_obs_t<false, true>(e, with_rewards, mask);
   else launch_obs_t<false, false>(e, with_rewards, mask);
@@ -254,6 +307,7 @@ int mgx_create(const int32_t* program, size_t program_words, const uint16_t* cla
       nm += per_m ? std::min<int>(d.S * per_m, 4096) : 0;
     }
     d.NF = nf; d.NM = nm; d.NTS = nts;
+    e->aoe_local = mgx_aoe_is_target_local(P) && !getenv("MGX_AOE_SERIAL");
     d.X = (any_aoe || d.NT > 0 || d.n_schedule > 0 || d.n_matq > 0 || d.game_on_tick >= 0 || P[MGX_H_DYNAMIC_TAGS] ||
            mgx_sec_cnt(P, MGX_SEC_QUERIES) > 0) ? 1 : 0;
   }
@@ -304,12 +358,15 @@ int mgx_create(const int32_t* program, size_t program_words, const uint16_t* cla
     if (P[MGX_H_DYNAMIC_TAGS]) A_(e->alloc_env(&d.obj_tags, S * MGX_TAG_WORDS));
     if (d.NL) { A_(e->alloc_env(&d.tl_items, d.NL * S)); A_(e->alloc_env(&d.tl_count, (size_t)d.NL)); }
     if (d.NF) { A_(e->alloc_env(&d.fx_obj, (size_t)d.NF)); A_(e->alloc_env(&d.fx_aoe, (size_t)d.NF)); A_(e->alloc_env(&d.fx_rc, (size_t)d.NF));
-                A_(e->alloc_env(&d.fx_inside, (size_t)d.NF * d.AW)); A_(e->alloc_env(&d.fx_count, 1)); }
+                A_(e->alloc_env(&d.fx_inside, (size_t)d.NF * d.AW)); A_(e->alloc_env(&d.fx_count, 1));
+                if (e->aoe_local) A_(e->alloc(&d.fx_pack, E * (size_t)d.NF)); }
     if (d.NM) { A_(e->alloc_env(&d.mb_obj, (size_t)d.NM)); A_(e->alloc_env(&d.mb_aoe, (size_t)d.NM));
-                A_(e->alloc_env(&d.mb_inside, (size_t)d.NM * d.AW)); A_(e->alloc_env(&d.mb_count, 1)); }
+                A_(e->alloc_env(&d.mb_inside, (size_t)d.NM * d.AW)); A_(e->alloc_env(&d.mb_count, 1));
+                if (e->aoe_local) A_(e->alloc(&d.mb_pack, E * (size_t)d.NM)); }
     if (d.NTS) { A_(e->alloc_env(&d.ts_obj, (size_t)d.NTS)); A_(e->alloc_env(&d.ts_ctrl, (size_t)d.NTS)); A_(e->alloc_env(&d.ts_rc, (size_t)d.NTS));
                  A_(e->alloc_env(&d.ts_count, 1)); }
     A_(e->alloc_env(&d.terr_prev, A * std::max(1, d.NT)));
+    if (d.NT > 0 && d.NTS > 0) { A_(e->alloc(&d.terr_owner, E * (size_t)d.NT * HW, 0xFF)); A_(e->alloc_env(&d.terr_dirty, 1, 1)); }
     A_(e->alloc_env(&d.next_event, 1));
     A_(e->alloc_env(&d.obj_flags, S));
     if (P[MGX_H_SPAWNS]) { A_(e->alloc_env(&d.def_aoe, S)); A_(e->alloc_env(&d.def_count, 1)); }
@@ -325,13 +382,16 @@ int mgx_create(const int32_t* program, size_t program_words, const uint16_t* cla
   d.obs = e->own_obs; d.terminals = e->own_term; d.truncations = e->own_trunc; d.rewards = e->own_rew;
   d.actions = e->own_act; d.vibe_actions = e->own_vact;
 
-  e->lds_world = (size_t)mgx_world_lds_fixed(d.A, d.X != 0);
+  e->verbose = getenv("MGX_VERBOSE") != nullptr;
+  e->lds_world = d.X ? mgx_world_x_lds_bytes(d.A) : mgx_world_fast_lds_bytes(d.A);
   e->prog_in_lds = program_words * 4 + e->lds_world <= 40 * 1024;  // 4 workgroups per CU (160 KB LDS) keep their copy
+#ifdef MGX_CPU_EMU
+  e->prog_in_lds = false;  // the LDS copy needs a workgroup barrier; the sanitizer build runs work-items one by one
+#endif
   if (e->prog_in_lds) e->lds_world += program_words * 4;
   if (getenv("MGX_VERBOSE"))
     fprintf(stderr, "[mgx] E=%d A=%d S=%d program=%zu B world: X=%d prog_in_lds=%d lds=%zu B\n", d.E, d.A, d.S,
             program_words * 4, d.X, (int)e->prog_in_lds, e->lds_world);
-  e->verbose = getenv("MGX_VERBOSE") != nullptr;
   {  // per-class static tag tokens (ascending tag id, core/grid_object.cpp:181-186)
     std::vector<uint32_t> info(P[MGX_H_NUM_CLASSES]);
     std::vector<uint16_t> toks;
@@ -371,11 +431,13 @@ int mgx_create(const int32_t* program, size_t program_words, const uint16_t* cla
       const int32_t* C = P + d.sec[MGX_SEC_CLASSES] + c * MGX_C_WORDS;
       int n = 0;
       for (int w = 0; w < MGX_TAG_WORDS; w++) n += __builtin_popcount((unsigned)C[MGX_C_TAGS + w]);
-      if (!C[MGX_C_STATIC]) n += 1 + P[MGX_H_NUM_RESOURCES] * digits + (C[MGX_C_KIND] == MGX_KIND_AGENT ? 2 : 0);
+      if (!C[MGX_C_STATIC]) n += 1 + P[MGX_H_NUM_RESOURCES] * digits + (C[MGX_C_KIND] == MGX_KIND_AGENT ? 2 : 0) +
+                                 P[MGX_H_NUM_MATQ_TAGS];  // + the tags materialized queries may add
       max_per_obj = std::max(max_per_obj, n);
       e->class_list_tokens[c] = C[MGX_C_STATIC] ? 0 : n;
     }
-    e->pool_from_maps = !d.X && !P[MGX_H_SPAWNS] && !P[MGX_H_DYNAMIC_TAGS];
+    // without run-time object creation and without tag mutations the class maps bound the lists exactly
+    e->pool_from_maps = !P[MGX_H_SPAWNS] && !P[MGX_H_TAG_MUTATIONS];
     long long bound = e->pool_from_maps ? e->list_tokens_bound(class_maps, 0, (size_t)E, nullptr) : (long long)S * max_per_obj;
     e->pool_tokens = (e->pool_prefix + (int)std::min<long long>(bound, 16384) + 7) & ~7;
   }
@@ -402,7 +464,7 @@ int mgx_create(const int32_t* program, size_t program_words, const uint16_t* cla
     for (int i = 0; i < n_code; i++)
       if (!reward_only[i] && code[i * MGX_GV_WORDS + MGX_GV_OP] == MGX_GOP_STAT && code[i * MGX_GV_WORDS + MGX_GV_A0] != 1)
         reads_agent_stats = true;
-    d.defer_book = reads_agent_stats ? 0 : 1;
+    d.defer_book = (reads_agent_stats || d.X) ? 0 : 1;  // (the extended kernel's phases may run as separate launches)
   }
   {  // reward code made only of inventory / constant arithmetic reads nothing the observation kernel writes
     bool pure = !d.X;
@@ -416,6 +478,24 @@ int mgx_create(const int32_t* program, size_t program_words, const uint16_t* cla
       }
     }
     e->rewards_early = pure;
+    auto has_query = [&](int start, int count) {
+      for (int i = 0; i < count; i++) {
+        const int op = P[d.sec[MGX_SEC_GV_CODE] + (start + i) * MGX_GV_WORDS + MGX_GV_OP];
+        if (op == MGX_GOP_QUERY_INVENTORY || op == MGX_GOP_QUERY_COUNT) return true;
+      }
+      return false;
+    };
+    for (int k = 0; k < n_rw; k++)
+      if (has_query(rw[k * MGX_RW_WORDS + MGX_RW_GV_START], rw[k * MGX_RW_WORDS + MGX_RW_GV_COUNT])) e->rewards_ext = true;
+    bool obsval_ext = false;
+    for (int i = 0; i < d.n_obs_values; i++) {
+      const int32_t* V = P + d.sec[MGX_SEC_OBS_VALUES] + i * MGX_OV_WORDS;
+      if (has_query(V[MGX_OV_GV_START], V[MGX_OV_GV_COUNT])) obsval_ext = true;
+    }
+    if (obsval_ext) {
+      int arc = e->alloc(&d.obsval, (size_t)d.E * d.A * d.n_obs_values);
+      if (arc != MGX_OK) { mgx_destroy(e); return arc; }
+    }
   }
   // The world kernel stages 17 (+ extended: 176) bytes per agent and env in LDS, 64 envs per workgroup: up to 160 KB,
   // i.e. about 147 agents per env in the lean variant.  Past 64 KB the kernels need the opt-in attribute.
@@ -424,24 +504,19 @@ int mgx_create(const int32_t* program, size_t program_words, const uint16_t* cla
     return fail(MGX_ERR_PROGRAM, "mgx_create: too many agents per env for the world kernel's LDS staging (160 KB per 64 envs)");
   }
   {
-    hipError_t la = hipFuncSetAttribute((const void*)mgx_world_kernel_ext<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_world);
-    if (la == hipSuccess) la = hipFuncSetAttribute((const void*)mgx_world_kernel_ext<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_world);
-    if (la == hipSuccess) la = mgx_world_fast_set_lds(e->lds_world) ? hipSuccess : hipErrorInvalidValue;
-    if (la != hipSuccess) { mgx_destroy(e); return fail(MGX_ERR_HIP, "mgx_create: cannot raise the world kernel's dynamic LDS limit"); }
+    static std::mutex mu;
+    static int next_slot = 0;
+    std::lock_guard<std::mutex> lock(mu);
+    e->slot = next_slot;
+    if (!d.X) next_slot = (next_slot + 1) % MGX_FAST_SLOTS;
   }
-  {  // Build sanity: with a private segment (stack frames of the out-of-line handler functions + spills) of 9 200 bytes
-     // per lane the extended world kernel produced wrong results on gfx950 / ROCm 7.2 without any error; at 6 736 it is
-     // correct.  Refuse to run a build that is past 8 KiB instead of stepping envs wrongly.
-    const void* ks[] = {(const void*)mgx_world_kernel_ext<true>, (const void*)mgx_world_kernel_ext<false>, (const void*)mgx_init_kernel};
-    for (const void* k : ks) {
-      hipFuncAttributes fa;
-      if (hipFuncGetAttributes(&fa, k) == hipSuccess && fa.localSizeBytes > 8192) {
-        mgx_destroy(e);
-        return fail(MGX_ERR_HIP, "mgx_create: a kernel of this build needs " + std::to_string(fa.localSizeBytes) +
-                                     " bytes of private memory per lane (> 8192): rebuild with smaller stack frames");
-      }
-    }
+  if (!(d.X ? mgx_world_x_set_lds(e->lds_world)
+            : (e->slot == 0 ? mgx_world_fast_set_lds_s0(e->lds_world) : mgx_world_fast_set_lds_s1(e->lds_world)))) {
+    mgx_destroy(e);
+    return fail(MGX_ERR_HIP, "mgx_create: cannot raise the world kernel's dynamic LDS limit");
   }
+  if (e->verbose && d.X)
+    fprintf(stderr, "[mgx] extended world kernel: %zu bytes of private memory per lane\n", mgx_world_x_private_bytes());
   rc = size_obs_lds(e);
   if (rc != MGX_OK) { mgx_destroy(e); return rc; }
   hipError_t he = hipSuccess;
@@ -456,7 +531,8 @@ int mgx_create(const int32_t* program, size_t program_words, const uint16_t* cla
   he = hipGetLastError();
   if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
   if (he != hipSuccess) { mgx_destroy(e); return fail(MGX_ERR_HIP, std::string("mgx_init_kernel: ") + hipGetErrorString(he)); }
-  for (int i = 0; i < 3; i++) (void)hipEventCreate(&e->ev[i]);
+  MGX_TRACE_POINT(e, "init kernel");
+  for (int i = 0; i <= MGX_T_COUNT; i++) (void)hipEventCreate(&e->ev[i]);
   rc = init_buffers(e);  // ctor -> _make_buffers -> set_buffers -> _init_buffers (mettagrid_c.cpp:190, 271-292)
   if (rc != MGX_OK) { mgx_destroy(e); return rc; }
   *out = e;
@@ -468,7 +544,7 @@ void mgx_destroy(mgx_engine* e) {
   (void)hipSetDevice(e->device);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   for (void* p : e->allocs) (void)hipFree(p);
-  for (int i = 0; i < 3; i++) if (e->ev[i]) (void)hipEventDestroy(e->ev[i]);
+  for (int i = 0; i <= MGX_T_COUNT; i++) if (e->ev[i]) (void)hipEventDestroy(e->ev[i]);
   if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
 }
@@ -572,26 +648,41 @@ int mgx_step(mgx_engine* e) {
     HIP_TRY(hipMemcpyAsync(e->own_act, e->h_act, rows * 4, hipMemcpyHostToDevice, e->stream));
     HIP_TRY(hipMemcpyAsync(e->own_vact, e->h_vact, rows * 4, hipMemcpyHostToDevice, e->stream));
   }
-  if (d.X) {  // executed_actions / _action_success cleared (:944,962-964); the lean world kernel clears its own rows
-    HIP_TRY(hipMemsetAsync(d.executed, 0, rows * 4, e->stream));
-    HIP_TRY(hipMemsetAsync(d.success, 0, rows, e->stream));
-  }
-  if (e->profiling) HIP_TRY(hipEventRecord(e->ev[0], e->stream));
+  // timing segments (profiling only): event k closes segment k - 1 of include/mgx.h MGX_T_*
+#define MGX_MARK(k) do { if (e->profiling) HIP_TRY(hipEventRecord(e->ev[k], e->stream)); } while (0)
+  MGX_MARK(0);
   {
     const int pw = (int)e->prog.size();
-    if (d.X) {
-      dim3 grid((d.E + MGX_WAVE - 1) / MGX_WAVE), block(MGX_WAVE);
-      if (e->prog_in_lds) hipLaunchKernelGGL((mgx_world_kernel_ext<true>), grid, block, e->lds_world, e->stream, e->d, pw);
-      else hipLaunchKernelGGL((mgx_world_kernel_ext<false>), grid, block, e->lds_world, e->stream, e->d, pw);
+    MGX_TRACE_POINT(e, "before world");
+    if (!d.X) {
+      if (e->slot == 0) mgx_launch_world_fast_s0(e->prog_in_lds, e->lds_world, e->stream, e->d, pw);
+      else mgx_launch_world_fast_s1(e->prog_in_lds, e->lds_world, e->stream, e->d, pw);
+      MGX_MARK(1); MGX_MARK(2); MGX_MARK(3);
+    } else if (e->aoe_local && (d.NF > 0 || d.NM > 0 || d.NT > 0)) {
+      mgx_launch_world_x(e->prog_in_lds, e->lds_world, e->stream, e->d, pw, MGX_PH_ACTIONS);
+      MGX_TRACE_POINT(e, "world kernel (actions)");
+      MGX_MARK(1);
+      int trc = launch_terr(e);  // the per-agent territory effects read the ownership map
+      if (trc) return trc;
+      mgx_launch_aoe(e->stream, e->d);
+      MGX_TRACE_POINT(e, "aoe kernel");
+      MGX_MARK(2);
+      mgx_launch_world_x(e->prog_in_lds, e->lds_world, e->stream, e->d, pw, MGX_PH_TAIL);
+      MGX_MARK(3);
     } else {
-      mgx_launch_world_fast(e->prog_in_lds, e->lds_world, e->stream, e->d, pw);
+      mgx_launch_world_x(e->prog_in_lds, e->lds_world, e->stream, e->d, pw, MGX_PH_ALL);
+      MGX_MARK(1); MGX_MARK(2); MGX_MARK(3);
     }
+    MGX_TRACE_POINT(e, "world kernel");
   }
   HIP_TRY(hipGetLastError());
-  if (e->profiling) HIP_TRY(hipEventRecord(e->ev[1], e->stream));
-  int rc = launch_obs(e, true);
+  int rc = launch_obs(e, true);   // (+ ownership map refresh and query-backed obs values in front of it)
   if (rc) return rc;
-  if (e->profiling) HIP_TRY(hipEventRecord(e->ev[2], e->stream));
+  MGX_TRACE_POINT(e, "obs kernel");
+  MGX_MARK(4);
+  if (e->rewards_ext) { mgx_launch_values(e->stream, e->d, 1, nullptr); HIP_TRY(hipGetLastError()); }
+  MGX_MARK(5);
+#undef MGX_MARK
   if (e->mem_kind == MGX_MEM_HOST) {
     HIP_TRY(hipMemcpyAsync(e->h_obs, d.obs, rows * d.T * 3, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipMemcpyAsync(e->h_term, d.terminals, rows, hipMemcpyDeviceToHost, e->stream));
@@ -752,9 +843,8 @@ int mgx_get_step_timing(mgx_engine* e, float* ms_out) {
   if (!e || !ms_out) return fail(MGX_ERR_BAD_ARG, "mgx_get_step_timing: null argument");
   if (!e->profiling) return fail(MGX_ERR_BAD_ARG, "mgx_get_step_timing: profiling is off");
   HIP_TRY(hipSetDevice(e->device));
-  HIP_TRY(hipEventSynchronize(e->ev[2]));
-  HIP_TRY(hipEventElapsedTime(&ms_out[0], e->ev[0], e->ev[1]));
-  HIP_TRY(hipEventElapsedTime(&ms_out[1], e->ev[1], e->ev[2]));
+  HIP_TRY(hipEventSynchronize(e->ev[MGX_T_COUNT]));
+  for (int k = 0; k < MGX_T_COUNT; k++) HIP_TRY(hipEventElapsedTime(&ms_out[k], e->ev[k], e->ev[k + 1]));
   return MGX_OK;
 }
 

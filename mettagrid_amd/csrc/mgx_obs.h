@@ -96,14 +96,14 @@ struct MgxBase {
 //   agents u32[A] (slot | rc << 16) | aginfo u32[A] | spawn u16[A] | vstat f32[A] | written i32[A] |
 //   rwinfo u32[A] (reward start | count << 16) | misc u32[4] | pool u16[POOL+8] | rows u32[WAVES*4][Tpad+16] |
 //   cell u16[A][CP], vj u8[A][CP], vcount u32[A]: per agent the occupied window cells in window order (slot + 1 and
-//   window index j of each), compacted | X extras |
+//   window index j of each), compacted | X: vmask u8[A][CP] territory token of each listed cell, obs values |
 //   blk i32[blk_words]: program sections INV_FEATURES..OBS_VALUES (PL variants only) | gtok u32[A][GT] global tokens
 // CP = NOFF rounded up to 16: stride of the per-agent lists.
 __host__ __device__ inline int mgx_align16(int x) { return (x + 15) & ~15; }
 struct MgxObsLds {
   int grid, offs, loc, minobs, visited, tokinfo, dyn, agents, aginfo, spawn, vstat, written, rwinfo, misc, pool, rows, row_words,
       row_pitch, cell, vj, vcount, cp, blk, gtok, total;
-  int owner, obsval, tscore;  // X only: per-cell territory owner u16[HW], obs values u32[A][NOV], scores i64[8][256]
+  int owner, obsval, tscore, vmask;  // X only: per-cell territory owner u16[HW] (overlaid), obs values u32[A][NOV], mask list
 };
 // Upper bound of the global (location 0xFE) tokens of one agent: completion, last action, last action move, last
 // reward, two local-position tokens and every digit of every obs value (a u32 has at most 32 digits in base 2).
@@ -118,20 +118,13 @@ __host__ __device__ inline MgxObsLds mgx_obs_lds_layout(int HW, int NOFF, int S,
   MgxObsLds l;
   int o = 0;
   l.cp = (NOFF + 15) & ~15;
-  // The grid, the window offsets, the list-builder queue and (when the rewards are evaluated early, blk_early) the
-  // program block are dead once the visible-cell lists and the global tokens exist (barrier before the encode phase);
-  // the staging rows are first written after it: in the lean variant the rows overlay them (the extended encode still
-  // reads the offsets for the territory mask).
-  const bool overlay = !X;
-  if (!overlay) {
-    l.grid = o; o += mgx_align16(HW * 2);
-    l.offs = o; o += mgx_align16(NOFF * 2);
-  }
+  // The grid, the window offsets, the list-builder queue, the territory owner map (X) and (when the rewards are
+  // evaluated early, blk_early) the program block are dead once the visible-cell lists and the global tokens exist
+  // (barrier before the encode phase); the staging rows are first written after it, so the rows overlay them.
   l.loc = o; o += mgx_align16(l.cp);
   l.minobs = o; o += mgx_align16((S + 1) * 4);
   l.visited = o; o += mgx_align16(S * 4);
   l.tokinfo = o; o += mgx_align16(S * 4);
-  if (!overlay) { l.dyn = o; o += mgx_align16(S * 2); }
   l.agents = o; o += mgx_align16(A * 4);
   l.aginfo = o; o += mgx_align16(A * 4);
   l.spawn = o; o += mgx_align16(A * 2);
@@ -143,30 +136,27 @@ __host__ __device__ inline MgxObsLds mgx_obs_lds_layout(int HW, int NOFF, int S,
   l.row_words = (T + 3) & ~3;
   l.row_pitch = l.row_words + 16;  // + one trash word per lane of a 16-lane row: masked-off stores land there
   l.rows = o;
+  l.owner = 0;
   {
     const int rows_bytes = MGX_OBS_WAVES * 4 * l.row_pitch * 4;  // one staging row per DPP row of every wavefront
-    if (overlay) {
-      int eo = o;
-      l.grid = eo; eo += mgx_align16(HW * 2);
-      l.offs = eo; eo += mgx_align16(NOFF * 2);
-      l.dyn = eo; eo += mgx_align16(S * 2);
-      if (blk_early) { l.blk = eo; eo += mgx_align16(blk_words * 4); }
-      const int early_bytes = eo - o;
-      o += rows_bytes > early_bytes ? rows_bytes : early_bytes;
-    } else {
-      o += rows_bytes;
-    }
+    int eo = o;
+    l.grid = eo; eo += mgx_align16(HW * 2);
+    l.offs = eo; eo += mgx_align16(NOFF * 2);
+    l.dyn = eo; eo += mgx_align16(S * 2);
+    if (X) { l.owner = eo; eo += mgx_align16(HW * 2); }
+    if (blk_early) { l.blk = eo; eo += mgx_align16(blk_words * 4); }
+    const int early_bytes = eo - o;
+    o += rows_bytes > early_bytes ? rows_bytes : early_bytes;
   }
   l.cell = o; o += mgx_align16(A * l.cp * 2);
   l.vj = o; o += mgx_align16(A * l.cp);
   l.vcount = o; o += mgx_align16(A * 4);
-  l.owner = l.obsval = l.tscore = 0;
+  l.vmask = l.obsval = l.tscore = 0;
   if (X) {
-    l.owner = o; o += mgx_align16(HW * 2);
+    l.vmask = o; o += mgx_align16(A * l.cp);   // per visible cell: 0 no territory token, 1 friendly, 2 foreign owner
     l.obsval = o; o += mgx_align16((A * NOV + 1) * 4);
-    l.tscore = o; o += 8 * MGX_OBS_THREADS * 8;
   }
-  if (!(overlay && blk_early)) { l.blk = o; o += mgx_align16(blk_words * 4); }
+  if (!blk_early) { l.blk = o; o += mgx_align16(blk_words * 4); }
   l.gtok = o; o += mgx_align16(A * GT * 4);
   l.total = o;
   return l;
@@ -188,6 +178,7 @@ __device__ __forceinline__ uint32_t mgx_wave_sum(uint32_t x) {
 template <bool WITH_REWARDS, bool X, bool PL>
 __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int pool_tokens, int pool_prefix, const uint8_t* env_mask,
                                                                   int blk_start, int blk_words, int rewards_early) {
+  MGX_KERNARG_ENTRY(d);
   extern __shared__ __align__(16) uint8_t smem[];
   const int env = blockIdx.x;
   if (env_mask && !env_mask[env]) return;  // episode restart: only the restarted envs get initial observations
@@ -225,15 +216,11 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
   Env e(d, d.P, env);
   e.step = d.step[env];
   const uint32_t step = e.step;
-  const int sid_visited = mgx_wk(d, MGX_S_CELL_VISITED);
+  const int sid_visited = d.wk[MGX_S_CELL_VISITED];
   uint16_t* s_owner = (uint16_t*)(smem + L.owner);
+  uint8_t* s_vmask = smem + L.vmask;
   uint32_t* s_obsval = (uint32_t*)(smem + L.obsval);
   const bool want_mask = X && d.aoe_mask_feat != 0 && d.NT > 0;
-  if (X) {
-    e.xl.terr_score = (long long*)(smem + L.tscore);
-    e.xl.lane = tid;
-    e.xl.stride = MGX_OBS_THREADS;
-  }
   // Program view of the interpreted sections: LDS copy (PL) or the blob itself.
   typedef typename std::conditional<PL, MgxLdsProg, MgxGlobalProg>::type VP;
   VP vp;
@@ -257,7 +244,7 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
       float* prev = &d.ag_rprev[e.ao(a) * d.NRW + k];
       const float pv = *prev;
       MgxCtx vc = mgx_ctx(slot, slot);
-      float val = ev.template eval_code<Env::TOPQ>(rw[MGX_RW_GV_START], rw[MGX_RW_GV_COUNT], slot, vc, 0);
+      float val = ev.template eval_code<0>(rw[MGX_RW_GV_START], rw[MGX_RW_GV_COUNT], slot, vc, 0);
       if (rw[MGX_RW_ACCUMULATE]) total = __fadd_rn(total, val);
       else total = __fadd_rn(total, __fsub_rn(val, pv));
       *prev = val;
@@ -281,8 +268,8 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
   float pre_tw = 0.f, pre_tf = 0.f;
   if (tid == 0) {
     const float* gs0 = d.game_stats + (size_t)env * d.NG;
-    pre_tw = gs0[mgx_wk(d, MGX_S_GAME_TOKENS_WRITTEN)];
-    pre_tf = gs0[mgx_wk(d, MGX_S_GAME_TOKENS_FREE)];
+    pre_tw = gs0[d.wk[MGX_S_GAME_TOKENS_WRITTEN]];
+    pre_tf = gs0[d.wk[MGX_S_GAME_TOKENS_FREE]];
   }
   if (tid < S) {
     pre_cls = d.obj_cls[e.so(tid)];
@@ -341,7 +328,7 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
     if (cls != MGX_DEAD_CLASS) {
       const uint32_t cinfo = pre ? pre_cinfo : d.cls_tokinfo[cls];  // start(16) | group(8) | ntags(6) | agent(1) | static(1)
       s_visited[s] = vis;
-      if ((cinfo >> 31) != 0 && !dyn_tags) {
+      if ((cinfo >> 31) != 0) {  // static class: nothing about it changes, tags included (MGX_C_STATIC, compiler.py)
         info = (cinfo & 0xFFFFu) | (((cinfo >> 24) & 0x3Fu) << 16);
       } else {
         const uint32_t k = atomicAdd(&s_misc[1], 1u);
@@ -390,7 +377,7 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
       }
       int ntags = (cinfo >> 24) & 0x3F;
       uint32_t tagw[MGX_TAG_WORDS];
-      if (dyn_tags) {
+      if (dyn_tags && !is_static) {
         ntags = 0;
 #pragma unroll
         for (int w = 0; w < MGX_TAG_WORDS; w++) { tagw[w] = d.obj_tags[o * MGX_TAG_WORDS + w]; ntags += __popc(tagw[w]); }
@@ -403,7 +390,7 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
       const uint32_t start = atomicAdd(&s_misc[0], (uint32_t)n);
       if ((int)(start + n) <= pool_tokens) {
         MgxObjTok w{s_pool, (int)start};
-        if (dyn_tags) {  // ascending tag id (core/grid_object.cpp:181-186)
+        if (dyn_tags && !is_static) {  // ascending tag id (core/grid_object.cpp:181-186)
 #pragma unroll
           for (int wd = 0; wd < MGX_TAG_WORDS; wd++) {
             uint32_t m = tagw[wd];
@@ -462,7 +449,7 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
             float* prev = &d.ag_rprev[e.ao(a) * NRW + k];
             const float pv = *prev;
             MgxCtx vc = mgx_ctx(slot, slot);
-            const float val = ev.template eval_code<Env::TOPQ>(rw[MGX_RW_GV_START], rw[MGX_RW_GV_COUNT], slot, vc, 0);
+            const float val = ev.template eval_code<0>(rw[MGX_RW_GV_START], rw[MGX_RW_GV_COUNT], slot, vc, 0);
             contrib = rw[MGX_RW_ACCUMULATE] ? val : __fsub_rn(val, pv);
             *prev = val;
           }
@@ -487,24 +474,17 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
     }
   }
   if constexpr (X) {
-    if (want_mask) {  // TerritoryTracker::compute_observability_at (:254-273): first territory with an owner decides
+    if (want_mask) {  // TerritoryTracker::compute_observability_at (:254-273): first territory with an owner decides.
+                      // The per-type ownership maps are current here: mgx_terr_kernel runs right before this kernel.
       for (int cellidx = tid; cellidx < HW; cellidx += MGX_OBS_THREADS) {
-        int owner = -1;
-        for (int ti = 0; ti < d.NT && owner < 0; ti++) owner = e.cell_owner(cellidx / d.W, cellidx % d.W, ti);
-        s_owner[cellidx] = owner < 0 ? 0xFFFF : (uint16_t)owner;
+        uint16_t owner = 0xFFFF;
+        for (int ti = 0; ti < d.NT && owner == 0xFFFF; ti++) owner = d.terr_owner[((size_t)env * d.NT + ti) * (size_t)HW + cellidx];
+        s_owner[cellidx] = owner;
       }
     }
-    if (tid == 0) {  // query-backed obs values share the env's query workspace -> evaluated serially here
-      for (int a = 0; a < A; a++)
-        for (int i = 0; i < d.n_obs_values; i++) {
-          const int32_t* V = d.P + d.sec[MGX_SEC_OBS_VALUES] + i * MGX_OV_WORDS;
-          int slot = s_agents[a] & 0xFFFF;
-          MgxCtx vc = mgx_ctx(slot, slot);
-          s_obsval[a * d.n_obs_values + i] =
-              (uint32_t)e.template eval_code<Env::TOPQ>(V[MGX_OV_GV_START], V[MGX_OV_GV_COUNT], slot, vc, 0);
-        }
-    }
-    if (d.n_obs_values > 0) __syncthreads();  // obs values are read by the global-token threads below
+    if (d.obsval)  // query-backed obs values: evaluated by mgx_values_kernel (one env per lane) right before this kernel
+      for (int i = tid; i < A * d.n_obs_values; i += MGX_OBS_THREADS) s_obsval[i] = d.obsval[(size_t)env * A * d.n_obs_values + i];
+    if (want_mask || (d.obsval && d.n_obs_values > 0)) __syncthreads();  // read by other threads below
   }
 
   // ---- phase 1: per agent the list of window cells that will emit tokens, in window order (ballot compaction), and
@@ -577,8 +557,12 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
         const bool inb = j < NOFF && (unsigned)r < (unsigned)d.H && (unsigned)c < (unsigned)d.W;
         const uint32_t cs = inb ? (uint32_t)s_grid[inb ? __mul24(r, d.W) + c : 0] : 0u;  // map <= 255 x 255
         bool keep = cs != 0;
+        uint32_t mv = 0;  // _emit_tile_observability_tokens (:337-362): 1 = the cell's owner tag is one of mine, 2 = not
         if constexpr (X) {
-          if (want_mask && inb) keep = keep || s_owner[r * d.W + c] != 0xFFFF;  // mask-only cells still emit one token
+          if (want_mask && inb) {
+            const uint16_t ow = s_owner[r * d.W + c];
+            if (ow != 0xFFFF) { mv = e.has_tag((int)(ag & 0xFFFF), ow) ? 1u : 2u; keep = true; }  // mask-only cells still emit one token
+          }
         }
         if (step > 0 && cs) atomicMin(&s_minobs[cs - 1], (uint32_t)a);
         const unsigned long long m = __ballot(keep);
@@ -586,6 +570,7 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
           const int k = count + __popcll(m & ((1ull << lane) - 1ull));
           s_cell[a * CP + k] = (uint16_t)cs;
           s_vj[a * CP + k] = (uint8_t)j;
+          if constexpr (X) s_vmask[a * CP + k] = (uint8_t)mv;
         }
         count += __popcll(m);
       }
@@ -624,7 +609,9 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
     for (int i = 0; i < d.n_obs_values; i++) {  // _emit_obs_value_tokens :1207-1238
       VP V = vp + d.sec[MGX_SEC_OBS_VALUES] + i * MGX_OV_WORDS;
       uint32_t rem;
-      if constexpr (X) {
+      bool ext = false;
+      if constexpr (X) ext = d.obsval != nullptr;
+      if (ext) {
         rem = s_obsval[a * d.n_obs_values + i];
       } else {
         MgxCtx vc = mgx_ctx(my_slot, my_slot);
@@ -680,11 +667,9 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
         stale = (has && mo == (uint32_t)a && pv < step) ? step - pv : 0u;
       }
       if constexpr (X) {
-        if (want_mask && valid) {  // _emit_tile_observability_tokens (:337-362): before the cell's object tokens
-          const char2 o = s_offs[j];
-          const int r = (int)((ag >> 24) & 0xFF) + o.x, c = (int)((ag >> 16) & 0xFF) + o.y;
-          const uint16_t ow = s_owner[r * d.W + c];
-          if (ow != 0xFFFF) { mask = e.has_tag(my_slot, ow) ? 1u : 2u; n += 1; }
+        if (want_mask) {  // the territory token comes before the cell's object tokens (:337-362); decided in phase 1
+          mask = valid ? (uint32_t)s_vmask[ac * CP + kk] : 0u;
+          if (mask) n += 1;
         }
       }
       const int incl = mgx_row_incl_scan(n);
@@ -796,16 +781,16 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
           tf = __fadd_rn(tf, (float)(T - n));
         }
       }
-      gs[mgx_wk(d, MGX_S_GAME_TOKENS_WRITTEN)] = tw;
-      gs[mgx_wk(d, MGX_S_GAME_TOKENS_FREE)] = tf;
+      gs[d.wk[MGX_S_GAME_TOKENS_WRITTEN]] = tw;
+      gs[d.wk[MGX_S_GAME_TOKENS_FREE]] = tf;
       if (overflow) d.err[env] |= 1u;
     }
   }
   MGX_TICK(13);
   if (WITH_REWARDS && !rewards_early) {
-    if constexpr (X) __syncthreads();  // cell.visited stats of all waves are in before value expressions read them
-    // X: query-backed values share one workspace per env -> one thread walks the agents in order
-    for (int a = X ? (tid == 0 ? 0 : A) : tid; a < A; a += X ? 1 : MGX_OBS_THREADS) agent_rewards(a);
+    // (reward expressions with query operands never reach this kernel: mgx_values_kernel evaluates them, one env per
+    // lane, after it — the host launches this kernel without rewards then)
+    for (int a = tid; a < A; a += MGX_OBS_THREADS) agent_rewards(a);
   }
   MGX_TICK(14);
 }

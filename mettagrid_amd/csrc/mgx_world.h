@@ -19,6 +19,15 @@
 
 #include "mgx_device.h"
 
+// Each translation unit instantiates these templates under its own set of build switches (MGX_WORLD_IDS,
+// MGX_BIG, MGX_OUTLINE ...): on the GPU every unit is its own code object, but the single host binary of the
+// sanitizer build (tests/cpu_emu) would merge the differing inline definitions.  One namespace per unit keeps them apart.
+#ifndef MGX_TU_NS
+#define MGX_TU_NS mgx_tu_engine
+#endif
+extern __shared__ __align__(16) uint8_t mgx_dyn_lds[];  // dynamic LDS of the world kernels
+namespace MGX_TU_NS {
+
 struct MgxCtx {  // handler/handler_context.hpp:38-112 (the fields the supported filters/mutations read)
   int actor, target, source;  // object slots, MGX_SLOT_NONE (-1) or MGX_SLOT_PROXY (-2)
   int proxy_tag;              // tag carried by the territory proxy cell
@@ -85,30 +94,45 @@ MGX_DBG_LINKAGE __device__ unsigned long long mgx_dbg_cycles[16];
 #ifndef MGX_WORLD_LPW
 #define MGX_WORLD_LPW 64
 #endif
-#define MGX_WORLD_THREADS (MGX_WAVE * (MGX_WAVE / MGX_WORLD_LPW))
+// MGX_WORLD_EPG: envs per workgroup = stride of the [k][env] LDS arrays.  The LDS a workgroup needs grows with the
+// agents per env (17 B per agent and env, + 320 B per env in the extended variant); fewer envs per workgroup let more
+// workgroups share a CU's 160 KB when there are many agents.
+#ifndef MGX_WORLD_EPG
+#define MGX_WORLD_EPG 64
+#endif
+#define MGX_WORLD_THREADS (MGX_WAVE * (MGX_WORLD_EPG / MGX_WORLD_LPW))
 __device__ __forceinline__ int mgx_world_lane() {  // index of this lane's env inside the workgroup's 64-env group
   return (int)((threadIdx.x >> 6) * MGX_WORLD_LPW + (threadIdx.x & (MGX_WAVE - 1)));
 }
 
-__host__ __device__ inline int mgx_world_alds_bytes(int A) { return A * MGX_WAVE * (2 + 2 + 2 + 2 + 4 + 4); }
+// Extended handler VM: frames and handler contexts per lane (see MgxEnvT::vm_run).
+#define MGX_VM_FRAMES 6
+#define MGX_VM_CTXS 6
+#define MGX_VM_WORDS (MGX_VM_FRAMES * 4 + MGX_VM_CTXS * 2)
+// MGX_OUTLINE: the few large functions of the extended variant that stay real calls (one instance each, no recursion).
+#ifndef MGX_OUTLINE
+#define MGX_OUTLINE
+#endif
+__host__ __device__ inline int mgx_world_alds_bytes(int A) { return A * MGX_WORLD_EPG * (2 + 2 + 2 + 2 + 4 + 4); }
+// byte offset of the extended variant's per-lane scratch (deferred deltas | territory scores | VM words) in the LDS
+__host__ __device__ inline int mgx_world_xlds_off(int A) { return ((A * MGX_WORLD_EPG + 15) & ~15) + ((mgx_world_alds_bytes(A) + 15) & ~15); }
 // Dynamic LDS of the world kernels: order u8[A][64] | swm u32[A][64] | act i16[2][A][64] | slot, rc, prev, cls u16[A][64] |
-// [X: deferred i32[28][64] | territory i64[8][64]] | program i32[prog_words] (when it fits).
+// [X: deferred i32[28][64] | territory i64[8][64] | VM u32[MGX_VM_WORDS][64]] | program i32[prog_words] (when it fits).
 __host__ __device__ inline int mgx_world_lds_fixed(int A, bool X) {
-  int o = ((A * MGX_WAVE + 15) & ~15) + ((mgx_world_alds_bytes(A) + 15) & ~15);
-  if (X) o += 28 * MGX_WAVE * 4 + 8 * MGX_WAVE * 8;
+  int o = ((A * MGX_WORLD_EPG + 15) & ~15) + ((mgx_world_alds_bytes(A) + 15) & ~15);
+  if (X) o += 28 * MGX_WORLD_EPG * 4 + 8 * MGX_WORLD_EPG * 8 + MGX_VM_WORDS * MGX_WORLD_EPG * 4;
   return o;
 }
-extern __shared__ __align__(16) uint8_t mgx_dyn_lds[];
 __device__ __forceinline__ MgxALds mgx_world_alds(uint8_t* lds, int A, int lane) {
-  const int off = (A * MGX_WAVE + 15) & ~15;
+  const int off = (A * MGX_WORLD_EPG + 15) & ~15;
   MgxALds al;
   al.lane = lane; al.A = A;
   al.swm = (uint32_t*)(lds + off);
-  al.act = (int16_t*)(lds + off + A * MGX_WAVE * 4);
-  al.slot = (uint16_t*)(lds + off + A * MGX_WAVE * 8);
-  al.rc = al.slot + A * MGX_WAVE;
-  al.prev = al.rc + A * MGX_WAVE;
-  al.cls = al.prev + A * MGX_WAVE;
+  al.act = (int16_t*)(lds + off + A * MGX_WORLD_EPG * 4);
+  al.slot = (uint16_t*)(lds + off + A * MGX_WORLD_EPG * 8);
+  al.rc = al.slot + A * MGX_WORLD_EPG;
+  al.prev = al.rc + A * MGX_WORLD_EPG;
+  al.cls = al.prev + A * MGX_WORLD_EPG;
   return al;
 }
 
@@ -133,7 +157,7 @@ struct MgxEnvT {  // per-lane view of one env
 #ifdef MGX_CONST_DEV
   static constexpr const MgxDev& d = g_mgx_dev;
 #else
-  const MgxDev& d;
+  const MgxDev& d;  // the launching kernel's own by-value argument
 #endif
   PP P_;
   int env_;
@@ -154,13 +178,21 @@ struct MgxEnvT {  // per-lane view of one env
   // live in the kernel's stack frame, and an out-of-line handler function has to re-load them through `this` after
   // every store that might alias it.
 #ifdef MGX_WORLD_IDS
-  __device__ __forceinline__ int envi() const { return (int)(blockIdx.x * MGX_WAVE) + mgx_world_lane(); }
+  __device__ __forceinline__ int envi() const { return (int)(blockIdx.x * MGX_WORLD_EPG) + mgx_world_lane(); }
   __device__ __forceinline__ PP prog() const {
     if constexpr (std::is_same<PP, MgxLdsProg>::value) return (MgxLdsProg)(int32_t*)(mgx_dyn_lds + mgx_world_lds_fixed(d.A, X));
     else return d.P;
   }
   __device__ __forceinline__ MgxALds AL() const { return mgx_world_alds(mgx_dyn_lds, d.A, mgx_world_lane()); }
+  __device__ __forceinline__ MgxXLds XL() const {  // per-lane scratch of the extended variant
+    MgxXLds x;
+    x.def_delta = (int*)(mgx_dyn_lds + mgx_world_xlds_off(d.A));
+    x.terr_score = (long long*)(mgx_dyn_lds + mgx_world_xlds_off(d.A) + 28 * MGX_WORLD_EPG * 4);
+    x.lane = mgx_world_lane(); x.stride = MGX_WORLD_EPG;
+    return x;
+  }
 #else
+  __device__ __forceinline__ const MgxXLds& XL() const { return xl; }
   __device__ __forceinline__ int envi() const { return env_; }
   __device__ __forceinline__ PP prog() const { return P_; }
   __device__ __forceinline__ const MgxALds& AL() const { return al_; }
@@ -265,10 +297,10 @@ struct MgxEnvT {  // per-lane view of one env
   __device__ MGX_BIG void on_inventory_change(int a, int item, int delta, int amount) const {
     if (a < 0 || delta == 0) return;
     const size_t sb = ao(a) * d.NSP;
-    const int s_flow = (delta > 0 ? mgx_wk(d, MGX_S_RES_GAINED_BASE) : mgx_wk(d, MGX_S_RES_LOST_BASE)) + item;
-    const int s_amt = mgx_wk(d, MGX_S_RES_AMOUNT_BASE) + item;
+    const int s_flow = (delta > 0 ? d.wk[MGX_S_RES_GAINED_BASE] : d.wk[MGX_S_RES_LOST_BASE]) + item;
+    const int s_amt = d.wk[MGX_S_RES_AMOUNT_BASE] + item;
     const bool died = amount == 0 && delta < 0 && item == d.hp_res;
-    const int s_death = mgx_wk(d, MGX_S_DEATH);
+    const int s_death = d.wk[MGX_S_DEATH];
     const float flow = d.ag_stats[sb + s_flow];
     uint32_t* tw = &d.ag_touched[ao(a) * d.NSW + (s_amt >> 5)];
     const uint32_t tword = *tw;
@@ -377,33 +409,18 @@ struct MgxEnvT {  // per-lane view of one env
   __device__ __forceinline__ int tag_list(int tag) const { return prog()[d.sec[MGX_SEC_TAG_LISTS] + tag]; }
   __device__ __forceinline__ uint16_t* tl_items(int li) const { return d.tl_items + ((size_t)envi() * d.NL + li) * d.S; }
   __device__ __forceinline__ uint16_t& tl_count(int li) const { return d.tl_count[(size_t)envi() * d.NL + li]; }
-  template <int DEPTH>
-  __device__ void fire_tag_handlers(int o, int tag, int start_field, const MgxCtx& c) const {  // grid_object.cpp:83-123
-    PP C = cls_of(o);
-    PP th = prog() + d.sec[MGX_SEC_TAG_HANDLERS] + C[start_field] * MGX_TH_WORDS;
-    for (int i = 0; i < C[start_field + 1]; i++, th += MGX_TH_WORDS) {
-      if (th[MGX_TH_TAG] != tag) continue;
-      if constexpr (DEPTH > 0) {
-        MgxCtx h = c;
-        h.actor = h.target = o;
-        h.skip_trigger = false;
-        apply_handler<DEPTH - 1>(th[MGX_TH_HANDLER], h);
-      } else {
-        flag(4u);
-      }
-    }
-  }
-  template <int DEPTH>
-  __device__ void add_tag(int o, int tag, const MgxCtx& c) const {
-    if (o < 0 || tag < 0 || tag >= 256 || !d.obj_tags || has_tag(o, tag)) return;
+  // GridObject::add_tag / remove_tag without the lifecycle handlers (core/grid_object.cpp:93-123): bitset + TagIndex.
+  // Returns true when the tag set changed; the handler VM (vm_run) then fires on_tag_add / on_tag_remove.
+  __device__ __forceinline__ bool tag_set(int o, int tag) const {
+    if (o < 0 || tag < 0 || tag >= 256 || !d.obj_tags || has_tag(o, tag)) return false;
     d.obj_tags[so(o) * MGX_TAG_WORDS + (tag >> 5)] |= 1u << (tag & 31);
     int li = tag_list(tag);
     if (li >= 0) { uint16_t n = tl_count(li); if (n < d.S) { tl_items(li)[n] = (uint16_t)o; tl_count(li) = n + 1; } }
-    if (!c.skip_trigger) fire_tag_handlers<DEPTH>(o, tag, MGX_C_TAG_ADD_START, c);
+    territory_tags_changed(o);
+    return true;
   }
-  template <int DEPTH>
-  __device__ void remove_tag(int o, int tag, const MgxCtx& c) const {
-    if (o < 0 || tag < 0 || tag >= 256 || !d.obj_tags || !has_tag(o, tag)) return;
+  __device__ __forceinline__ bool tag_clear(int o, int tag) const {
+    if (o < 0 || tag < 0 || tag >= 256 || !d.obj_tags || !has_tag(o, tag)) return false;
     d.obj_tags[so(o) * MGX_TAG_WORDS + (tag >> 5)] &= ~(1u << (tag & 31));
     int li = tag_list(tag);
     if (li >= 0) {  // stable erase (core/tag_index.cpp:37-43)
@@ -412,7 +429,17 @@ struct MgxEnvT {  // per-lane view of one env
       for (int i = 0; i < n; i++) { uint16_t v = it[i]; if (v != (uint16_t)o) it[k++] = v; }
       tl_count(li) = (uint16_t)k;
     }
-    if (!c.skip_trigger) fire_tag_handlers<DEPTH>(o, tag, MGX_C_TAG_REMOVE_START, c);
+    territory_tags_changed(o);
+    return true;
+  }
+  // first on_tag_add / on_tag_remove record of object o's class for `tag` at or after record j, or -1
+  __device__ __forceinline__ int next_tag_handler(int o, int tag, int start_field, int j, int* handler) const {
+    PP C = cls_of(o);
+    PP th = prog() + d.sec[MGX_SEC_TAG_HANDLERS] + C[start_field] * MGX_TH_WORDS;
+    const int n = C[start_field + 1];
+    for (; j < n; j++)
+      if (th[j * MGX_TH_WORDS + MGX_TH_TAG] == tag) { *handler = th[j * MGX_TH_WORDS + MGX_TH_HANDLER]; return j; }
+    return -1;
   }
 
   // ---- query workspace ----
@@ -446,7 +473,7 @@ struct MgxEnvT {  // per-lane view of one env
     return (mx >= 0 && n > mx) ? mx : n;
   }
   template <int QD>
-  __device__ int eval_query(int qi, const MgxCtx& c, int depth) const {
+  __device__ MGX_OUTLINE int eval_query(int qi, const MgxCtx& c, int depth) const {
     if constexpr (!X || QD == 0) {
       flag(4u);
       return 0;
@@ -541,7 +568,7 @@ struct MgxEnvT {  // per-lane view of one env
 
   // ---- game values (cpp/src/mettagrid/core/game_value.cpp:14-148): postfix code on a small f32 stack ----
   template <int QD>
-  __device__ float eval_code(int start, int count, int entity, const MgxCtx& outer, int depth) const {
+  __device__ MGX_OUTLINE float eval_code(int start, int count, int entity, const MgxCtx& outer, int depth) const {
     MgxValueStack st;  // registers, not a dynamically indexed array (which the compiler would place in scratch)
     PP code = prog() + d.sec[MGX_SEC_GV_CODE] + start * MGX_GV_WORDS;
     for (int i = 0; i < count; i++, code += MGX_GV_WORDS) {
@@ -682,7 +709,7 @@ struct MgxEnvT {  // per-lane view of one env
     }
   }
   template <int QD>
-  __device__ MGX_BIG bool check_filters(int pc, const MgxCtx& c, int depth) const {  // handler/handler.cpp:95-103
+  __device__ MGX_OUTLINE bool check_filters(int pc, const MgxCtx& c, int depth) const {  // handler/handler.cpp:95-103
     PP atoms = prog() + d.sec[MGX_SEC_ATOMS];
     while (pc >= 0) {
       PP a = atoms + pc * MGX_AT_WORDS;
@@ -705,6 +732,7 @@ struct MgxEnvT {  // per-lane view of one env
       int mine = 0;
       for (int i = 0; i < n; i++) mine += to[i] == (uint16_t)slot;
       if (!mine) return;
+      d.terr_dirty[envi()] = 1;  // the cached ownership map (mgx_terr_kernel) is stale
       uint16_t rc = d.obj_rc[so(slot)];
       for (int pass = 0; pass < mine; pass++) {
         int i = 0;
@@ -715,20 +743,25 @@ struct MgxEnvT {  // per-lane view of one env
       }
     }
   }
+  __device__ __forceinline__ void territory_tags_changed(int o) const {  // ownership depends on the sources' tags (:223-229)
+    if constexpr (X) {
+      if (d.NTS > 0 && cls_of(o)[MGX_C_TERR_COUNT] > 0) d.terr_dirty[envi()] = 1;
+    }
+  }
   // Grid::move_object.  known_empty: the caller saw (r, c) empty and no grid cell has been written since (the acting
   // agent stepping into the cell its own line scan just read) — the target is then not read again.
   __device__ MGX_BIG bool move_object(int slot, int r, int c, bool known_empty = false) const {
     if (r < 0 || c < 0 || r >= d.H || c >= d.W) return false;
     if (!known_empty && cell(r, c) != 0) return false;
     const bool own = slot == cur_slot && AL().rc != nullptr;
-    const uint16_t rc = own ? AL().rc[cur_agent * MGX_WAVE + AL().lane] : d.obj_rc[so(slot)];
+    const uint16_t rc = own ? AL().rc[cur_agent * MGX_WORLD_EPG + AL().lane] : d.obj_rc[so(slot)];
     cell(r, c) = (uint16_t)(slot + 1);
     cell(rc >> 8, rc & 0xFF) = 0;
     grid_dirty = 1;
     d.obj_rc[so(slot)] = (uint16_t)((r << 8) | c);
     if (AL().rc) {
-      if (own) AL().rc[cur_agent * MGX_WAVE + AL().lane] = (uint16_t)((r << 8) | c);
-      else { int a = agent_of(slot); if (a >= 0) AL().rc[a * MGX_WAVE + AL().lane] = (uint16_t)((r << 8) | c); }
+      if (own) AL().rc[cur_agent * MGX_WORLD_EPG + AL().lane] = (uint16_t)((r << 8) | c);
+      else { int a = agent_of(slot); if (a >= 0) AL().rc[a * MGX_WORLD_EPG + AL().lane] = (uint16_t)((r << 8) | c); }
     }
     territory_moved(slot);
     return true;
@@ -826,17 +859,18 @@ struct MgxEnvT {  // per-lane view of one env
   }
 
   // ---- mutations (handler/mutations/*.hpp) ----
-  template <int DEPTH>
+  // Every mutation except the ones that apply a handler (UseTarget, tag changes with lifecycle handlers, materialized
+  // query recomputation): those are steps of the handler VMs (run_handler / vm_run), which own all nesting.
   __device__ MGX_BIG void mutate(PP m, MgxCtx& c) const {
     int a0 = m[MGX_MU_A0], a1 = m[MGX_MU_A1], a2 = m[MGX_MU_A2], a3 = m[MGX_MU_A3];
     switch (m[MGX_MU_OP]) {
       case MGX_MOP_RESOURCE_DELTA: {  // resource_mutation.hpp:25-47
         if constexpr (X) {
           if (c.deferred && a0 == MGX_ENT_TARGET && c.target >= 0 && !(cls_of(c.target)[MGX_C_MODIFIER_MASK] & (1 << a1))) {
-            int* dd = xl.def_delta + a1 * xl.stride + xl.lane;
-            int* meta = xl.def_delta + 13 * xl.stride + xl.lane;       // seen mask
-            int* cnt = xl.def_delta + 14 * xl.stride + xl.lane;        // number of first-seen entries
-            if (!((*meta >> a1) & 1)) { *meta |= 1 << a1; xl.def_delta[(15 + *cnt) * xl.stride + xl.lane] = a1; *cnt += 1; *dd = 0; }
+            int* dd = XL().def_delta + a1 * XL().stride + XL().lane;
+            int* meta = XL().def_delta + 13 * XL().stride + XL().lane;       // seen mask
+            int* cnt = XL().def_delta + 14 * XL().stride + XL().lane;        // number of first-seen entries
+            if (!((*meta >> a1) & 1)) { *meta |= 1 << a1; XL().def_delta[(15 + *cnt) * XL().stride + XL().lane] = a1; *cnt += 1; *dd = 0; }
             *dd += a2;
             break;
           }
@@ -852,7 +886,7 @@ struct MgxEnvT {  // per-lane view of one env
         int amount = a3 < 0 ? (int)inv(s, a2) : a3;
         int moved = transfer(s, t, a2, amount);
         int sa = agent_of(s);
-        if (moved > 0 && sa >= 0) astat_add(sa, mgx_wk(d, MGX_S_RES_DEPOSITED_BASE) + a2, (float)moved);
+        if (moved > 0 && sa >= 0) astat_add(sa, d.wk[MGX_S_RES_DEPOSITED_BASE] + a2, (float)moved);
         if constexpr (X) {
           if (m[MGX_MU_A4] && (d.obj_order[so(s)] & 0xF) == 0xF) remove_object(s);  // resource_mutation.hpp:88-97
         }
@@ -901,44 +935,21 @@ struct MgxEnvT {  // per-lane view of one env
         cell(ry >> 8, ry & 0xFF) = (uint16_t)(c.actor + 1); grid_dirty = 1;
         d.obj_rc[so(c.actor)] = ry;
         d.obj_rc[so(c.target)] = rx;
-        if (AL().rc) { AL().rc[xa * MGX_WAVE + AL().lane] = ry; AL().rc[ya * MGX_WAVE + AL().lane] = rx; }
+        if (AL().rc) { AL().rc[xa * MGX_WORLD_EPG + AL().lane] = ry; AL().rc[ya * MGX_WORLD_EPG + AL().lane] = rx; }
         territory_moved(c.actor);  // on_object_moved twice (core/grid.hpp:100-103)
         territory_moved(c.target);
-        astat_add(xa, mgx_wk(d, MGX_S_SWAP), 1.f);
-        break;
-      }
-      case MGX_MOP_USE_TARGET: {  // use_target_mutation.hpp:17-29, core/grid_object.cpp:72-80
-        if (c.target < 0 || agent_of(c.actor) < 0) { c.mutation_failed = true; break; }
-        int h = cls_of(c.target)[MGX_C_ON_USE];
-        bool ok = false;
-        if constexpr (DEPTH > 0) {
-          if (h >= 0) { MgxCtx use = c; ok = apply_handler<DEPTH - 1>(h, use); }
-        } else {
-          flag(4u);
-        }
-        if (!ok) { c.mutation_failed = true; break; }
-        int after = cls_of(c.actor)[MGX_C_ON_AFTER_USE];
-        if constexpr (DEPTH > 0) { if (after >= 0) apply_handler<DEPTH - 1>(after, c); }
+        astat_add(xa, d.wk[MGX_S_SWAP], 1.f);
         break;
       }
       default:
-        if constexpr (X) mutate_ext<DEPTH>(m, c);
+        if constexpr (X) mutate_ext(m, c);
         else flag(4u);
         break;
     }
   }
-  template <int DEPTH>
-  __device__ void mutate_ext(PP m, MgxCtx& c) const {
+  __device__ MGX_BIG void mutate_ext(PP m, MgxCtx& c) const {
     int a0 = m[MGX_MU_A0], a1 = m[MGX_MU_A1], a2 = m[MGX_MU_A2], a3 = m[MGX_MU_A3];
     switch (m[MGX_MU_OP]) {
-      case MGX_MOP_ADD_TAG: add_tag<DEPTH>(resolve(c, a0), a1, c); break;        // tag_mutation.hpp:16-30
-      case MGX_MOP_REMOVE_TAG: remove_tag<DEPTH>(resolve(c, a0), a1, c); break;  // :32-45
-      case MGX_MOP_REMOVE_TAGS_PREFIX: {                                         // :47-67
-        int e = resolve(c, a0);
-        PP ids = prog() + d.sec[MGX_SEC_WORDLIST] + a1;
-        for (int i = 0; i < a2; i++) remove_tag<DEPTH>(e, ids[i], c);
-        break;
-      }
       case MGX_MOP_GAME_VALUE: {  // game_value_mutation.hpp:21-27 (a0 target entity, a1 value, a2 source)
         int e = resolve(c, a0);
         float delta = eval_value<TOPQ>(a2, e, c, 0);
@@ -952,7 +963,6 @@ struct MgxEnvT {  // per-lane view of one env
         }
         break;
       }
-      case MGX_MOP_RECOMPUTE_QUERY: recompute_query<DEPTH>(a0, c); break;
       case MGX_MOP_PUSH_OBJECT: {  // push_object_mutation.hpp:33-67
         if (c.actor < 0 || c.target < 0) { c.mutation_failed = true; break; }
         uint16_t arc = d.obj_rc[so(c.actor)], trc = d.obj_rc[so(c.target)];
@@ -1019,74 +1029,11 @@ struct MgxEnvT {  // per-lane view of one env
       default: flag(4u); break;
     }
   }
-  template <int DEPTH>
-  __device__ void recompute_query(int tag, const MgxCtx& c) const {  // query_system.cpp:119-175
-    MgxCtx t = c;
-    t.skip_trigger = true;
-    uint16_t* lost = qbuf(QB_LOST);
-    uint16_t* keep = qbuf(QB_KEEP);
-    int nl = 0, nk = 0;
-    PP mq = prog() + d.sec[MGX_SEC_MATQ];
-    for (int i = 0; i < d.n_matq; i++, mq += MGX_MQ_WORDS) {
-      if (mq[MGX_MQ_TAG] != tag) continue;
-      int li = tag_list(tag);
-      if (li >= 0) { nl = tl_count(li); const uint16_t* it = tl_items(li); for (int k = 0; k < nl; k++) lost[k] = it[k]; }
-      for (int k = 0; k < nl; k++) { t.actor = t.target = lost[k]; remove_tag<DEPTH>(lost[k], tag, t); }
-      int n = eval_query<TOPQ>(mq[MGX_MQ_QUERY], c, 0);
-      const uint16_t* res = qbuf(QB_BASE);
-      for (int k = 0; k < n; k++) {
-        int o = res[k];
-        bool dup = false;
-        for (int q = 0; q < nk; q++) dup |= keep[q] == (uint16_t)o;
-        if (!dup) keep[nk++] = (uint16_t)o;
-        t.actor = t.target = o;
-        add_tag<DEPTH>(o, tag, t);
-      }
-      break;
-    }
-    t.skip_trigger = false;
-    for (int k = 0; k < nl; k++) {
-      bool kept = false;
-      for (int q = 0; q < nk; q++) kept |= keep[q] == lost[k];
-      if (!kept) { t.actor = t.target = lost[k]; fire_tag_handlers<DEPTH>(lost[k], tag, MGX_C_TAG_REMOVE_START, t); }
-    }
-    for (int q = 0; q < nk; q++) {
-      bool had = false;
-      for (int k = 0; k < nl; k++) had |= lost[k] == keep[q];
-      if (!had) { t.actor = t.target = keep[q]; fire_tag_handlers<DEPTH>(keep[q], tag, MGX_C_TAG_ADD_START, t); }
-    }
-  }
-
-  // Handler::try_apply (handler/handler.cpp:76-93) and MultiHandler::try_apply (multi_handler.cpp:8-21).
-  // DEPTH bounds nesting (multi -> leaf -> use_target -> on_use multi -> leaf); exceeded depth raises MGX_ENV_DEPTH.
-  template <int DEPTH>
-  __device__ MGX_BIG bool apply_handler(int h, MgxCtx& c) const {
-    PP hd = prog() + d.sec[MGX_SEC_HANDLERS] + h * MGX_HD_WORDS;
-    if (hd[MGX_HD_KIND] == MGX_HK_LEAF) {
-      if (!check_filters<TOPQ>(hd[MGX_HD_FILTER_PC], c, 0)) return false;
-      c.mutation_failed = false;
-      PP m = prog() + d.sec[MGX_SEC_MUTS] + hd[MGX_HD_MUT_START] * MGX_MU_WORDS;
-      for (int i = 0; i < hd[MGX_HD_MUT_COUNT]; i++, m += MGX_MU_WORDS) {
-        mutate<DEPTH>(m, c);
-        if (c.mutation_failed) return false;
-      }
-      return true;
-    }
-    bool any = false;
-    if constexpr (DEPTH > 0) {
-      PP kids = prog() + d.sec[MGX_SEC_CHILDREN] + hd[MGX_HD_CHILD_START];
-      bool first = hd[MGX_HD_KIND] == MGX_HK_FIRST_MATCH;
-      for (int i = 0; i < hd[MGX_HD_CHILD_COUNT]; i++) {
-        if (apply_handler<DEPTH - 1>(kids[i], c)) {
-          any = true;
-          if (first) return true;
-        }
-      }
-    } else {
-      flag(4u);
-    }
-    return any;
-  }
+  // Handler::try_apply (handler/handler.cpp:76-93) and MultiHandler::try_apply (multi_handler.cpp:8-21) are executed
+  // by two iterative VMs — no recursion anywhere in the handler path:
+  //   run_handler (lean variant): frames in registers, the only nesting is multi-handler children and UseTarget;
+  //   vm_run (extended variant): frames and handler contexts in LDS, also tag lifecycle handlers and the phases of a
+  //   materialized-query recomputation.
   // Iterative form of apply_handler<3> for the lean variant (no tag handlers, no queries: the only nested handler
   // applications are a multi-handler's children and UseTarget's on_use / on_after_use).  An explicit stack of at most
   // four frames (the template depth of the recursive form) lives in registers; there is ONE copy of the filter and
@@ -1166,7 +1113,7 @@ struct MgxEnvT {  // per-lane view of one env
             else { stage = ST_USE_RET; push_h = h2; push_cs = cs + 1; }
           } else {
             c.mutation_failed = false;
-            mutate<0>(m, c);
+            mutate(m, c);
             if (c.mutation_failed) failed |= 1u << cs;
           }
         }
@@ -1183,19 +1130,221 @@ struct MgxEnvT {  // per-lane view of one env
     c.mutation_failed = (failed & 1u) != 0;
     return rv;
   }
-  // apply a top-level handler: iterative VM in the lean variant, recursive templates in the extended one
+  // ---- extended handler VM ----
+  // One loop, one copy of the filter and mutation interpreters, an explicit stack of MGX_VM_FRAMES frames and
+  // MGX_VM_CTXS handler contexts per lane in LDS ([word][lane], bank-conflict free).  A frame is four words:
+  //   [0] handler index, -1 = the "raw" top-level record (filters + mutation list of an event / AoE / territory handler)
+  //   [1] i (16) | stage (4) << 16 | any << 20 | nostop << 21 | owns its ctx slot << 22 | ctx slot (4) << 24
+  //   [2] sub-state of the mutation in progress (0 = not started)     [3] aux (list lengths of a query recomputation)
+  // What the recursive form did by calling itself is a push here: multi-handler children and on_after_use run on
+  // their parent's context slot (MultiHandler::try_apply passes ctx by reference, use_target_mutation.hpp:27 applies
+  // on_after_use to the caller's ctx), UseTarget's on_use on a copy (:17-25), tag lifecycle handlers on a copy with
+  // actor = target = the tagged object (core/grid_object.cpp:83-91).
+  __device__ __forceinline__ uint32_t* vm_words() const {
+#ifdef MGX_WORLD_IDS
+    return (uint32_t*)(mgx_dyn_lds + mgx_world_xlds_off(d.A) + 28 * MGX_WORLD_EPG * 4 + 8 * MGX_WORLD_EPG * 8) + mgx_world_lane();
+#else
+    return nullptr;  // the handler VM only runs in the lane-per-env world kernels
+#endif
+  }
+  static __device__ __forceinline__ void ctx_store(uint32_t* vm, int cs, const MgxCtx& c) {
+    vm[(MGX_VM_FRAMES * 4 + cs * 2) * MGX_WORLD_EPG] = (uint32_t)((c.actor + 2) & 0xFFFF) | ((uint32_t)((c.target + 2) & 0xFFFF) << 16);
+    vm[(MGX_VM_FRAMES * 4 + cs * 2 + 1) * MGX_WORLD_EPG] = (uint32_t)(c.target_r & 0xFF) | ((uint32_t)(c.target_c & 0xFF) << 8) |
+        ((uint32_t)((c.proxy_tag + 1) & 0x1FF) << 16) | (c.mutation_failed ? 1u << 28 : 0u) | (c.skip_trigger ? 1u << 29 : 0u) |
+        (c.deferred ? 1u << 30 : 0u);
+  }
+  static __device__ __forceinline__ MgxCtx ctx_load(const uint32_t* vm, int cs) {
+    const uint32_t w0 = vm[(MGX_VM_FRAMES * 4 + cs * 2) * MGX_WORLD_EPG], w1 = vm[(MGX_VM_FRAMES * 4 + cs * 2 + 1) * MGX_WORLD_EPG];
+    MgxCtx c;
+    c.actor = (int)(w0 & 0xFFFF) - 2; c.target = (int)(w0 >> 16) - 2; c.source = MGX_SLOT_NONE;
+    c.target_r = (int)(w1 & 0xFF); c.target_c = (int)((w1 >> 8) & 0xFF); c.proxy_tag = (int)((w1 >> 16) & 0x1FF) - 1;
+    c.move_direction = 0;
+    c.mutation_failed = (w1 >> 28) & 1u; c.skip_trigger = (w1 >> 29) & 1u; c.deferred = (w1 >> 30) & 1u;
+    return c;
+  }
+  // h0 >= 0: Handler / MultiHandler h0 (returns try_apply's result).  h0 < 0: the raw record (raw_fpc, raw_ms, raw_mc):
+  // filters, then EVERY mutation with no stop on mutation_failed (events handler/event.cpp:86-92, AoE sources
+  // core/aoe_tracker.cpp:99-113, territory handlers core/territory_tracker.cpp:62-66); returns whether the filters passed.
+  __device__ MGX_OUTLINE bool vm_run(int h0, int raw_fpc, int raw_ms, int raw_mc, MgxCtx& c0) const {
+    enum { ST_ENTER = 0, ST_KIDS = 1, ST_MUTS = 2 };
+    uint32_t* vm = vm_words();
+    PP handlers = prog() + d.sec[MGX_SEC_HANDLERS];
+    PP muts = prog() + d.sec[MGX_SEC_MUTS];
+    int sp = 0, nctx = 1;
+    bool rv = false;
+    ctx_store(vm, 0, c0);
+    vm[0] = (uint32_t)h0; vm[MGX_WORLD_EPG] = (uint32_t)(ST_ENTER << 16) | (h0 < 0 ? 1u << 21 : 0u); vm[2 * MGX_WORLD_EPG] = 0; vm[3 * MGX_WORLD_EPG] = 0;
+    while (sp >= 0) {
+      uint32_t* fr = vm + sp * 4 * MGX_WORLD_EPG;
+      const int h = (int)fr[0];
+      const uint32_t st = fr[MGX_WORLD_EPG];
+      uint32_t sub = fr[2 * MGX_WORLD_EPG];
+      int i = st & 0xFFFF, stage = (st >> 16) & 0xF, any = (st >> 20) & 1;
+      const bool nostop = (st >> 21) & 1;
+      const int cs = (st >> 24) & 0xF;
+      MgxCtx c = ctx_load(vm, cs);
+      int kind = MGX_HK_LEAF, fpc = raw_fpc, ms = raw_ms, mc = raw_mc, cstart = 0, ccount = 0;
+      if (h >= 0) {
+        PP hd = handlers + h * MGX_HD_WORDS;
+        kind = hd[MGX_HD_KIND]; fpc = hd[MGX_HD_FILTER_PC]; ms = hd[MGX_HD_MUT_START]; mc = hd[MGX_HD_MUT_COUNT];
+        cstart = hd[MGX_HD_CHILD_START]; ccount = hd[MGX_HD_CHILD_COUNT];
+      }
+      int push_h = -1, push_cs = cs;  // handler to apply next (new frame); push_cs == nctx: on the context `pc`
+      MgxCtx pc = c;
+      bool pop = false;
+      if (stage == ST_ENTER) {
+        if (kind == MGX_HK_LEAF) {
+          if (!check_filters<TOPQ>(fpc, c, 0)) { rv = false; pop = true; }
+          else { c.mutation_failed = false; stage = ST_MUTS; i = 0; sub = 0; }
+        } else {
+          stage = ST_KIDS; i = 0; any = 0;
+        }
+      }
+      if (stage == ST_KIDS && !pop) {
+        if (i > 0 && rv) {
+          any = 1;
+          if (kind == MGX_HK_FIRST_MATCH) { rv = true; pop = true; }
+        }
+        if (!pop) {
+          if (i < ccount) { push_h = (prog() + d.sec[MGX_SEC_CHILDREN] + cstart)[i]; i++; }
+          else { rv = any != 0; pop = true; }
+        }
+      } else if (stage == ST_MUTS && !pop) {
+        if (sub == 0) {
+          if (!nostop && i > 0 && c.mutation_failed) { rv = false; pop = true; }
+          else if (i >= mc) { rv = true; pop = true; }
+        }
+        if (!pop) {
+          PP m = muts + (ms + i) * MGX_MU_WORDS;
+          const int op = m[MGX_MU_OP], a0 = m[MGX_MU_A0], a1 = m[MGX_MU_A1], a2 = m[MGX_MU_A2];
+          bool done = true;  // this mutation is finished (no handler left to apply for it)
+          if (op == MGX_MOP_USE_TARGET) {  // use_target_mutation.hpp:17-29, core/grid_object.cpp:72-80
+            if (sub == 0) {
+              int h2 = -1;
+              if (c.target >= 0 && agent_of(c.actor) >= 0) h2 = cls_of(c.target)[MGX_C_ON_USE];
+              if (h2 < 0) c.mutation_failed = true;
+              else { push_h = h2; push_cs = nctx; sub = 1; done = false; }
+            } else if (sub == 1) {
+              if (!rv) c.mutation_failed = true;
+              else {
+                const int after = cls_of(c.actor)[MGX_C_ON_AFTER_USE];
+                if (after >= 0) { push_h = after; sub = 2; done = false; }
+              }
+            }
+          } else if (op == MGX_MOP_ADD_TAG || op == MGX_MOP_REMOVE_TAG) {  // tag_mutation.hpp:16-45
+            const int o = resolve(c, a0);
+            const bool add = op == MGX_MOP_ADD_TAG;
+            bool fire = sub != 0;
+            if (sub == 0) { fire = (add ? tag_set(o, a1) : tag_clear(o, a1)) && !c.skip_trigger; sub = 1; }
+            if (fire) {
+              int hh = -1;
+              const int j = next_tag_handler(o, a1, add ? MGX_C_TAG_ADD_START : MGX_C_TAG_REMOVE_START, (int)sub - 1, &hh);
+              if (j >= 0) { sub = (uint32_t)j + 2; push_h = hh; push_cs = nctx; pc.actor = pc.target = o; pc.skip_trigger = false; done = false; }
+            }
+          } else if (op == MGX_MOP_REMOVE_TAGS_PREFIX) {  // tag_mutation.hpp:47-67: remove_tag per matching tag id
+            const int o = resolve(c, a0);
+            PP ids = prog() + d.sec[MGX_SEC_WORDLIST] + a1;
+            int idx = (int)(sub >> 12), jj = (int)(sub & 0xFFF);  // jj: 0 = tag idx not removed yet, else 1 + next record
+            while (idx < a2) {
+              if (jj == 0) {
+                if (!(tag_clear(o, ids[idx]) && !c.skip_trigger)) { idx++; continue; }
+                jj = 1;
+              }
+              int hh = -1;
+              const int j = next_tag_handler(o, ids[idx], MGX_C_TAG_REMOVE_START, jj - 1, &hh);
+              if (j >= 0) { sub = ((uint32_t)idx << 12) | (uint32_t)(j + 2); push_h = hh; push_cs = nctx; pc.actor = pc.target = o; pc.skip_trigger = false; done = false; break; }
+              idx++; jj = 0;
+            }
+          } else if (op == MGX_MOP_RECOMPUTE_QUERY) {  // query_system.cpp:119-175
+            uint16_t* lost = qbuf(QB_LOST);
+            uint16_t* keep = qbuf(QB_KEEP);
+            uint32_t aux = fr[3 * MGX_WORLD_EPG];
+            if (sub == 0) {  // untag the old members and tag the new ones silently, then fire handlers for the differences
+              int nl = 0, nk = 0;
+              PP mq = prog() + d.sec[MGX_SEC_MATQ];
+              for (int q = 0; q < d.n_matq; q++, mq += MGX_MQ_WORDS) {
+                if (mq[MGX_MQ_TAG] != a0) continue;
+                const int li = tag_list(a0);
+                if (li >= 0) { nl = tl_count(li); const uint16_t* it = tl_items(li); for (int k = 0; k < nl; k++) lost[k] = it[k]; }
+                for (int k = 0; k < nl; k++) tag_clear(lost[k], a0);
+                const int n = eval_query<TOPQ>(mq[MGX_MQ_QUERY], c, 0);
+                const uint16_t* res = qbuf(QB_BASE);
+                for (int k = 0; k < n; k++) {
+                  const int o = res[k];
+                  bool dup = false;
+                  for (int z = 0; z < nk; z++) dup |= keep[z] == (uint16_t)o;
+                  if (!dup) keep[nk++] = (uint16_t)o;
+                  tag_set(o, a0);
+                }
+                break;
+              }
+              aux = (uint32_t)nl | ((uint32_t)nk << 16);
+              fr[3 * MGX_WORLD_EPG] = aux;
+              sub = 1u << 28;  // phase 1 (objects that lost the tag), object 0, record 0
+            }
+            const int nl = (int)(aux & 0xFFFF), nk = (int)(aux >> 16);
+            int phase = (int)(sub >> 28), k = (int)(sub & 0xFFFF), j = (int)((sub >> 16) & 0xFFF);
+            while (phase <= 2) {
+              const int cnt = phase == 1 ? nl : nk;
+              const uint16_t* mine = phase == 1 ? lost : keep;
+              const uint16_t* other = phase == 1 ? keep : lost;
+              const int no = phase == 1 ? nk : nl;
+              bool pushed = false;
+              for (; k < cnt; k++, j = 0) {
+                const int o = mine[k];
+                bool both = false;
+                for (int z = 0; z < no; z++) both |= other[z] == (uint16_t)o;
+                if (both) continue;
+                int hh = -1;
+                const int jn = next_tag_handler(o, a0, phase == 1 ? MGX_C_TAG_REMOVE_START : MGX_C_TAG_ADD_START, j, &hh);
+                if (jn < 0) continue;
+                sub = ((uint32_t)phase << 28) | ((uint32_t)(jn + 1) << 16) | (uint32_t)k;
+                push_h = hh; push_cs = nctx; pc.actor = pc.target = o; pc.skip_trigger = false; done = false; pushed = true;
+                break;
+              }
+              if (pushed) break;
+              phase++; k = 0; j = 0;
+            }
+          } else {
+            mutate(m, c);
+          }
+          if (done) { sub = 0; i++; }
+        }
+      }
+      ctx_store(vm, cs, c);
+      if (pop) {
+        if (st & (1u << 22)) nctx--;  // the frame ran on its own context copy: slots are released in stack order
+        sp--;
+        continue;
+      }
+      fr[MGX_WORLD_EPG] = (uint32_t)i | ((uint32_t)stage << 16) | ((uint32_t)any << 20) | (st & (3u << 21)) | ((uint32_t)cs << 24);
+      fr[2 * MGX_WORLD_EPG] = sub;
+      if (push_h >= 0) {
+        if (sp + 1 >= MGX_VM_FRAMES || push_cs >= MGX_VM_CTXS) {  // deeper than the engine supports: the nested handler
+          flag(4u);                                                // counts as "did not apply"
+          rv = false;
+          continue;
+        }
+        const bool own = push_cs == nctx;
+        if (own) { ctx_store(vm, nctx, pc); nctx++; }
+        sp++;
+        uint32_t* nf = vm + sp * 4 * MGX_WORLD_EPG;
+        nf[0] = (uint32_t)push_h; nf[MGX_WORLD_EPG] = (uint32_t)(ST_ENTER << 16) | (own ? 1u << 22 : 0u) | ((uint32_t)push_cs << 24);
+        nf[2 * MGX_WORLD_EPG] = 0; nf[3 * MGX_WORLD_EPG] = 0;
+      }
+    }
+    c0 = ctx_load(vm, 0);
+    return rv;
+  }
+  // apply a top-level handler: register VM in the lean variant, LDS VM in the extended one
   __device__ __forceinline__ bool apply_top(int h, MgxCtx& c) const {
-    if constexpr (X) return apply_handler<3>(h, c);
+    if constexpr (X) return vm_run(h, 0, 0, 0, c);
     else return run_handler(h, c);
   }
 
-  // Filters + every mutation, no stop on mutation_failed (events, AoE sources, territory handlers:
-  // handler/event.cpp:86-92, core/aoe_tracker.cpp:99-113, core/territory_tracker.cpp:62-66).
-  __device__ MGX_BIG bool apply_all(int filter_pc, int mut_start, int mut_count, MgxCtx& c) const {
-    if (!check_filters<TOPQ>(filter_pc, c, 0)) return false;
-    PP m = prog() + d.sec[MGX_SEC_MUTS] + mut_start * MGX_MU_WORDS;
-    for (int i = 0; i < mut_count; i++, m += MGX_MU_WORDS) mutate<2>(m, c);
-    return true;
+  // Filters + every mutation, no stop on mutation_failed (events, AoE sources, territory handlers).
+  __device__ __forceinline__ bool apply_all(int filter_pc, int mut_start, int mut_count, MgxCtx& c) const {
+    return vm_run(-1, filter_pc, mut_start, mut_count, c);
   }
 
   // ---- events (handler/event.cpp:34-101, handler/event_scheduler.cpp:36-53) ----
@@ -1266,8 +1415,8 @@ struct MgxEnvT {  // per-lane view of one env
     const uint16_t rc = d.obj_rc[so(tgt)];
     const int r = rc >> 8, c = rc & 0xFF;
     const size_t fb = (size_t)envi() * d.NF;
-    xl.def_delta[13 * xl.stride + xl.lane] = 0;  // seen mask
-    xl.def_delta[14 * xl.stride + xl.lane] = 0;  // count
+    XL().def_delta[13 * XL().stride + XL().lane] = 0;  // seen mask
+    XL().def_delta[14 * XL().stride + XL().lane] = 0;  // count
     // exits first.  The reference walks an unordered_set<AOESource*> here (address order); registration order is used.
     for (int f = 0; f < nf; f++) {
       if (d.fx_obj[fb + f] == 0xFFFF) continue;
@@ -1296,10 +1445,10 @@ struct MgxEnvT {  // per-lane view of one env
         apply_all(a[MGX_AO_FILTER_PC], a[MGX_AO_MUT_START], a[MGX_AO_MUT_COUNT], ac);
       }
     }
-    const int cnt = xl.def_delta[14 * xl.stride + xl.lane];
+    const int cnt = XL().def_delta[14 * XL().stride + XL().lane];
     for (int k = 0; k < cnt; k++) {  // net delta per resource, first-seen order (:347-361)
-      int res = xl.def_delta[(15 + k) * xl.stride + xl.lane];
-      int dl = xl.def_delta[res * xl.stride + xl.lane];
+      int res = XL().def_delta[(15 + k) * XL().stride + XL().lane];
+      int dl = XL().def_delta[res * XL().stride + XL().lane];
       if (dl != 0) inv_update<1>(tgt, res, dl);
     }
   }
@@ -1334,14 +1483,210 @@ struct MgxEnvT {  // per-lane view of one env
     }
   }
 
+  // ---- area effects, one lane per AGENT (mgx_aoe_kernel) ----
+  // When every AoE / territory handler of the program only reads and writes its TARGET (an agent) — plus things
+  // nothing changes during the phase: positions, tags, the sources' registration lists — the agents of an env are
+  // independent here and each is handled by its own lane, in the reference's per-agent order: fixed AoEs, territory
+  // (mettagrid_c.cpp:1032-1035), then the mobile sources in registration order (:1038).  The host decides
+  // (mgx_aoe_is_target_local) from the filter atoms and mutations the records can reach; everything else takes the
+  // serial form above through the handler VM.
+  __device__ __forceinline__ void mutate_local(PP m, MgxCtx& c) const {
+    const int a0 = m[MGX_MU_A0], a1 = m[MGX_MU_A1], a2 = m[MGX_MU_A2], a3 = m[MGX_MU_A3];
+    switch (m[MGX_MU_OP]) {
+      case MGX_MOP_RESOURCE_DELTA: {  // resource_mutation.hpp:25-47 (target only)
+        if (c.deferred && c.target >= 0 && !(cls_of(c.target)[MGX_C_MODIFIER_MASK] & (1 << a1))) {
+          int* dd = XL().def_delta + a1 * XL().stride + XL().lane;
+          int* meta = XL().def_delta + 13 * XL().stride + XL().lane;
+          int* cnt = XL().def_delta + 14 * XL().stride + XL().lane;
+          if (!((*meta >> a1) & 1)) { *meta |= 1 << a1; XL().def_delta[(15 + *cnt) * XL().stride + XL().lane] = a1; *cnt += 1; *dd = 0; }
+          *dd += a2;
+        } else if (c.target >= 0) {
+          inv_update<1>(c.target, a1, a2);
+        }
+        break;
+      }
+      case MGX_MOP_CLEAR_INVENTORY: {
+        const int e = c.target;
+        if (e < 0) break;
+        if (a2 == 0) {
+          unsigned long long ord = d.obj_order[so(e)];
+          for (int k = 0; k < 16; k++) {
+            int item = (int)((ord >> (4 * k)) & 0xF);
+            if (item == 0xF) break;
+            inv_update<1>(e, item, -(int)inv(e, item));
+          }
+        } else {
+          PP ids = prog() + d.sec[MGX_SEC_WORDLIST] + a1;
+          for (int i = 0; i < a2; i++) inv_update<1>(e, ids[i], -(int)inv(e, ids[i]));
+        }
+        break;
+      }
+      case MGX_MOP_CHANGE_VIBE: if (c.target >= 0) d.obj_vibe[so(c.target)] = (uint8_t)a1; break;
+      case MGX_MOP_STATS: {  // agent scope on the target
+        float v = eval_value<0>(a3, c.target, c, 0);
+        int a = agent_of(c.target);
+        if (a >= 0) astat_set(a, a2, v);
+        break;
+      }
+      case MGX_MOP_GAME_VALUE: {
+        const int e = c.target;
+        float delta = eval_value<0>(a2, e, c, 0);
+        PP V = prog() + d.sec[MGX_SEC_OBS_VALUES] + a1 * MGX_OV_WORDS;
+        PP code = prog() + d.sec[MGX_SEC_GV_CODE] + V[MGX_OV_GV_START] * MGX_GV_WORDS;
+        if (code[MGX_GV_OP] == MGX_GOP_INVENTORY) { if (e >= 0) inv_update<1>(e, code[MGX_GV_A0], (int)delta); }
+        else if (code[MGX_GV_OP] == MGX_GOP_STAT) { int a = agent_of(e); if (a >= 0) astat_add_touch(a, code[MGX_GV_A1], delta); }
+        break;
+      }
+      default: flag(4u); break;  // not reachable: the host only selects this path for the operations above
+    }
+  }
+  __device__ __forceinline__ bool apply_all_local(int filter_pc, int mut_start, int mut_count, MgxCtx& c) const {
+    if (!check_filters<0>(filter_pc, c, 0)) return false;
+    PP m = prog() + d.sec[MGX_SEC_MUTS] + mut_start * MGX_MU_WORDS;
+    for (int i = 0; i < mut_count; i++, m += MGX_MU_WORDS) mutate_local(m, c);
+    return true;
+  }
+  // the `inside` bit of agent ai for one source: lanes of a wavefront share the word, so changes are atomic
+  static __device__ __forceinline__ void inside_set(uint32_t* w, int ai, bool on) {
+    if (on) atomicOr(w, 1u << (ai & 31)); else atomicAnd(w, ~(1u << (ai & 31)));
+  }
+  // Packed source record written by mgx_aoe_prep_kernel every step: rc (16) | radius (8) << 16 | live << 24 — live = the
+  // source is registered and has an effect (territory-style AoEs without mutations and presence deltas never do).
+  static __device__ __forceinline__ bool pack_covers(uint32_t p, int r, int c) {
+    const int dr = r - (int)((p >> 8) & 0xFF), dc = c - (int)(p & 0xFF), rad = (int)((p >> 16) & 0xFF);
+    return ((p >> 24) & 1u) && dr * dr + dc * dc <= rad * rad;
+  }
+  __device__ __forceinline__ void aoe_local_agent(int ai) const {
+    const int tgt = d.ag_obj[ao(ai)];
+    const uint16_t rc = d.obj_rc[so(tgt)];
+    const int r = rc >> 8, c = rc & 0xFF;
+    // ---- AOETracker::apply_fixed (core/aoe_tracker.cpp:278-362) for this agent ----
+    const int nf = d.NF ? d.fx_count[envi()] : 0;
+    if (nf > 0) {
+      const size_t fb = (size_t)envi() * d.NF;
+      XL().def_delta[13 * XL().stride + XL().lane] = 0;
+      XL().def_delta[14 * XL().stride + XL().lane] = 0;
+      for (int f = 0; f < nf; f++) {  // exits first
+        const uint32_t p = d.fx_pack[fb + f];
+        if (!((p >> 24) & 1u)) continue;
+        uint32_t* w = &d.fx_inside[(fb + f) * d.AW + (ai >> 5)];
+        if (!((*w >> (ai & 31)) & 1u)) continue;
+        if (!pack_covers(p, r, c)) { inside_set(w, ai, false); presence(aoe(d.fx_aoe[fb + f]), tgt, -1); }
+      }
+      for (int f = 0; f < nf; f++) {
+        const uint32_t p = d.fx_pack[fb + f];
+        if (!pack_covers(p, r, c)) continue;
+        PP a = aoe(d.fx_aoe[fb + f]);
+        const int src = d.fx_obj[fb + f];
+        const bool skip_self = !a[MGX_AO_EFFECT_SELF] && src == tgt;
+        MgxCtx fc = mgx_ctx(src, tgt);
+        fc.deferred = true;
+        const bool passes = !skip_self && check_filters<0>(a[MGX_AO_FILTER_PC], fc, 0);
+        uint32_t* w = &d.fx_inside[(fb + f) * d.AW + (ai >> 5)];
+        const bool was = (*w >> (ai & 31)) & 1u;
+        if (passes && !was) { inside_set(w, ai, true); presence(a, tgt, +1); }
+        else if (!passes && was) { inside_set(w, ai, false); presence(a, tgt, -1); }
+        if (passes && a[MGX_AO_MUT_COUNT] > 0) {
+          MgxCtx ac = mgx_ctx(src, tgt);
+          ac.deferred = true;
+          apply_all_local(a[MGX_AO_FILTER_PC], a[MGX_AO_MUT_START], a[MGX_AO_MUT_COUNT], ac);
+        }
+      }
+      const int cnt = XL().def_delta[14 * XL().stride + XL().lane];
+      for (int k = 0; k < cnt; k++) {
+        int res = XL().def_delta[(15 + k) * XL().stride + XL().lane];
+        int dl = XL().def_delta[res * XL().stride + XL().lane];
+        if (dl != 0) inv_update<1>(tgt, res, dl);
+      }
+    }
+    // ---- TerritoryTracker::apply_effects (core/territory_tracker.cpp:275-346); ownership from the current map ----
+    for (int ti = 0; ti < d.NT; ti++) {
+      PP TE = prog() + d.sec[MGX_SEC_TERRITORIES] + ti * MGX_TE_WORDS;
+      const uint16_t ov = d.terr_owner[((size_t)envi() * d.NT + ti) * (size_t)(d.H * d.W) + r * d.W + c];
+      const int cur = ov == 0xFFFF ? -1 : (int)ov;
+      int16_t& pv = d.terr_prev[ao(ai) * d.NT + ti];
+      const int prev = pv;
+      for (int pass = 0; pass < 3; pass++) {
+        const int tag = pass == 0 ? prev : cur;
+        const bool run = pass == 0 ? (prev != cur && prev >= 0) : pass == 1 ? (prev != cur && cur >= 0) : cur >= 0;
+        if (pass == 2) pv = (int16_t)cur;
+        if (!run) continue;
+        const int start = TE[pass == 0 ? MGX_TE_EXIT_START : pass == 1 ? MGX_TE_ENTER_START : MGX_TE_PRES_START];
+        const int count = TE[pass == 0 ? MGX_TE_EXIT_COUNT : pass == 1 ? MGX_TE_ENTER_COUNT : MGX_TE_PRES_COUNT];
+        for (int i = 0; i < count; i++) {
+          PP hd = prog() + d.sec[MGX_SEC_HANDLERS] + (start + i) * MGX_HD_WORDS;
+          MgxCtx tc = mgx_ctx(MGX_SLOT_PROXY, tgt);
+          tc.proxy_tag = tag;
+          tc.target_r = r; tc.target_c = c;
+          apply_all_local(hd[MGX_HD_FILTER_PC], hd[MGX_HD_MUT_START], hd[MGX_HD_MUT_COUNT], tc);
+        }
+      }
+    }
+    // ---- AOETracker::apply_mobile (core/aoe_tracker.cpp:364-415): this agent against every mobile source, in
+    // registration order.  Eight sources per trip: their packed records are one 32-byte load, the range tests and the
+    // `inside` words are independent, and only sources in range (or left since the last tick) take the full path. ----
+    const int nm = d.NM ? d.mb_count[envi()] : 0;
+    const size_t mb = (size_t)envi() * d.NM;
+    for (int m0 = 0; m0 < nm; m0 += 8) {
+      uint32_t p8[8], w8[8];
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        const int m = min(m0 + q, nm - 1);
+        p8[q] = d.mb_pack[mb + m];
+        w8[q] = d.mb_inside[(mb + m) * d.AW + (ai >> 5)];
+      }
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        const int m = m0 + q;
+        if (m >= nm) break;
+        const uint32_t p = p8[q];
+        if (!((p >> 24) & 1u)) continue;                       // unregistered source
+        const bool was = (w8[q] >> (ai & 31)) & 1u;
+        const bool in_range = pack_covers(p, r, c);
+        if (!in_range && !was) continue;
+        const int src = d.mb_obj[mb + m];
+        PP a = aoe(d.mb_aoe[mb + m]);
+        if (!a[MGX_AO_EFFECT_SELF] && src == tgt) continue;
+        uint32_t* w = &d.mb_inside[(mb + m) * d.AW + (ai >> 5)];
+        if (!in_range) { inside_set(w, ai, false); presence(a, tgt, -1); continue; }
+        MgxCtx mc = mgx_ctx(src, tgt);
+        if (check_filters<0>(a[MGX_AO_FILTER_PC], mc, 0)) {
+          if (!was) { inside_set(w, ai, true); presence(a, tgt, +1); }
+          if (a[MGX_AO_MUT_COUNT] > 0) { MgxCtx ac = mgx_ctx(src, tgt); apply_all_local(a[MGX_AO_FILTER_PC], a[MGX_AO_MUT_START], a[MGX_AO_MUT_COUNT], ac); }
+        } else if (was) {
+          inside_set(w, ai, false);
+          presence(a, tgt, -1);
+        }
+      }
+    }
+  }
+  // One packed record per registered AoE source (mgx_aoe_prep_kernel, one thread per source): see pack_covers.
+  __device__ __forceinline__ void aoe_pack_source(int k) const {
+    const bool fixed = k < d.NF;
+    const int i = fixed ? k : k - d.NF;
+    const size_t q = (size_t)envi() * (fixed ? d.NF : d.NM) + i;
+    const int n = fixed ? (d.NF ? d.fx_count[envi()] : 0) : (d.NM ? d.mb_count[envi()] : 0);
+    uint32_t p = 0;
+    if (i < n) {
+      const int obj = fixed ? d.fx_obj[q] : d.mb_obj[q];
+      if (obj != 0xFFFF) {
+        PP a = aoe(fixed ? d.fx_aoe[q] : d.mb_aoe[q]);
+        const uint16_t rc = fixed ? d.fx_rc[q] : d.obj_rc[so(obj)];  // fixed: location at registration (:166-200)
+        const bool effect = !fixed || a[MGX_AO_MUT_COUNT] > 0 || a[MGX_AO_PRES_COUNT] > 0;
+        p = (uint32_t)rc | ((uint32_t)(a[MGX_AO_RADIUS] & 0xFF) << 16) | (effect ? 1u << 24 : 0u);
+      }
+    }
+    if (fixed) d.fx_pack[q] = p; else d.mb_pack[q] = p;
+  }
+
   // ---- territory (core/territory_tracker.cpp) ----
   __device__ int cell_owner(int r, int c, int ti) const {  // compute_cell_ownership :215-252 -> winning tag or -1
     PP TE = prog() + d.sec[MGX_SEC_TERRITORIES] + ti * MGX_TE_WORDS;
     PP prefix = prog() + d.sec[MGX_SEC_WORDLIST] + TE[MGX_TE_TAGS_START];
     const int np = min(TE[MGX_TE_TAGS_COUNT], 8);
     if (TE[MGX_TE_TAGS_COUNT] > 8) flag(4u);
-    long long* score = xl.terr_score + xl.lane;
-    for (int k = 0; k < np; k++) score[k * xl.stride] = 0;
+    long long* score = XL().terr_score + XL().lane;
+    for (int k = 0; k < np; k++) score[k * XL().stride] = 0;
     const size_t tb = (size_t)envi() * d.NTS;
     const int n = d.ts_count[envi()];
     for (int i = 0; i < n; i++) {
@@ -1360,23 +1705,29 @@ struct MgxEnvT {  // per-lane view of one env
       long long sr = (int)(cur >> 8) - r, sc = (int)(cur & 0xFF) - c;
       unsigned long long d2 = (unsigned long long)(sr * sr + sc * sc);
       long long s = (long long)strength * 1024 - (long long)decay * (long long)mgx_floor_sqrt(d2 << 20);
-      if (s > 0) score[k * xl.stride] += s;
+      if (s > 0) score[k * XL().stride] += s;
     }
-    // unique maximum wins, any tie at the maximum -> none.  Tags are visited in ascending id like the oracle; the
-    // reference's unordered_map order does not matter for this rule.
+    // unique maximum wins, any tie at the maximum -> none: a rule that does not depend on the order the tags are
+    // visited in (the reference walks an unordered_map).
     int win = -1;
     long long best = 0;
     bool tied = false;
-    for (int t = 0; t < 256; t++) {
-      int k = 0;
-      while (k < np && prefix[k] != t) k++;
-      if (k >= np) continue;
-      long long s = score[k * xl.stride];
+    for (int k = 0; k < np; k++) {
+      long long s = score[k * XL().stride];
       if (s <= 0) continue;
-      if (s > best) { win = t; best = s; tied = false; }
+      if (s > best) { win = prefix[k]; best = s; tied = false; }
       else if (s == best && win >= 0) tied = true;
     }
     return tied ? -1 : win;
+  }
+  // Owner of a cell from the per-env ownership map when it is current (mgx_terr_kernel rebuilds it whenever a source
+  // moved or changed tags), else computed on the spot.
+  __device__ __forceinline__ int owner_at(int r, int c, int ti) const {
+    if (d.terr_owner && !d.terr_dirty[envi()]) {
+      const uint16_t v = d.terr_owner[((size_t)envi() * d.NT + ti) * (size_t)(d.H * d.W) + r * d.W + c];
+      return v == 0xFFFF ? -1 : (int)v;
+    }
+    return cell_owner(r, c, ti);
   }
   __device__ void run_territory_handlers(int start, int count, int tag, int tgt) const {
     for (int i = 0; i < count; i++) {
@@ -1393,7 +1744,7 @@ struct MgxEnvT {  // per-lane view of one env
     for (int ti = 0; ti < d.NT; ti++) {
       PP TE = prog() + d.sec[MGX_SEC_TERRITORIES] + ti * MGX_TE_WORDS;
       uint16_t rc = d.obj_rc[so(tgt)];
-      int cur = cell_owner(rc >> 8, rc & 0xFF, ti);
+      int cur = owner_at(rc >> 8, rc & 0xFF, ti);
       int16_t& pv = d.terr_prev[ao(ai) * d.NT + ti];
       int prev = pv;
       if (prev != cur && prev >= 0) run_territory_handlers(TE[MGX_TE_EXIT_START], TE[MGX_TE_EXIT_COUNT], prev, tgt);
@@ -1409,7 +1760,7 @@ struct MgxEnvT {  // per-lane view of one env
     const int dy = (orient == 0 || orient == 4 || orient == 5) ? -1 : (orient == 1 || orient == 6 || orient == 7) ? 1 : 0;
     PP mh = prog() + d.sec[MGX_SEC_MOVE_HANDLERS];
     for (int k = 0; k < d.n_move_handlers; k++, mh += MGX_MH_WORDS) {
-      uint16_t rc = (AL().rc && slot == cur_slot) ? AL().rc[cur_agent * MGX_WAVE + AL().lane] : d.obj_rc[so(slot)];
+      uint16_t rc = (AL().rc && slot == cur_slot) ? AL().rc[cur_agent * MGX_WORLD_EPG + AL().lane] : d.obj_rc[so(slot)];
       for (int i = 1; i <= mh[MGX_MH_MAX_RANGE]; i++) {
         int r = (rc >> 8) + dy * i, c = (rc & 0xFF) + dx * i;
         if (r < 0 || c < 0 || r >= d.H || c >= d.W) break;
@@ -1429,7 +1780,7 @@ struct MgxEnvT {  // per-lane view of one env
   __device__ MGX_BIG bool handle_action(int ai, int action, int stream) const {  // actions/action_handler.hpp:78-105
     PP ac = prog() + d.sec[MGX_SEC_ACTIONS] + action * MGX_AC_WORDS;
     int kind = ac[MGX_AC_KIND];
-    const int li = ai * MGX_WAVE + AL().lane;
+    const int li = ai * MGX_WORLD_EPG + AL().lane;
     int slot = AL().slot ? (int)AL().slot[li] : (int)d.ag_obj[ao(ai)];
     cur_agent = ai;
     cur_slot = slot;
@@ -1446,7 +1797,7 @@ struct MgxEnvT {  // per-lane view of one env
       const bool moved = rc != prev;
       if (moved) { AL().swm[li] = 0; AL().prev[li] = rc; }
       else AL().swm[li] += 1;
-      AL().act[(stream * d.A + ai) * MGX_WAVE + AL().lane] = (int16_t)(1 | (kind << 1) | (ok ? 8 : 0) | (moved ? 16 : 0));
+      AL().act[(stream * d.A + ai) * MGX_WORLD_EPG + AL().lane] = (int16_t)(1 | (kind << 1) | (ok ? 8 : 0) | (moved ? 16 : 0));
       cur_agent = cur_slot = -1;
       return ok;
     }
@@ -1456,7 +1807,7 @@ struct MgxEnvT {  // per-lane view of one env
       uint32_t swm = (AL().swm ? AL().swm[li] : d.ag_swm[ao(ai)]) + 1;
       if (AL().swm) AL().swm[li] = swm;
       d.ag_swm[ao(ai)] = swm;
-      int sid = mgx_wk(d, MGX_S_MAX_STEPS_WITHOUT_MOTION);
+      int sid = d.wk[MGX_S_MAX_STEPS_WITHOUT_MOTION];
       if ((float)swm > astat_get(ai, sid)) astat_set(ai, sid, (float)swm);
     } else {
       if (AL().swm) AL().swm[li] = 0;
@@ -1466,14 +1817,14 @@ struct MgxEnvT {  // per-lane view of one env
     }
     cur_agent = cur_slot = -1;
     int s_ok = kind == MGX_AK_NOOP ? MGX_S_NOOP_SUCCESS : kind == MGX_AK_MOVE ? MGX_S_MOVE_SUCCESS : MGX_S_VIBE_SUCCESS;
-    if (ok) astat_add(ai, mgx_wk(d, s_ok), 1.f);
-    else { astat_add(ai, mgx_wk(d, s_ok + 1), 1.f); astat_add(ai, mgx_wk(d, MGX_S_ACTION_FAILED), 1.f); }
+    if (ok) astat_add(ai, d.wk[s_ok], 1.f);
+    else { astat_add(ai, d.wk[s_ok + 1], 1.f); astat_add(ai, d.wk[MGX_S_ACTION_FAILED], 1.f); }
     MGX_TICK(7);
     return ok;
   }
 
   __device__ MGX_BIG void track_coverage(int ai) const {  // objects/agent.cpp:49-57
-    uint16_t rc = AL().rc ? AL().rc[ai * MGX_WAVE + AL().lane] : d.obj_rc[so(d.ag_obj[ao(ai)])];
+    uint16_t rc = AL().rc ? AL().rc[ai * MGX_WORLD_EPG + AL().lane] : d.obj_rc[so(d.ag_obj[ao(ai)])];
     // Unchanged position since the last call => the set is unchanged and both stats.set() calls would store the
     // values they already hold (keys exist since Agent::init): nothing to do.
     if (rc == d.ag_covrc[ao(ai)]) return;
@@ -1484,11 +1835,11 @@ struct MgxEnvT {  // per-lane view of one env
     uint32_t& w = d.ag_seen[ao(ai) * d.SEENW + (bit >> 5)];
     uint32_t uniq = d.ag_unique[ao(ai)];
     if (!(w & (1u << (bit & 31)))) { w |= 1u << (bit & 31); d.ag_unique[ao(ai)] = ++uniq; }
-    astat_set(ai, mgx_wk(d, MGX_S_CELL_UNIQUE), (float)uniq);
+    astat_set(ai, d.wk[MGX_S_CELL_UNIQUE], (float)uniq);
     int dist = abs((int)(sp >> 8) - r) + abs(c - (int)(sp & 0xFF));
     uint32_t md = max(d.ag_maxdist[ao(ai)], (uint32_t)dist);
     d.ag_maxdist[ao(ai)] = md;
-    astat_set(ai, mgx_wk(d, MGX_S_CELL_MAXDIST), (float)md);
+    astat_set(ai, d.wk[MGX_S_CELL_MAXDIST], (float)md);
   }
 
   // ---- std::mt19937 + libstdc++ uniform_int_distribution / shuffle ----
@@ -1497,13 +1848,13 @@ struct MgxEnvT {  // per-lane view of one env
   // of a chunk in flight together.  Per agent at most four stat cells change: the result counter of each stream
   // (success or failed), action.failed (+1 per failed call, added one by one like the reference) and
   // max_steps_without_motion (set when a call's incremented counter exceeds it).
-  __device__ void bookkeeping_flush() const {
+  __device__ MGX_BIG void bookkeeping_flush() const {
     const int A = d.A, lane = AL().lane;
-    const int s_max = mgx_wk(d, MGX_S_MAX_STEPS_WITHOUT_MOTION), s_failed = mgx_wk(d, MGX_S_ACTION_FAILED);
+    const int s_max = d.wk[MGX_S_MAX_STEPS_WITHOUT_MOTION], s_failed = d.wk[MGX_S_ACTION_FAILED];
     // the six result counters as scalars (a lane-varying index into d.wk would be a memory load per agent)
-    const int w_noop_ok = mgx_wk(d, MGX_S_NOOP_SUCCESS), w_noop_no = mgx_wk(d, MGX_S_NOOP_SUCCESS + 1);
-    const int w_move_ok = mgx_wk(d, MGX_S_MOVE_SUCCESS), w_move_no = mgx_wk(d, MGX_S_MOVE_SUCCESS + 1);
-    const int w_vibe_ok = mgx_wk(d, MGX_S_VIBE_SUCCESS), w_vibe_no = mgx_wk(d, MGX_S_VIBE_SUCCESS + 1);
+    const int w_noop_ok = d.wk[MGX_S_NOOP_SUCCESS], w_noop_no = d.wk[MGX_S_NOOP_SUCCESS + 1];
+    const int w_move_ok = d.wk[MGX_S_MOVE_SUCCESS], w_move_no = d.wk[MGX_S_MOVE_SUCCESS + 1];
+    const int w_vibe_ok = d.wk[MGX_S_VIBE_SUCCESS], w_vibe_no = d.wk[MGX_S_VIBE_SUCCESS + 1];
     for (int i0 = 0; i0 < A; i0 += 8) {
       int id0[8], id1[8], nfail[8];
       uint32_t res0[8], res1[8], swm0[8], tw[8];
@@ -1511,9 +1862,9 @@ struct MgxEnvT {  // per-lane view of one env
 #pragma unroll
       for (int q = 0; q < 8; q++) {
         const int i = min(i0 + q, A - 1);
-        const int li = i * MGX_WAVE + lane;
+        const int li = i * MGX_WORLD_EPG + lane;
         res0[q] = (uint32_t)(uint16_t)AL().act[li];
-        res1[q] = (uint32_t)(uint16_t)AL().act[A * MGX_WAVE + li];
+        res1[q] = (uint32_t)(uint16_t)AL().act[A * MGX_WORLD_EPG + li];
         if (i0 + q >= A) res0[q] = res1[q] = 0;
         // result bytes have bit 0 set; an action id that was never handled (invalid / wrong stream) is cleared by the caller
         auto stat_of = [&](uint32_t r) {
@@ -1540,7 +1891,7 @@ struct MgxEnvT {  // per-lane view of one env
       for (int q = 0; q < 8; q++) {
         const int i = i0 + q;
         if (i >= A || !((res0[q] | res1[q]) & 1)) continue;
-        const int li = i * MGX_WAVE + lane;
+        const int li = i * MGX_WORLD_EPG + lane;
         const size_t sb = ao(i) * d.NSP;
         // replay the calls: a call that did not move increments the counter and may raise the max stat
         uint32_t swm = swm0[q];
@@ -1609,15 +1960,15 @@ struct MgxEnvT {  // per-lane view of one env
 
   // track_coverage of every agent (mettagrid_c.cpp:1054-1056).  Agents are independent here, so the loads of eight
   // of them are issued together.  Both stat keys exist since Agent::init (mgx_init_kernel calls track_coverage).
-  __device__ void track_coverage_all() const {
+  __device__ MGX_BIG void track_coverage_all() const {
     const int A = d.A, lane = AL().lane;
-    const int su = mgx_wk(d, MGX_S_CELL_UNIQUE), sm = mgx_wk(d, MGX_S_CELL_MAXDIST);
+    const int su = d.wk[MGX_S_CELL_UNIQUE], sm = d.wk[MGX_S_CELL_MAXDIST];
     for (int i0 = 0; i0 < A; i0 += 8) {
       uint16_t rc8[8], cov8[8];
 #pragma unroll
       for (int q = 0; q < 8; q++) {
         const int i = min(i0 + q, A - 1);
-        rc8[q] = AL().rc[i * MGX_WAVE + lane];
+        rc8[q] = AL().rc[i * MGX_WORLD_EPG + lane];
         cov8[q] = d.ag_covrc[ao(i)];
       }
       uint16_t sp8[8];
@@ -1694,20 +2045,27 @@ __device__ __forceinline__ int16_t mgx_sat16(int32_t a) { return (int16_t)max(-3
 
 // order: LDS, [k][lane] bytes (k-major so that a wavefront access is bank-conflict free)
 __device__ __forceinline__ void mgx_swap(uint8_t* order, int lane, int i, int j) {
-  uint8_t a = order[i * MGX_WAVE + lane], b = order[j * MGX_WAVE + lane];
-  order[i * MGX_WAVE + lane] = b;
-  order[j * MGX_WAVE + lane] = a;
+  uint8_t a = order[i * MGX_WORLD_EPG + lane], b = order[j * MGX_WORLD_EPG + lane];
+  order[i * MGX_WORLD_EPG + lane] = b;
+  order[j * MGX_WORLD_EPG + lane] = a;
 }
 
+// phases (extended variant; the lean one always runs everything): MGX_PH_ACTIONS = steps 1-6 of _step (snapshot, ++step,
+// shuffle, action dispatch, timestep events, per-agent on_tick), MGX_PH_AOE = fixed AoE + territory per agent, mobile
+// AoE, deferred AoE registration (the general, serial form; games whose area effects only touch their target run
+// mgx_aoe_kernel instead: one lane per AGENT), MGX_PH_TAIL = game on_tick + coverage tracking.
+enum { MGX_PH_ACTIONS = 1, MGX_PH_AOE = 2, MGX_PH_TAIL = 4, MGX_PH_ALL = 7 };
 template <class PP, bool X>
-__device__ __forceinline__ void mgx_world_body(const MgxDev& d, PP P, uint8_t* order, MgxXLds xl, MgxALds al, int lane, int env) {
+__device__ __forceinline__ void mgx_world_body(const MgxDev& d, PP P, uint8_t* order, MgxXLds xl, MgxALds al, int lane, int env, int phases) {
   MgxEnvT<PP, X> e(d, P, env);
   e.xl = xl;
   const int A = d.A;
   MGX_TICK0();
-  e.step = ++d.step[env];
-  if constexpr (!X) {  // executed_actions / _action_success cleared (mettagrid_c.cpp:944,962-964): the lean variant does
-                       // it here (five 16-byte stores per env) instead of two memset launches per step
+  if constexpr (!X) phases = MGX_PH_ALL;
+  const bool act = (phases & MGX_PH_ACTIONS) != 0;
+  e.step = act ? ++d.step[env] : d.step[env];
+  if (act) {  // executed_actions / _action_success cleared (mettagrid_c.cpp:944,962-964): done here (a few 16-byte
+              // stores per env) instead of two memset launches per step
     if ((A & 3) == 0) {
       uint4* ex = (uint4*)(d.executed + e.ao(0));
       for (int i = 0; i < A / 4; i++) ex[i] = make_uint4(0u, 0u, 0u, 0u);
@@ -1741,20 +2099,23 @@ __device__ __forceinline__ void mgx_world_body(const MgxDev& d, PP P, uint8_t* o
     for (int q = 0; q < 8; q++) {
       int i = i0 + q;
       if (i < A) {
-        int li = i * MGX_WAVE + lane;
+        int li = i * MGX_WORLD_EPG + lane;
         al.slot[li] = slot8[q]; al.rc[li] = rc8[q]; al.prev[li] = prev8[q]; al.swm[li] = swm8[q]; al.cls[li] = cls8[q];
-        al.act[li] = mgx_sat16(a8[q]); al.act[A * MGX_WAVE + li] = mgx_sat16(v8[q]);
-        if (want_stepprev) d.ag_stepprev[e.ao(i)] = rc8[q];  // mettagrid_c.cpp:929-931
+        al.act[li] = mgx_sat16(a8[q]); al.act[A * MGX_WORLD_EPG + li] = mgx_sat16(v8[q]);
+        if (want_stepprev && act) d.ag_stepprev[e.ao(i)] = rc8[q];  // mettagrid_c.cpp:929-931
         order[li] = (uint8_t)i;
       }
     }
   }
   e.al_ = al;
   MGX_TICK(0);
+#if defined(MGX_DBG_STOP) && MGX_DBG_STOP == 1
+  return;
+#endif
   // std::shuffle (bits/stl_algo.h:3729-3795): one draw for an even n, then paired draws.  The generator outputs
   // are produced eight at a time (rng_block): one round trip for the state words of the whole shuffle instead of
   // three dependent ones per draw.  A Lemire rejection (probability < 1e-7) simply consumes one more output.
-  if (A >= 2) {
+  if (A >= 2 && act) {
     const uint32_t ndraw = (uint32_t)A / 2;  // A even: 1 + (A - 2) / 2, A odd: (A - 1) / 2
     uint32_t j = 0;                          // draws done
     while (j < ndraw) {
@@ -1792,36 +2153,42 @@ __device__ __forceinline__ void mgx_world_body(const MgxDev& d, PP P, uint8_t* o
   PP acts = P + d.sec[MGX_SEC_ACTIONS];
   const int repeats = d.max_priority + 1;
   MGX_TICK(1);
-  for (int stream = 0; stream < 2; stream++) {
+#if defined(MGX_DBG_STOP) && MGX_DBG_STOP == 2
+  return;
+#endif
+  for (int stream = 0; stream < (act ? 2 : 0); stream++) {
     for (int k = 0; k < A; k++) {
-      int ai = order[k * MGX_WAVE + lane];
-      int a = al.act[(stream * A + ai) * MGX_WAVE + lane];
+      int ai = order[k * MGX_WORLD_EPG + lane];
+      int a = al.act[(stream * A + ai) * MGX_WORLD_EPG + lane];
       if (a < 0 || a >= d.nact) {  // _handle_invalid_action :914-919
         for (int rep = 0; rep < repeats; rep++) {
-          e.astat_add(ai, mgx_wk(d, MGX_S_INVALID_INDEX), 1.f);
-          if (a < 0 && a >= -MGX_INVALID_WINDOW) e.astat_add(ai, mgx_wk(d, MGX_S_INVALID_NEG_BASE) + a + MGX_INVALID_WINDOW, 1.f);
-          else if (a >= d.nact && a < d.nact + MGX_INVALID_WINDOW) e.astat_add(ai, mgx_wk(d, MGX_S_INVALID_POS_BASE) + a - d.nact, 1.f);
+          e.astat_add(ai, d.wk[MGX_S_INVALID_INDEX], 1.f);
+          if (a < 0 && a >= -MGX_INVALID_WINDOW) e.astat_add(ai, d.wk[MGX_S_INVALID_NEG_BASE] + a + MGX_INVALID_WINDOW, 1.f);
+          else if (a >= d.nact && a < d.nact + MGX_INVALID_WINDOW) e.astat_add(ai, d.wk[MGX_S_INVALID_POS_BASE] + a - d.nact, 1.f);
           else e.flag(2u);
         }
         d.success[e.ao(ai)] = 0;
-        al.act[(stream * A + ai) * MGX_WAVE + lane] = 0;  // no handle_action call: empty result byte
+        al.act[(stream * A + ai) * MGX_WORLD_EPG + lane] = 0;  // no handle_action call: empty result byte
         continue;
       }
       bool is_vibe = acts[a * MGX_AC_WORDS + MGX_AC_KIND] == MGX_AK_VIBE;
-      if (is_vibe != (stream == 1)) { al.act[(stream * A + ai) * MGX_WAVE + lane] = 0; continue; }
+      if (is_vibe != (stream == 1)) { al.act[(stream * A + ai) * MGX_WORLD_EPG + lane] = 0; continue; }
       if (e.handle_action(ai, a, stream)) {
         d.executed[e.ao(ai)] = a;
         d.success[e.ao(ai)] = 1;
       }
     }
     MGX_TICK(2 + stream);
+#if defined(MGX_DBG_STOP) && (MGX_DBG_STOP == 3 || MGX_DBG_STOP == 4)
+    if (stream == MGX_DBG_STOP - 3) return;
+#endif
   }
   if constexpr (X) {
-    if (d.n_schedule > 0) e.process_events();  // mettagrid_c.cpp:1009-1011
+    if (act && d.n_schedule > 0) e.process_events();  // mettagrid_c.cpp:1009-1011
   }
-  if (d.any_on_tick) {
+  if (d.any_on_tick && act) {
     for (int i = 0; i < A; i++) {  // per-agent on_tick (mettagrid_c.cpp:1019-1024); slot and class come from LDS
-      const int li = i * MGX_WAVE + lane;
+      const int li = i * MGX_WORLD_EPG + lane;
       const int h = e.cls(al.cls[li])[MGX_C_ON_TICK];
       if (h >= 0) {
         const int slot = al.slot[li];
@@ -1831,6 +2198,7 @@ __device__ __forceinline__ void mgx_world_body(const MgxDev& d, PP P, uint8_t* o
     }
   }
   if constexpr (X) {
+   if (phases & MGX_PH_AOE) {
     if (d.NF > 0 || d.NT > 0)
       for (int i = 0; i < A; i++) {  // mettagrid_c.cpp:1032-1035
         if (d.NF > 0) e.apply_fixed(i);
@@ -1842,35 +2210,42 @@ __device__ __forceinline__ void mgx_world_body(const MgxDev& d, PP P, uint8_t* o
       for (int k = 0; k < n; k++) e.register_aoes(d.def_aoe[(size_t)env * d.S + k]);
       d.def_count[env] = 0;
     }
-    if (d.game_on_tick >= 0) {       // :1050-1052
+   }
+    if ((phases & MGX_PH_TAIL) && d.game_on_tick >= 0) {       // :1050-1052
       MgxCtx c = mgx_ctx(MGX_SLOT_NONE, MGX_SLOT_NONE);
-      e.template apply_handler<3>(d.game_on_tick, c);
+      e.apply_top(d.game_on_tick, c);
     }
   }
   MGX_TICK(4);
-  if (d.defer_book) e.bookkeeping_flush();
-  e.track_coverage_all();
+#if defined(MGX_DBG_STOP) && MGX_DBG_STOP == 5
+  return;
+#endif
+  if (d.defer_book && act) e.bookkeeping_flush();
+#if defined(MGX_DBG_STOP) && MGX_DBG_STOP == 6
+  return;
+#endif
+  if (phases & MGX_PH_TAIL) e.track_coverage_all();
   MGX_TICK(5);
 }
 
 // PROG_LDS: the program blob is first copied into LDS (16-byte coalesced loads) and every table lookup of the
 // handler VM becomes a ds_read.
 template <bool PROG_LDS, bool X>
-__device__ __forceinline__ void mgx_world_entry(const MgxDev& d, int prog_words) {
+__device__ __forceinline__ void mgx_world_entry(const MgxDev& d, int prog_words, int phases = MGX_PH_ALL) {
   uint8_t* order = mgx_dyn_lds;
   const int lane = mgx_world_lane();
   const bool active = (threadIdx.x & (MGX_WAVE - 1)) < MGX_WORLD_LPW;
-  const int env = blockIdx.x * MGX_WAVE + lane;
+  const int env = blockIdx.x * MGX_WORLD_EPG + lane;
   MgxXLds xl;
   xl.lane = lane;
-  xl.stride = MGX_WAVE;
+  xl.stride = MGX_WORLD_EPG;
   const MgxALds al = mgx_world_alds(mgx_dyn_lds, d.A, lane);
-  int off = ((d.A * MGX_WAVE + 15) & ~15) + ((mgx_world_alds_bytes(d.A) + 15) & ~15);
+  int off = ((d.A * MGX_WORLD_EPG + 15) & ~15) + ((mgx_world_alds_bytes(d.A) + 15) & ~15);
   if (X) {
     xl.def_delta = (int*)(mgx_dyn_lds + off);
-    off += 28 * MGX_WAVE * 4;
+    off += 28 * MGX_WORLD_EPG * 4;
     xl.terr_score = (long long*)(mgx_dyn_lds + off);
-    off += 8 * MGX_WAVE * 8;
+    off += 8 * MGX_WORLD_EPG * 8 + MGX_VM_WORDS * MGX_WORLD_EPG * 4;
   } else {
     xl.def_delta = nullptr;
     xl.terr_score = nullptr;
@@ -1882,23 +2257,41 @@ __device__ __forceinline__ void mgx_world_entry(const MgxDev& d, int prog_words)
     for (int i = threadIdx.x; i < prog_words / 4; i += blockDim.x) dst[i] = src[i];
     __syncthreads();
     if (!active || env >= d.E) return;
-    mgx_world_body<MgxLdsProg, X>(d, (MgxLdsProg)lprog, order, xl, al, lane, env);
+    mgx_world_body<MgxLdsProg, X>(d, (MgxLdsProg)lprog, order, xl, al, lane, env, phases);
   } else {
     if (!active || env >= d.E) return;
-    mgx_world_body<MgxGlobalProg, X>(d, d.P, order, xl, al, lane, env);
+    mgx_world_body<MgxGlobalProg, X>(d, d.P, order, xl, al, lane, env, phases);
   }
 }
 
 
+}  // namespace MGX_TU_NS
+using namespace MGX_TU_NS;
+
 // Host launcher of the non-extended world kernels (defined in mgx_world_fast.hip).
-void mgx_launch_world_fast(bool prog_lds, size_t lds, hipStream_t stream, const MgxDev& d, int prog_words);
-bool mgx_world_fast_set_lds(size_t lds);  // raises the kernels' dynamic LDS limit (needed past 64 KB)
+// (one copy per constant-memory slot: mgx_world_fast.hip is compiled with MGX_SLOT = 0 and 1)
+#define MGX_FAST_SLOTS 2
+size_t mgx_world_fast_lds_bytes(int A);   // dynamic LDS of the unit's kernels without the program copy
+void mgx_launch_world_fast_s0(bool prog_lds, size_t lds, hipStream_t stream, const MgxDev& d, int prog_words);
+void mgx_launch_world_fast_s1(bool prog_lds, size_t lds, hipStream_t stream, const MgxDev& d, int prog_words);
+bool mgx_world_fast_set_lds_s0(size_t lds);  // raises the kernels' dynamic LDS limit (needed past 64 KB)
+bool mgx_world_fast_set_lds_s1(size_t lds);
+// ... and of the extended one (mgx_world_x.hip)
+void mgx_launch_world_x(bool prog_lds, size_t lds, hipStream_t stream, const MgxDev& d, int prog_words, int phases);
+bool mgx_world_x_set_lds(size_t lds);
+size_t mgx_world_x_lds_bytes(int A);
+size_t mgx_world_x_private_bytes();
+void mgx_launch_values(hipStream_t stream, const MgxDev& d, int phase, const uint8_t* env_mask);
+// lane-per-agent area effects (mgx_aoe.hip) and the host analysis that allows them
+void mgx_launch_aoe(hipStream_t stream, const MgxDev& d);
+bool mgx_aoe_is_target_local(const int32_t* program);
 
 #ifndef MGX_WORLD_FAST_TU
 // Construction: MettaGrid ctor + _init_grid (mettagrid_c.cpp:42-191, 200-269).  One lane per env scans the class
 // map in row-major order; object slot = reference object id - 1; agent index = order of appearance.
 __global__ void __launch_bounds__(MGX_WAVE) mgx_init_kernel(MgxDev d, const uint16_t* class_maps, const uint32_t* seeds,
                                                             const uint8_t* env_mask) {
+  MGX_KERNARG_ENTRY(d);
   const int env = blockIdx.x * MGX_WAVE + threadIdx.x;
   if (env >= d.E) return;
   if (env_mask && !env_mask[env]) return;
@@ -1913,9 +2306,9 @@ __global__ void __launch_bounds__(MGX_WAVE) mgx_init_kernel(MgxDev d, const uint
   d.mt_idx[env] = 0;
   d.step[env] = 0;
   d.err[env] = 0;
-  e.gstat_touch(mgx_wk(d, MGX_S_GAME_TOKENS_WRITTEN));
-  e.gstat_touch(mgx_wk(d, MGX_S_GAME_TOKENS_DROPPED));
-  e.gstat_touch(mgx_wk(d, MGX_S_GAME_TOKENS_FREE));
+  e.gstat_touch(d.wk[MGX_S_GAME_TOKENS_WRITTEN]);
+  e.gstat_touch(d.wk[MGX_S_GAME_TOKENS_DROPPED]);
+  e.gstat_touch(d.wk[MGX_S_GAME_TOKENS_FREE]);
   const int HW = d.H * d.W;
   const uint16_t* cm = class_maps + (size_t)env * HW;
   int nobj = 0, nag = 0, nf = 0, nm = 0, nts = 0;
@@ -1946,7 +2339,7 @@ __global__ void __launch_bounds__(MGX_WAVE) mgx_init_kernel(MgxDev d, const uint
     for (int i = 0; i < C[MGX_C_INIT_INV_COUNT]; i++, ii += MGX_II_WORDS) {
       // objects/agent.cpp:79-84 (limits ignored, no callback, "<res>.amount" set), grid_object_factory.cpp:83-87
       e.inv_update<0>(slot, ii[MGX_II_ITEM], ii[MGX_II_AMOUNT], true, false);
-      if (ai >= 0) e.astat_set(ai, mgx_wk(d, MGX_S_RES_AMOUNT_BASE) + ii[MGX_II_ITEM], (float)ii[MGX_II_AMOUNT]);
+      if (ai >= 0) e.astat_set(ai, d.wk[MGX_S_RES_AMOUNT_BASE] + ii[MGX_II_ITEM], (float)ii[MGX_II_AMOUNT]);
     }
     e.gstat_add(C[MGX_C_OBJECTS_STAT], 1.f);
     if (d.X) {
@@ -1962,12 +2355,16 @@ __global__ void __launch_bounds__(MGX_WAVE) mgx_init_kernel(MgxDev d, const uint
         const int32_t* AO = d.P + d.sec[MGX_SEC_AOES] + a * MGX_AO_WORDS;
         if (AO[MGX_AO_STATIC]) {
           if (nf < d.NF) { size_t q = (size_t)env * d.NF + nf; d.fx_obj[q] = (uint16_t)slot; d.fx_aoe[q] = (uint16_t)a; d.fx_rc[q] = rc; nf++; }
+          else e.flag(8u);  // more sources than the capacity sized at mgx_create / mgx_set_map_pool
         } else if (nm < d.NM) {
           size_t q = (size_t)env * d.NM + nm; d.mb_obj[q] = (uint16_t)slot; d.mb_aoe[q] = (uint16_t)a; nm++;
+        } else {
+          e.flag(8u);
         }
       }
       for (int i = 0; i < C[MGX_C_TERR_COUNT]; i++)  // TerritoryTracker::register_source (:254-257)
         if (nts < d.NTS) { size_t q = (size_t)env * d.NTS + nts; d.ts_obj[q] = (uint16_t)slot; d.ts_ctrl[q] = (uint16_t)(C[MGX_C_TERR_START] + i); d.ts_rc[q] = rc; nts++; }
+        else e.flag(8u);
     }
   }
   d.num_objs[env] = (uint32_t)nobj;
@@ -1988,14 +2385,14 @@ __global__ void __launch_bounds__(MGX_WAVE) mgx_init_kernel(MgxDev d, const uint
         uint16_t* lost = e.qbuf(MgxEnvX::QB_LOST);
         int nl = e.tl_count(li);
         for (int k = 0; k < nl; k++) lost[k] = e.tl_items(li)[k];
-        for (int k = 0; k < nl; k++) e.remove_tag<0>(lost[k], tag, t);
+        for (int k = 0; k < nl; k++) e.tag_clear(lost[k], tag);
       }
       MgxCtx g = mgx_ctx(MGX_SLOT_NONE, MGX_SLOT_NONE);
       int n = e.eval_query<3>(mq[MGX_MQ_QUERY], g, 0);
       uint16_t* keep = e.qbuf(MgxEnvX::QB_KEEP);
       const uint16_t* res = e.qbuf(MgxEnvX::QB_BASE);
       for (int k = 0; k < n; k++) keep[k] = res[k];
-      for (int k = 0; k < n; k++) e.add_tag<0>(keep[k], tag, t);
+      for (int k = 0; k < n; k++) e.tag_set(keep[k], tag);
     }
   }
   for (int ai = 0; ai < nag; ai++) {

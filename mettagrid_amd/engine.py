@@ -265,10 +265,17 @@ class BatchedMettaGrid:
     def set_profiling(self, on: bool) -> None:
         _check(self.L.mgx_set_profiling(self.h, 1 if on else 0))
 
-    def step_timing_ms(self):
-        out = np.zeros(2, np.float32)
+    TIMING_SEGMENTS = ("actions", "aoe", "tail", "obs", "rewards")   # include/mgx.h MGX_T_*
+
+    def step_timing_segments_ms(self) -> dict:
+        out = np.zeros(len(self.TIMING_SEGMENTS), np.float32)
         _check(self.L.mgx_get_step_timing(self.h, out.ctypes.data))
-        return float(out[0]), float(out[1])
+        return {k: float(v) for k, v in zip(self.TIMING_SEGMENTS, out)}
+
+    def step_timing_ms(self):
+        """(world update, observation + rewards) of the most recent step in milliseconds."""
+        t = self.step_timing_segments_ms()
+        return t["actions"] + t["aoe"] + t["tail"], t["obs"] + t["rewards"]
 
     @property
     def state_bytes(self) -> int:

@@ -100,9 +100,13 @@ template <class T> static inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; 
 template <class T> static inline T atomicOr(T* p, T v) { T o = *p; *p = o | v; return o; }
 template <class T> static inline T atomicAnd(T* p, T v) { T o = *p; *p = o & v; return o; }
 template <class T> static inline T atomicMin(T* p, T v) { T o = *p; *p = o < v ? o : v; return o; }
-using std::max;
-using std::min;
+#define MGX_EMU_MINMAX(T)                                   \
+  static inline T min(T a, T b) { return b < a ? b : a; } \
+  static inline T max(T a, T b) { return a < b ? b : a; }
+MGX_EMU_MINMAX(int) MGX_EMU_MINMAX(unsigned) MGX_EMU_MINMAX(long) MGX_EMU_MINMAX(unsigned long) MGX_EMU_MINMAX(long long)
+MGX_EMU_MINMAX(unsigned long long) MGX_EMU_MINMAX(float) MGX_EMU_MINMAX(double)
 static inline int min(int a, unsigned b) { return a < (int)b ? a : (int)b; }
+static inline unsigned max(unsigned a, int b) { return a < (unsigned)b ? (unsigned)b : a; }
 // wavefront intrinsics: referenced by the (never launched) observation kernel only
 static inline int __builtin_amdgcn_update_dpp(int, int x, int, int, int, bool) { return x; }
 static inline int __builtin_amdgcn_readlane(int x, int) { return x; }

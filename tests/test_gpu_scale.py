@@ -19,13 +19,18 @@ from mettagrid_amd.mapgen import random_class_maps
 pytestmark = pytest.mark.gpu
 
 
-def _run_and_check(E, sample, steps, seed0=0):
+def _run_and_check(E, sample, steps, seed0=0, rung=3, actions=None):
     import torch
-    spec = presets.rung3_spec()
-    prog = compile_spec(spec, 32, 32, max_objects=192)
+    if rung == 3:
+        spec = presets.rung3_spec()
+        prog = compile_spec(spec, 32, 32, max_objects=192)
+        cms = random_class_maps(prog, 32, 32, {"wall": 40, "extractor": 8, "chest": 4}, {"red": 8, "blue": 8},
+                                range(seed0, seed0 + E))
+    else:
+        spec = presets.rung4_spec()
+        prog = compile_spec(spec, 64, 64, max_objects=presets.RUNG4_MAX_OBJECTS)
+        cms = random_class_maps(prog, 64, 64, presets.RUNG4_OBJECTS, presets.RUNG4_AGENTS, range(seed0, seed0 + E))
     A, T = prog.num_agents, prog.num_tokens
-    cms = random_class_maps(prog, 32, 32, {"wall": 40, "extractor": 8, "chest": 4}, {"red": 8, "blue": 8},
-                            range(seed0, seed0 + E))
     seeds = np.arange(seed0, seed0 + E, dtype=np.uint32)
     eng = BatchedMettaGrid(prog, cms, seeds, buffers="device")
     oracles = {i: op.OracleSim(prog, cms[i], int(seeds[i])) for i in sample}
@@ -50,6 +55,8 @@ def _run_and_check(E, sample, steps, seed0=0):
     for t in range(steps):
         a = rng.integers(-1, n_act + 1, size=E * A).astype(np.int32)   # includes invalid ids on both sides
         v = rng.integers(0, n_act, size=E * A).astype(np.int32)
+        if actions is not None:
+            a, v = actions(t, a, v)
         eng.actions.copy_(torch.from_numpy(a))
         eng.vibe_actions.copy_(torch.from_numpy(v))
         torch.cuda.synchronize()
@@ -80,6 +87,24 @@ def test_full_size_sampled_parity_and_row_wellformedness():
     # every agent sees at least its global tokens and itself
     assert (~empty[:, 0]).all().item()
     assert torch.isfinite(eng.rewards).all().item()
+
+
+def test_rung4_boundaries():
+    """BASELINE.json configs[3] rules and shape (64x64, 64 agents) across wavefront / workgroup boundaries; 55 steps reach
+    the first timestep event (t = 50, max_targets with the env's RNG)."""
+    _run_and_check(150, [0, 31, 32, 63, 64, 65, 127, 128, 149], steps=55, rung=4)
+
+
+def test_rung4_full_size_sampled_parity_and_row_wellformedness():
+    """configs[3] at its full size: 65 536 envs x 64x64 x 64 agents, AoE + territory + events (4.2 M agents per step)."""
+    E = 65536
+    sample = [0, 63, 64, 4097, 32767, 32768, 50001, 65535]
+    eng, T = _run_and_check(E, sample, steps=3, rung=4)
+    obs = eng.obs
+    empty = (obs == 0xFF).all(dim=2)
+    assert not (empty[:, :-1] & ~empty[:, 1:]).any().item()
+    assert ((obs[..., 0] == 0xFF) == empty).all().item()
+    assert (~empty[:, 0]).all().item()
 
 
 def test_large_rectangular_map():
