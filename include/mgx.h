@@ -97,6 +97,14 @@ int mgx_get_objects(mgx_engine* e, int32_t env, int32_t* out, int32_t* n_objects
 /* current_stat_reward per agent of env `env` (RewardHelper::current_reward, systems/reward.hpp:36-42). f32 [A]. */
 int mgx_get_reward_state(mgx_engine* e, int32_t env, float* out);
 
+/* set_inventory(agent_id, {resource: amount}) — mettagrid_py.cpp:203-207, Agent::set_inventory objects/agent.cpp:86-104:
+ * every item the agent holds is removed (Inventory::update(-amount), "<res>.amount" stat set to 0), then the given items
+ * are set one by one through Inventory::update (limits and stats apply).  `items` / `amounts` list the given map in ITS
+ * iteration order (the reference iterates a std::unordered_map; the Python mirror computes that order). */
+int mgx_set_inventory(mgx_engine* e, int32_t env, int32_t agent_id, const int32_t* items, const int32_t* amounts, int32_t n);
+/* tag_index().count_objects_with_tag(tag_id) — mettagrid_py.cpp:312,377-380: objects of env `env` registered under a tag. */
+int mgx_count_objects_with_tag(mgx_engine* e, int32_t env, int32_t tag_id, int32_t* out);
+
 /* OR of the per-env error bits over all envs; if first_env != NULL receives the first env with a bit set (or -1).
  * Replaces the exceptions thrown from inside step() in the reference. */
 int mgx_poll_errors(mgx_engine* e, uint32_t* bits, int32_t* first_env);

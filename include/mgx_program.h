@@ -18,7 +18,7 @@
 #include <stdint.h>
 
 #define MGX_MAGIC 0x3158474d /* "MGX1" little-endian */
-#define MGX_VERSION 7
+#define MGX_VERSION 8
 
 #define MGX_MAX_RESOURCES 13 /* inventory order list = 4-bit ids in one u64, 0xF terminator; see DESIGN.md */
 #define MGX_TAG_WORDS 8      /* 256 tags = 8 x u32 (reference kMaxTags, core/types.hpp:62) */
@@ -103,8 +103,10 @@ enum {
   MGX_SEC_CLASSES = 0, MGX_SEC_LIMITS, MGX_SEC_MODS, MGX_SEC_DROP_ORDER, MGX_SEC_INIT_INV, MGX_SEC_HANDLERS,
   MGX_SEC_CHILDREN, MGX_SEC_ATOMS, MGX_SEC_MUTS, MGX_SEC_ACTIONS, MGX_SEC_MOVE_HANDLERS, MGX_SEC_OBS_OFFSETS,
   MGX_SEC_INV_FEATURES, MGX_SEC_GV_CODE, MGX_SEC_REWARDS, MGX_SEC_OBS_VALUES, MGX_SEC_WORDLIST,
-  MGX_SEC_QUERIES, MGX_SEC_EVENTS, MGX_SEC_SCHEDULE, MGX_SEC_MATQ, MGX_SEC_TAG_HANDLERS, MGX_SEC_AOES,
+  MGX_SEC_QUERIES, MGX_SEC_EVENTS, MGX_SEC_MATQ, MGX_SEC_TAG_HANDLERS, MGX_SEC_AOES,
   MGX_SEC_PRESENCE, MGX_SEC_TERRITORIES, MGX_SEC_TERR_CONTROLS, MGX_SEC_TAG_LISTS /* 256 words: tag -> list idx or -1 */,
+  MGX_SEC_SCHEDULE /* last: the only section that grows with the episode length (periodic events); the world kernels
+                      keep everything in front of it in LDS and read the schedule, one entry per firing, from HBM */,
   MGX_SEC_COUNT
 };
 

@@ -157,6 +157,10 @@ class _Compiler:
         self._qdepth = 0          # nesting level of the query currently being emitted (filters/values inherit it)
         self.dynamic_tags = False
         self.tag_mutations = False       # AddTag / RemoveTag / RemoveTagsWithPrefix somewhere in the program
+        # Records emitted once per distinct content: the reference's converter builds one config per agent
+        # (mettagrid_c_config.py:657-790), so 64 identical agents would otherwise bring 64 copies of every handler,
+        # limit group and reward list — a program that no longer fits the world kernel's LDS copy or its caches.
+        self._memo: dict = {}
 
     # ---- id tables -------------------------------------------------------------------------------------------
     def build_ids(self) -> None:
@@ -251,7 +255,11 @@ class _Compiler:
             w[t >> 5] |= 1 << (t & 31)
         return [x - (1 << 32) if x >= (1 << 31) else x for x in w]
 
-    def prefix_tags(self, prefix: str) -> list[int]:  # mettagrid_c_config.py:74-75
+    def prefix_tags(self, prefix, tags=None) -> list[int]:  # mettagrid_c_config.py:74-75
+        if tags is not None:          # explicit names (a config that already went through the reference's converter)
+            return [self.tag_id[n] for n in tags]
+        if isinstance(prefix, tuple):
+            return [self.tag_id[n] for n in prefix]
         return [i for n, i in self.tag_id.items() if n.startswith(prefix)]
 
     # ---- game values -----------------------------------------------------------------------------------------
@@ -381,10 +389,10 @@ class _Compiler:
         elif isinstance(f, S.ResourceFilter):
             self._atom(K.FOP_RESOURCE, self.ent(f.entity), self.res_id[f.resource], f.min_amount, on_true, on_false)
         elif isinstance(f, S.SharedTagPrefixFilter):
-            off = self.emit_words(self.tag_mask_words(self.prefix_tags(f.prefix)))
+            off = self.emit_words(self.tag_mask_words(self.prefix_tags(f.prefix, f.tags)))
             self._atom(K.FOP_SHARED_TAG, off, 0, 0, on_true, on_false)
         elif isinstance(f, S.TagPrefixFilter):
-            off = self.emit_words(self.tag_mask_words(self.prefix_tags(f.prefix)))
+            off = self.emit_words(self.tag_mask_words(self.prefix_tags(f.prefix, f.tags)))
             self._atom(K.FOP_TAG, self.ent(f.entity), off, 0, on_true, on_false)
         elif isinstance(f, S.TargetLocEmptyFilter):
             self._atom(K.FOP_TARGET_LOC_EMPTY, 0, 0, 0, on_true, on_false)
@@ -453,7 +461,7 @@ class _Compiler:
         if isinstance(m, S.RemoveTagsWithPrefix):
             self.dynamic_tags = True
             self.tag_mutations = True
-            ids = self.prefix_tags(m.prefix)
+            ids = self.prefix_tags(m.prefix, m.tags)
             return [K.MOP_REMOVE_TAGS_PREFIX, self.ent(m.entity), self.emit_words(ids) if ids else 0, len(ids), 0, 0]
         if isinstance(m, S.GameValueMutation):
             if not isinstance(m.value, (S.InventoryValue, S.StatValue)):
@@ -512,6 +520,9 @@ class _Compiler:
         return start, len(recs)
 
     def aoes(self, aoes: list) -> tuple[int, int]:
+        key = ("aoes", repr(aoes))
+        if key in self._memo:
+            return self._memo[key]
         recs = []
         for a in aoes:
             fpc = self.filters_emit(a.filters)
@@ -524,6 +535,7 @@ class _Compiler:
         start = self.counts[K.SEC_AOES]
         for r in recs:
             self.emit(K.SEC_AOES, r)
+        self._memo[key] = (start, len(recs))
         return start, len(recs)
 
     def terr_controls(self, controls: list) -> tuple[int, int]:
@@ -536,10 +548,19 @@ class _Compiler:
         return start, len(controls)
 
     # ---- handlers --------------------------------------------------------------------------------------------
-    def handler(self, h) -> int:
-        """Returns handler index or -1 (None / empty multi; mettagrid_c_config.py:405-427)."""
+    def handler(self, h, fresh: bool = False) -> int:
+        """Returns handler index or -1 (None / empty multi; mettagrid_c_config.py:405-427).  ``fresh``: always emit a
+        new record (lists of consecutive leaf handlers)."""
         if h is None:
             return -1
+        key = ("handler", repr(h))
+        if key in self._memo and not fresh:
+            return self._memo[key]
+        hid = self._handler(h)
+        self._memo[key] = hid
+        return hid
+
+    def _handler(self, h) -> int:
         if isinstance(h, S.Handler):
             fpc = self.filters_emit(h.filters)
             muts = [self.mutation(m) for m in h.mutations]
@@ -566,6 +587,9 @@ class _Compiler:
         per-resource pointer; drop order follows the iteration order of the `_limits` unordered_map
         (inventory.cpp:141-173) which this computes with the libstdc++ emulator.
         """
+        key = ("limits", repr(limit_defs))
+        if key in self._memo:
+            return self._memo[key]
         start = self.counts[K.SEC_LIMITS]
         owner: dict[int, int] = {}
         lim_map = UMap()
@@ -590,11 +614,15 @@ class _Compiler:
             for r in reachable:
                 self.emit(K.SEC_DROP_ORDER, [r])
             self.emit(K.SEC_LIMITS, [mask, mn, mx, mstart, len(mods), dstart, len(reachable)])
-        return start, len(limit_defs), res_limit, mod_mask
+        self._memo[key] = (start, len(limit_defs), res_limit, mod_mask)
+        return self._memo[key]
 
     def init_inventory(self, initial: dict, keep_zero: bool) -> tuple[int, int]:
         """(item, amount) list in the order the reference's constructors insert them: iteration order of the
         config-side unordered_map that pybind11 builds from the Python dict."""
+        key = ("init_inv", repr(list(initial.items())), keep_zero)
+        if key in self._memo:
+            return self._memo[key]
         ids = [self.res_id[k] for k in initial if k in self.res_id]
         amounts = {self.res_id[k]: int(v) for k, v in initial.items() if k in self.res_id}
         order = from_pydict(ids).keys()
@@ -604,6 +632,7 @@ class _Compiler:
             if amounts[item] > 0 or keep_zero:
                 self.emit(K.SEC_INIT_INV, [item, amounts[item]])
                 n += 1
+        self._memo[key] = (start, n)
         return start, n
 
     def emit_class(self, *, kind, type_id, vibe, group, on_use, on_tick, on_after_use, lim, init_inv, rewards,
@@ -781,14 +810,18 @@ class _Compiler:
                 for rn in sp.resource_names:
                     if rn not in configured:
                         limit_defs.append(([self.res_id[rn]], default_limit, 65535, {}))
-                rstart = self.counts[K.SEC_REWARDS]
-                for rw in a.rewards:
-                    gstart, gcount = self.gv_emit(rw.value)
-                    ts, tid = -1, -1
-                    if isinstance(rw.value, S.StatValue):  # resolved (and the key created) at init: reward.hpp:45-53
-                        ts = 0 if rw.value.scope == "agent" else 1
-                        tid = self.stat(rw.value.scope, rw.value.name)
-                    self.emit(K.SEC_REWARDS, [gstart, gcount, 1 if rw.per_tick else 0, ts, tid])
+                rkey = ("rewards", repr(a.rewards))
+                if rkey in self._memo:
+                    rstart = self._memo[rkey]
+                else:
+                    rstart = self._memo[rkey] = self.counts[K.SEC_REWARDS]
+                    for rw in a.rewards:
+                        gstart, gcount = self.gv_emit(rw.value)
+                        ts, tid = -1, -1
+                        if isinstance(rw.value, S.StatValue):  # resolved (and the key created) at init: reward.hpp:45-53
+                            ts = 0 if rw.value.scope == "agent" else 1
+                            tid = self.stat(rw.value.scope, rw.value.name)
+                        self.emit(K.SEC_REWARDS, [gstart, gcount, 1 if rw.per_tick else 0, ts, tid])
                 cell = f"agent.{gname}.{idx}"
                 cid = self.emit_class(
                     kind=K.KIND_AGENT, type_id=self.type_id[a.name], vibe=a.vibe, group=gid,
@@ -885,13 +918,13 @@ class _Compiler:
             self.emit(K.SEC_MATQ, [self.tag_id[mq.tag], self.query(mq.query)])
         # ---- territories (territory_tracker.cpp:72-100) ----
         def leaf_list(handlers) -> tuple[int, int]:
-            ids = [self.handler(S.Handler(h.filters, h.mutations, "t")) for h in handlers]
+            ids = [self.handler(S.Handler(h.filters, h.mutations, "t"), fresh=True) for h in handlers]
             for a, b in zip(ids, ids[1:]):
                 assert b == a + 1
             return (ids[0] if ids else 0), len(ids)
         for name, tc in sp.territories.items():
             self.dynamic_tags = True
-            tg = self.prefix_tags(tc.tag_prefix)
+            tg = self.prefix_tags(tc.tag_prefix, tc.tags)
             toff = self.emit_words(tg) if tg else 0
             es, ec = leaf_list(tc.on_enter)
             xs, xc = leaf_list(tc.on_exit)

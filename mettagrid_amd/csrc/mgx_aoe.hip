@@ -16,8 +16,8 @@
 #include "mgx_world.h"
 
 #define MGX_AOE_THREADS 256
-__global__ void __launch_bounds__(MGX_AOE_THREADS) mgx_aoe_kernel(MgxDev d) {
-  MGX_KERNARG_ENTRY(d);
+__global__ void __launch_bounds__(MGX_AOE_THREADS) mgx_aoe_kernel(const MgxDev* __restrict__ dp) {
+  const MgxDev& d = *dp;  // per-engine copy in device memory (see mgx_world_x.hip)
   extern __shared__ __align__(16) uint8_t aoe_lds[];
   const int wave = (int)threadIdx.x / MGX_WAVE, lane = (int)threadIdx.x & (MGX_WAVE - 1);
   const int env = (int)blockIdx.x * (MGX_AOE_THREADS / MGX_WAVE) + wave;
@@ -31,7 +31,8 @@ __global__ void __launch_bounds__(MGX_AOE_THREADS) mgx_aoe_kernel(MgxDev d) {
 }
 
 // One thread per (env, registered AoE source): the packed (location, radius, live) record aoe_local_agent scans.
-__global__ void __launch_bounds__(256) mgx_aoe_prep_kernel(MgxDev d) {
+__global__ void __launch_bounds__(256) mgx_aoe_prep_kernel(const MgxDev* __restrict__ dp) {
+  const MgxDev& d = *dp;
   const int per = d.NF + d.NM;
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= (long long)d.E * per) return;
@@ -39,11 +40,11 @@ __global__ void __launch_bounds__(256) mgx_aoe_prep_kernel(MgxDev d) {
   e.aoe_pack_source((int)(idx % per));
 }
 
-void mgx_launch_aoe(hipStream_t stream, const MgxDev& d) {
+void mgx_launch_aoe(hipStream_t stream, const MgxDev& d, const MgxDev* dp) {
   const long long sources = (long long)d.E * (d.NF + d.NM);
-  if (sources > 0) hipLaunchKernelGGL(mgx_aoe_prep_kernel, dim3((unsigned)((sources + 255) / 256)), dim3(256), 0, stream, d);
+  if (sources > 0) hipLaunchKernelGGL(mgx_aoe_prep_kernel, dim3((unsigned)((sources + 255) / 256)), dim3(256), 0, stream, dp);
   const int epb = MGX_AOE_THREADS / MGX_WAVE;
-  hipLaunchKernelGGL(mgx_aoe_kernel, dim3((d.E + epb - 1) / epb), dim3(MGX_AOE_THREADS), 28 * MGX_AOE_THREADS * 4, stream, d);
+  hipLaunchKernelGGL(mgx_aoe_kernel, dim3((d.E + epb - 1) / epb), dim3(MGX_AOE_THREADS), 28 * MGX_AOE_THREADS * 4, stream, dp);
 }
 
 // Host analysis: true when every AoE record and every territory handler of the program is "target-local" — its filters

@@ -45,6 +45,24 @@ static bool g_trace = getenv("MGX_TRACE") != nullptr;
   do {                                                                             \
     if (g_trace) { (void)hipStreamSynchronize((e)->stream); fprintf(stderr, "[mgx] done: %s\n", what); fflush(stderr); } \
   } while (0)
+// Agent::set_inventory (objects/agent.cpp:86-104) for one agent: a single work-item, the same Inventory::update code
+// the world kernels use.
+__global__ void mgx_set_inventory_kernel(const MgxDev* __restrict__ dp, int env, int agent, const int32_t* items,
+                                         const int32_t* amounts, int n) {
+  const MgxDev& d = *dp;
+  MgxEnvX e(d, d.P, env);
+  e.step = d.step[env];
+  const int slot = d.ag_obj[e.ao(agent)];
+  unsigned long long ord = d.obj_order[e.so(slot)];  // iterate a copy of the current items
+  for (int k = 0; k < 16; k++) {
+    const int item = (int)((ord >> (4 * k)) & 0xF);
+    if (item == 0xF) break;
+    e.inv_update<1>(slot, item, -(int)e.inv(slot, item));
+    e.astat_set(agent, d.wk[MGX_S_RES_AMOUNT_BASE] + item, 0.f);
+  }
+  for (int i = 0; i < n; i++) e.inv_update<1>(slot, items[i], amounts[i] - (int)e.inv(slot, items[i]));
+}
+
 static thread_local std::string g_err;
 static int fail(int code, const std::string& msg) {
   g_err = msg;
@@ -59,6 +77,9 @@ static int fail(int code, const std::string& msg) {
 
 struct mgx_engine {
   MgxDev d{};
+  MgxDev* d_dev = nullptr;     // copy of `d` in device memory for the kernels that take it by pointer (extended path)
+  MgxDev d_dev_host{};         // what d_dev holds
+  bool d_dev_valid = false;
   int device = 0;
   hipStream_t stream = nullptr;
   std::vector<void*> allocs;
@@ -78,6 +99,7 @@ struct mgx_engine {
   int pool_tokens = 0;   // capacity of the LDS token pool (entries), including the class-tag prefix
   int pool_prefix = 0;   // entries of the per-class static tag table at the head of the pool
   bool prog_in_lds = false;
+  int prog_lds_words = 0;   // program words in front of the schedule section (what the world kernels copy into LDS)
   int obs_blk_start = 0, obs_blk_words = 0;  // program block the observation kernel interprets
   bool obs_blk_lds = false;
   std::vector<int> class_list_tokens;  // worst-case per-step token list length per class (0: static class)
@@ -172,6 +194,15 @@ static void launch_obs_t(mgx_engine* e, bool with_rewards, const uint8_t* mask) 
   else
     hipLaunchKernelGGL((mgx_obs_kernel<false, X, PL>), grid, block, e->lds_obs, e->stream, dd, e->pool_tokens, e->pool_prefix, mask, e->obs_blk_start, e->obs_blk_words, (int)e->rewards_early);
 }
+// Device-memory copy of e->d, brought up to date (stream-ordered) whenever the host table changed.
+static const MgxDev* dev_copy(mgx_engine* e) {
+  if (!e->d_dev_valid || memcmp(&e->d_dev_host, &e->d, sizeof(MgxDev)) != 0) {
+    (void)hipMemcpyAsync(e->d_dev, &e->d, sizeof(MgxDev), hipMemcpyHostToDevice, e->stream);
+    memcpy(&e->d_dev_host, &e->d, sizeof(MgxDev));
+    e->d_dev_valid = true;
+  }
+  return e->d_dev;
+}
 static int launch_terr(mgx_engine* e) {  // refresh the ownership maps of the envs whose territory sources changed
   if (e->d.X && e->d.NT > 0 && e->d.terr_owner) {
     hipLaunchKernelGGL(mgx_terr_kernel, dim3(e->d.E), dim3(256), 8 * 256 * 8, e->stream, e->d);
@@ -187,7 +218,7 @@ static int launch_obs(mgx_engine* e, bool with_rewards, const uint8_t* mask = nu
   int trc = launch_terr(e);
   if (trc) return trc;
   MGX_TRACE_POINT(e, "terr kernel");
-  if (e->d.obsval) mgx_launch_values(e->stream, e->d, 0, mask);
+  if (e->d.obsval) mgx_launch_values(e->stream, e->d, dev_copy(e), 0, mask);
   MGX_TRACE_POINT(e, "values kernel");
   if (e->rewards_ext) with_rewards = false;
   if (e->d.X) launch_obs_t<true, false>(e, with_rewards, mask);
@@ -373,6 +404,7 @@ int mgx_create(const int32_t* program, size_t program_words, const uint16_t* cla
     A_(e->alloc(&d.qws, E * d.QB * S));
     A_(e->alloc(&d.qvis, E * (d.QD + 1) * d.SW));
   }
+  A_(e->alloc(&e->d_dev, 1));
   A_(e->alloc(&dmaps, E * HW));
   A_(e->alloc(&dseeds, E));
   A_(e->alloc(&e->dmask, E));
@@ -384,11 +416,16 @@ int mgx_create(const int32_t* program, size_t program_words, const uint16_t* cla
 
   e->verbose = getenv("MGX_VERBOSE") != nullptr;
   e->lds_world = d.X ? mgx_world_x_lds_bytes(d.A) : mgx_world_fast_lds_bytes(d.A);
-  e->prog_in_lds = program_words * 4 + e->lds_world <= 40 * 1024;  // 4 workgroups per CU (160 KB LDS) keep their copy
+  // The world kernels copy the program — everything in front of the schedule, the last and only section that grows with
+  // the episode length — into LDS when it leaves room for 4 (lean) / 3 (extended) workgroups per CU (160 KB LDS).
+  // (Rung 4, measured: the copy at 2 workgroups per CU is slower than the program in HBM at 3: 9.8 against 8.4 ms.)
+  e->prog_lds_words = (int)((d.sec[MGX_SEC_SCHEDULE] + 3) & ~3);
+  e->prog_in_lds = (size_t)e->prog_lds_words * 4 + e->lds_world <= (size_t)(d.X ? 53 : 40) * 1024;
+  if (const char* o = getenv("MGX_PROG_LDS")) e->prog_in_lds = e->prog_in_lds && atoi(o) != 0;
 #ifdef MGX_CPU_EMU
   e->prog_in_lds = false;  // the LDS copy needs a workgroup barrier; the sanitizer build runs work-items one by one
 #endif
-  if (e->prog_in_lds) e->lds_world += program_words * 4;
+  if (e->prog_in_lds) e->lds_world += (size_t)e->prog_lds_words * 4;
   if (getenv("MGX_VERBOSE"))
     fprintf(stderr, "[mgx] E=%d A=%d S=%d program=%zu B world: X=%d prog_in_lds=%d lds=%zu B\n", d.E, d.A, d.S,
             program_words * 4, d.X, (int)e->prog_in_lds, e->lds_world);
@@ -526,7 +563,7 @@ int mgx_create(const int32_t* program, size_t program_words, const uint16_t* cla
   if (he != hipSuccess) { mgx_destroy(e); return fail(MGX_ERR_HIP, std::string("mgx_create upload: ") + hipGetErrorString(he)); }
   e->dmaps = dmaps;
   e->dseeds = dseeds;
-  hipLaunchKernelGGL(mgx_init_kernel, dim3((d.E + MGX_WAVE - 1) / MGX_WAVE), dim3(MGX_WAVE), 0, e->stream, e->d, dmaps, dseeds,
+  hipLaunchKernelGGL(mgx_init_kernel, dim3((d.E + MGX_WAVE - 1) / MGX_WAVE), dim3(MGX_WAVE), 0, e->stream, dev_copy(e), dmaps, dseeds,
                      (const uint8_t*)nullptr);
   he = hipGetLastError();
   if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
@@ -620,7 +657,7 @@ int mgx_reset_envs(mgx_engine* e, const uint8_t* env_mask, const uint16_t* class
   hipLaunchKernelGGL(mgx_fill_rows_kernel, dim3(1, (unsigned)E), dim3(256), 0, e->stream, (uint8_t*)d.truncations, A, 0, (const uint8_t*)e->dmask, (int)E);
   hipLaunchKernelGGL(mgx_fill_rows_kernel, dim3(1, (unsigned)E), dim3(256), 0, e->stream, (uint8_t*)d.rewards, A * 4, 0, (const uint8_t*)e->dmask, (int)E);
   HIP_TRY(hipGetLastError());
-  hipLaunchKernelGGL(mgx_init_kernel, dim3((d.E + MGX_WAVE - 1) / MGX_WAVE), dim3(MGX_WAVE), 0, e->stream, e->d, e->dmaps, e->dseeds,
+  hipLaunchKernelGGL(mgx_init_kernel, dim3((d.E + MGX_WAVE - 1) / MGX_WAVE), dim3(MGX_WAVE), 0, e->stream, dev_copy(e), e->dmaps, e->dseeds,
                      (const uint8_t*)e->dmask);
   HIP_TRY(hipGetLastError());
   int rc = launch_obs(e, false, e->dmask);
@@ -652,25 +689,25 @@ int mgx_step(mgx_engine* e) {
 #define MGX_MARK(k) do { if (e->profiling) HIP_TRY(hipEventRecord(e->ev[k], e->stream)); } while (0)
   MGX_MARK(0);
   {
-    const int pw = (int)e->prog.size();
+    const int pw = e->prog_lds_words;
     MGX_TRACE_POINT(e, "before world");
     if (!d.X) {
       if (e->slot == 0) mgx_launch_world_fast_s0(e->prog_in_lds, e->lds_world, e->stream, e->d, pw);
       else mgx_launch_world_fast_s1(e->prog_in_lds, e->lds_world, e->stream, e->d, pw);
       MGX_MARK(1); MGX_MARK(2); MGX_MARK(3);
     } else if (e->aoe_local && (d.NF > 0 || d.NM > 0 || d.NT > 0)) {
-      mgx_launch_world_x(e->prog_in_lds, e->lds_world, e->stream, e->d, pw, MGX_PH_ACTIONS);
+      mgx_launch_world_x(e->prog_in_lds, e->lds_world, e->stream, e->d, dev_copy(e), pw, MGX_PH_ACTIONS);
       MGX_TRACE_POINT(e, "world kernel (actions)");
       MGX_MARK(1);
       int trc = launch_terr(e);  // the per-agent territory effects read the ownership map
       if (trc) return trc;
-      mgx_launch_aoe(e->stream, e->d);
+      mgx_launch_aoe(e->stream, e->d, dev_copy(e));
       MGX_TRACE_POINT(e, "aoe kernel");
       MGX_MARK(2);
-      mgx_launch_world_x(e->prog_in_lds, e->lds_world, e->stream, e->d, pw, MGX_PH_TAIL);
+      mgx_launch_world_x(e->prog_in_lds, e->lds_world, e->stream, e->d, dev_copy(e), pw, MGX_PH_TAIL);
       MGX_MARK(3);
     } else {
-      mgx_launch_world_x(e->prog_in_lds, e->lds_world, e->stream, e->d, pw, MGX_PH_ALL);
+      mgx_launch_world_x(e->prog_in_lds, e->lds_world, e->stream, e->d, dev_copy(e), pw, MGX_PH_ALL);
       MGX_MARK(1); MGX_MARK(2); MGX_MARK(3);
     }
     MGX_TRACE_POINT(e, "world kernel");
@@ -680,7 +717,7 @@ int mgx_step(mgx_engine* e) {
   if (rc) return rc;
   MGX_TRACE_POINT(e, "obs kernel");
   MGX_MARK(4);
-  if (e->rewards_ext) { mgx_launch_values(e->stream, e->d, 1, nullptr); HIP_TRY(hipGetLastError()); }
+  if (e->rewards_ext) { mgx_launch_values(e->stream, e->d, dev_copy(e), 1, nullptr); HIP_TRY(hipGetLastError()); }
   MGX_MARK(5);
 #undef MGX_MARK
   if (e->mem_kind == MGX_MEM_HOST) {
@@ -810,11 +847,61 @@ int mgx_get_reward_state(mgx_engine* e, int32_t env, float* out) {
   if (!r) r = d2h(e, cls.data(), d.obj_cls + (size_t)env * d.S, (size_t)d.S * 2);
   if (r) return r;
   for (int a = 0; a < d.A; a++) {
-    int n = e->prog[d.sec[MGX_SEC_CLASSES] + cls[ag_obj[a]] * MGX_C_WORDS + MGX_C_REWARD_COUNT];
+    const uint16_t c = ag_obj[a] < d.S ? cls[ag_obj[a]] : (uint16_t)MGX_DEAD_CLASS;
+    int n = c == MGX_DEAD_CLASS ? 0 : e->prog[d.sec[MGX_SEC_CLASSES] + c * MGX_C_WORDS + MGX_C_REWARD_COUNT];
     float t = 0.f;
     for (int k = 0; k < n; k++) t += prev[(size_t)a * d.NRW + k];
     out[a] = t;
   }
+  return MGX_OK;
+}
+
+int mgx_set_inventory(mgx_engine* e, int32_t env, int32_t agent_id, const int32_t* items, const int32_t* amounts, int32_t n) {
+  if (!e || env < 0 || env >= e->d.E || n < 0 || (n > 0 && (!items || !amounts)))
+    return fail(MGX_ERR_BAD_ARG, "mgx_set_inventory: bad argument");
+  if (agent_id < 0 || agent_id >= e->d.A) return MGX_OK;  // the reference ignores unknown agent ids (mettagrid_py.cpp:205)
+  for (int i = 0; i < n; i++)
+    if (items[i] < 0 || items[i] >= e->d.R || amounts[i] < 0 || amounts[i] > 65535)
+      return fail(MGX_ERR_BAD_ARG, "mgx_set_inventory: resource id or amount out of range");
+  HIP_TRY(hipSetDevice(e->device));
+  int32_t* dbuf = nullptr;
+  if (n > 0) {
+    HIP_TRY(hipMalloc((void**)&dbuf, (size_t)n * 8));
+    HIP_TRY(hipMemcpyAsync(dbuf, items, (size_t)n * 4, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemcpyAsync(dbuf + n, amounts, (size_t)n * 4, hipMemcpyHostToDevice, e->stream));
+  }
+  hipLaunchKernelGGL(mgx_set_inventory_kernel, dim3(1), dim3(1), 0, e->stream, dev_copy(e), env, agent_id,
+                     (const int32_t*)dbuf, (const int32_t*)(dbuf + n), n);
+  hipError_t le = hipGetLastError();
+  hipError_t se = hipStreamSynchronize(e->stream);
+  if (dbuf) (void)hipFree(dbuf);
+  if (le != hipSuccess || se != hipSuccess) return fail(MGX_ERR_HIP, "mgx_set_inventory: kernel failed");
+  return MGX_OK;
+}
+
+int mgx_count_objects_with_tag(mgx_engine* e, int32_t env, int32_t tag_id, int32_t* out) {
+  if (!e || !out || env < 0 || env >= e->d.E) return fail(MGX_ERR_BAD_ARG, "mgx_count_objects_with_tag: bad argument");
+  *out = 0;
+  if (tag_id < 0 || tag_id >= 256) return MGX_OK;
+  const MgxDev& d = e->d;
+  const size_t S = d.S;
+  uint32_t n = 0;
+  std::vector<uint16_t> cls(S);
+  std::vector<uint8_t> oflags(S, 0);
+  std::vector<uint32_t> tags(d.obj_tags ? S * MGX_TAG_WORDS : 0);
+  int r = d2h(e, &n, d.num_objs + env, 4);
+  if (!r) r = d2h(e, cls.data(), d.obj_cls + env * S, S * 2);
+  if (!r && d.obj_flags) r = d2h(e, oflags.data(), d.obj_flags + env * S, S);
+  if (!r && d.obj_tags) r = d2h(e, tags.data(), d.obj_tags + env * S * MGX_TAG_WORDS, S * MGX_TAG_WORDS * 4);
+  if (r) return r;
+  int count = 0;
+  for (uint32_t s = 0; s < n; s++) {
+    if (cls[s] == MGX_DEAD_CLASS || (oflags[s] & 1)) continue;  // removed objects are unregistered (tag_index.cpp:21-31)
+    const uint32_t w = d.obj_tags ? tags[s * MGX_TAG_WORDS + (tag_id >> 5)]
+                                  : (uint32_t)e->prog[d.sec[MGX_SEC_CLASSES] + cls[s] * MGX_C_WORDS + MGX_C_TAGS + (tag_id >> 5)];
+    count += (w >> (tag_id & 31)) & 1u;
+  }
+  *out = count;
   return MGX_OK;
 }
 

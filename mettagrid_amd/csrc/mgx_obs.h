@@ -103,7 +103,7 @@ __host__ __device__ inline int mgx_align16(int x) { return (x + 15) & ~15; }
 struct MgxObsLds {
   int grid, offs, loc, minobs, visited, tokinfo, dyn, agents, aginfo, spawn, vstat, written, rwinfo, misc, pool, rows, row_words,
       row_pitch, cell, vj, vcount, cp, blk, gtok, total;
-  int owner, obsval, tscore, vmask;  // X only: per-cell territory owner u16[HW] (overlaid), obs values u32[A][NOV], mask list
+  int owner, obsval, tscore, vmask, agtags;  // X only: per-cell territory owner u16[HW] (overlaid), obs values u32[A][NOV], mask list
 };
 // Upper bound of the global (location 0xFE) tokens of one agent: completion, last action, last action move, last
 // reward, two local-position tokens and every digit of every obs value (a u32 has at most 32 digits in base 2).
@@ -151,9 +151,10 @@ __host__ __device__ inline MgxObsLds mgx_obs_lds_layout(int HW, int NOFF, int S,
   l.cell = o; o += mgx_align16(A * l.cp * 2);
   l.vj = o; o += mgx_align16(A * l.cp);
   l.vcount = o; o += mgx_align16(A * 4);
-  l.vmask = l.obsval = l.tscore = 0;
+  l.vmask = l.obsval = l.tscore = l.agtags = 0;
   if (X) {
     l.vmask = o; o += mgx_align16(A * l.cp);   // per visible cell: 0 no territory token, 1 friendly, 2 foreign owner
+    l.agtags = o; o += mgx_align16(A * MGX_TAG_WORDS * 4);  // the agents' own tag bitsets (friend / foe of a cell's owner tag)
     l.obsval = o; o += mgx_align16((A * NOV + 1) * 4);
   }
   if (!blk_early) { l.blk = o; o += mgx_align16(blk_words * 4); }
@@ -219,6 +220,7 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
   const int sid_visited = d.wk[MGX_S_CELL_VISITED];
   uint16_t* s_owner = (uint16_t*)(smem + L.owner);
   uint8_t* s_vmask = smem + L.vmask;
+  uint32_t* s_agtags = (uint32_t*)(smem + L.agtags);
   uint32_t* s_obsval = (uint32_t*)(smem + L.obsval);
   const bool want_mask = X && d.aoe_mask_feat != 0 && d.NT > 0;
   // Program view of the interpreted sections: LDS copy (PL) or the blob itself.
@@ -481,6 +483,12 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
         for (int ti = 0; ti < d.NT && owner == 0xFFFF; ti++) owner = d.terr_owner[((size_t)env * d.NT + ti) * (size_t)HW + cellidx];
         s_owner[cellidx] = owner;
       }
+      // the observers' own tag bitsets, once per env instead of one HBM round trip per masked window cell
+      for (int i = tid; i < A * MGX_TAG_WORDS; i += MGX_OBS_THREADS) {
+        const int slot = (int)(s_agents[i / MGX_TAG_WORDS] & 0xFFFF);
+        s_agtags[i] = d.obj_tags ? d.obj_tags[e.so(slot) * MGX_TAG_WORDS + (i % MGX_TAG_WORDS)]
+                                 : (uint32_t)e.cls_of(slot)[MGX_C_TAGS + (i % MGX_TAG_WORDS)];
+      }
     }
     if (d.obsval)  // query-backed obs values: evaluated by mgx_values_kernel (one env per lane) right before this kernel
       for (int i = tid; i < A * d.n_obs_values; i += MGX_OBS_THREADS) s_obsval[i] = d.obsval[(size_t)env * A * d.n_obs_values + i];
@@ -561,7 +569,7 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
         if constexpr (X) {
           if (want_mask && inb) {
             const uint16_t ow = s_owner[r * d.W + c];
-            if (ow != 0xFFFF) { mv = e.has_tag((int)(ag & 0xFFFF), ow) ? 1u : 2u; keep = true; }  // mask-only cells still emit one token
+            if (ow != 0xFFFF) { mv = ((s_agtags[a * MGX_TAG_WORDS + (ow >> 5)] >> (ow & 31)) & 1u) ? 1u : 2u; keep = true; }  // mask-only cells still emit one token
           }
         }
         if (step > 0 && cs) atomicMin(&s_minobs[cs - 1], (uint32_t)a);

@@ -1384,7 +1384,7 @@ struct MgxEnvT {  // per-lane view of one env
     return 0;
   }
   __device__ void process_events() const {
-    PP sc = prog() + d.sec[MGX_SEC_SCHEDULE];
+    const int32_t* sc = d.P + d.sec[MGX_SEC_SCHEDULE];  // always from HBM: not part of the LDS program copy
     uint32_t k = d.next_event[envi()];
     while (k < (uint32_t)d.n_schedule && (uint32_t)sc[k * MGX_SC_WORDS + MGX_SC_TIMESTEP] <= step) {
       execute_event(sc[k * MGX_SC_WORDS + MGX_SC_EVENT]);
@@ -2277,21 +2277,21 @@ void mgx_launch_world_fast_s1(bool prog_lds, size_t lds, hipStream_t stream, con
 bool mgx_world_fast_set_lds_s0(size_t lds);  // raises the kernels' dynamic LDS limit (needed past 64 KB)
 bool mgx_world_fast_set_lds_s1(size_t lds);
 // ... and of the extended one (mgx_world_x.hip)
-void mgx_launch_world_x(bool prog_lds, size_t lds, hipStream_t stream, const MgxDev& d, int prog_words, int phases);
+void mgx_launch_world_x(bool prog_lds, size_t lds, hipStream_t stream, const MgxDev& d, const MgxDev* dev_copy, int prog_words, int phases);
 bool mgx_world_x_set_lds(size_t lds);
 size_t mgx_world_x_lds_bytes(int A);
 size_t mgx_world_x_private_bytes();
-void mgx_launch_values(hipStream_t stream, const MgxDev& d, int phase, const uint8_t* env_mask);
+void mgx_launch_values(hipStream_t stream, const MgxDev& d, const MgxDev* dev_copy, int phase, const uint8_t* env_mask);
 // lane-per-agent area effects (mgx_aoe.hip) and the host analysis that allows them
-void mgx_launch_aoe(hipStream_t stream, const MgxDev& d);
+void mgx_launch_aoe(hipStream_t stream, const MgxDev& d, const MgxDev* dev_copy);
 bool mgx_aoe_is_target_local(const int32_t* program);
 
 #ifndef MGX_WORLD_FAST_TU
 // Construction: MettaGrid ctor + _init_grid (mettagrid_c.cpp:42-191, 200-269).  One lane per env scans the class
 // map in row-major order; object slot = reference object id - 1; agent index = order of appearance.
-__global__ void __launch_bounds__(MGX_WAVE) mgx_init_kernel(MgxDev d, const uint16_t* class_maps, const uint32_t* seeds,
-                                                            const uint8_t* env_mask) {
-  MGX_KERNARG_ENTRY(d);
+__global__ void __launch_bounds__(MGX_WAVE) mgx_init_kernel(const MgxDev* __restrict__ dp, const uint16_t* class_maps,
+                                                            const uint32_t* seeds, const uint8_t* env_mask) {
+  const MgxDev& d = *dp;  // per-engine copy in device memory (see mgx_world_x.hip)
   const int env = blockIdx.x * MGX_WAVE + threadIdx.x;
   if (env >= d.E) return;
   if (env_mask && !env_mask[env]) return;

@@ -1,7 +1,10 @@
 // mgx_world_x.hip — the extended world-update kernel (rung 4: dynamic tags, tag index, queries, events, AoE,
 // territory, run-time object creation).  One env per lane like the lean kernel, but the handler VM keeps its frames and
 // handler contexts in LDS (MgxEnvT::vm_run) so that tag lifecycle handlers, materialized-query recomputation and
-// UseTarget nest without recursion.  A few large functions stay real calls (MGX_OUTLINE: vm_run, check_filters<Q>,
+// UseTarget nest without recursion.  These kernels take the engine's MgxDev through a POINTER to a per-engine copy in
+// device memory, not by value: with out-of-line functions holding a reference to it, a by-value argument is copied into
+// every lane's private memory (992 B of scratch) and each field access becomes a scratch load followed by a flat access.
+// A few large functions stay real calls (MGX_OUTLINE: vm_run, check_filters<Q>,
 // eval_code<Q>, eval_query<Q> — one instance each, bounded static call depth); everything else is inlined.
 #define MGX_BIG __forceinline__
 #define MGX_OUTLINE __noinline__
@@ -24,9 +27,8 @@
 #include "mgx_world.h"
 
 template <bool PROG_LDS>
-__global__ void __launch_bounds__(MGX_WORLD_THREADS) mgx_world_kernel_x(MgxDev d, int prog_words, int phases) {
-  MGX_KERNARG_ENTRY(d);
-  mgx_world_entry<PROG_LDS, true>(d, prog_words, phases);
+__global__ void __launch_bounds__(MGX_WORLD_THREADS) mgx_world_kernel_x(const MgxDev* __restrict__ dp, int prog_words, int phases) {
+  mgx_world_entry<PROG_LDS, true>(*dp, prog_words, phases);
 }
 
 // Game values with query operands (QueryInventoryValue / QueryCountValue) outside the world update: the global
@@ -34,8 +36,8 @@ __global__ void __launch_bounds__(MGX_WORLD_THREADS) mgx_world_kernel_x(MgxDev d
 // (phase 1, after it — RewardHelper::compute_entries, systems/reward.hpp:56-77, mettagrid_c.cpp:1070-1096).  Queries
 // share one workspace per env, so an env is walked by one lane, agents in index order.  Games without such values
 // never launch this kernel: the observation kernel evaluates plain values itself, one agent per lane.
-__global__ void __launch_bounds__(MGX_WORLD_THREADS) mgx_values_kernel(MgxDev d, int phase, const uint8_t* env_mask) {
-  MGX_KERNARG_ENTRY(d);
+__global__ void __launch_bounds__(MGX_WORLD_THREADS) mgx_values_kernel(const MgxDev* __restrict__ dp, int phase, const uint8_t* env_mask) {
+  const MgxDev& d = *dp;
   const int lane = mgx_world_lane();
   const bool active = (threadIdx.x & (MGX_WAVE - 1)) < MGX_WORLD_LPW;
   const int env = blockIdx.x * MGX_WORLD_EPG + lane;
@@ -75,9 +77,9 @@ __global__ void __launch_bounds__(MGX_WORLD_THREADS) mgx_values_kernel(MgxDev d,
     }
   }
 }
-void mgx_launch_values(hipStream_t stream, const MgxDev& d, int phase, const uint8_t* env_mask) {
+void mgx_launch_values(hipStream_t stream, const MgxDev& d, const MgxDev* dp, int phase, const uint8_t* env_mask) {
   dim3 grid((d.E + MGX_WORLD_EPG - 1) / MGX_WORLD_EPG), block(MGX_WORLD_THREADS);
-  hipLaunchKernelGGL(mgx_values_kernel, grid, block, 0, stream, d, phase, env_mask);
+  hipLaunchKernelGGL(mgx_values_kernel, grid, block, 0, stream, dp, phase, env_mask);
 }
 
 static std::mutex g_lds_mutex;
@@ -102,8 +104,8 @@ size_t mgx_world_x_private_bytes() {  // per-lane private segment of the build (
   return m;
 }
 
-void mgx_launch_world_x(bool prog_lds, size_t lds, hipStream_t stream, const MgxDev& d, int prog_words, int phases) {
+void mgx_launch_world_x(bool prog_lds, size_t lds, hipStream_t stream, const MgxDev& d, const MgxDev* dp, int prog_words, int phases) {
   dim3 grid((d.E + MGX_WORLD_EPG - 1) / MGX_WORLD_EPG), block(MGX_WORLD_THREADS);
-  if (prog_lds) hipLaunchKernelGGL((mgx_world_kernel_x<true>), grid, block, lds, stream, d, prog_words, phases);
-  else hipLaunchKernelGGL((mgx_world_kernel_x<false>), grid, block, lds, stream, d, prog_words, phases);
+  if (prog_lds) hipLaunchKernelGGL((mgx_world_kernel_x<true>), grid, block, lds, stream, dp, prog_words, phases);
+  else hipLaunchKernelGGL((mgx_world_kernel_x<false>), grid, block, lds, stream, dp, prog_words, phases);
 }

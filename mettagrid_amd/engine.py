@@ -26,7 +26,8 @@ LIB_PATH = os.environ.get("MGX_LIB") or os.path.join(_HERE, "libmgx.so")  # MGX_
 _lib = None
 OBJ_RECORD_WORDS = 42
 
-ENV_TOKEN_OVERFLOW, ENV_INVALID_KEY_RANGE, ENV_DEPTH, ENV_TOO_MANY_OBJECTS = 1, 2, 4, 8
+ENV_TOKEN_OVERFLOW, ENV_INVALID_KEY_RANGE, ENV_DEPTH, ENV_TOO_MANY_OBJECTS, ENV_TOKEN_POOL = 1, 2, 4, 8, 16
+ENV_PROXY_INVENTORY, ENV_AGENT_LIFECYCLE = 32, 64   # territory proxy given an inventory / an agent spawned or removed
 
 
 class MgxError(RuntimeError):
@@ -65,6 +66,8 @@ def load_lib():
     L.mgx_get_objects.argtypes = [vp, i32, vp, C.POINTER(i32)]
     L.mgx_get_reward_state.argtypes = [vp, i32, vp]
     L.mgx_poll_errors.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(i32)]
+    L.mgx_set_inventory.argtypes = [vp, i32, i32, vp, vp, i32]
+    L.mgx_count_objects_with_tag.argtypes = [vp, i32, i32, C.POINTER(i32)]
     L.mgx_set_profiling.argtypes = [vp, i32]
     L.mgx_get_step_timing.argtypes = [vp, vp]
     for name in ("mgx_num_envs", "mgx_num_agents", "mgx_num_tokens"):
@@ -204,6 +207,11 @@ class BatchedMettaGrid:
             raise MgxError(f"env {first}: handler / inventory-limit recursion exceeds the engine's depth")
         if bits & ENV_INVALID_KEY_RANGE:
             raise MgxError(f"env {first}: action index outside the tracked action.invalid_index window")
+        if bits & ENV_TOKEN_POOL:
+            raise MgxError(f"env {first}: the observation kernel's per-env token cache is exhausted "
+                           "(objects' token lists would be dropped from observations)")
+        if bits & (ENV_PROXY_INVENTORY | ENV_AGENT_LIFECYCLE):
+            raise MgxError(f"env {first}: a handler touched an agent's existence or a territory proxy's inventory (bits {bits})")
 
     # ---- readbacks ----
     def episode_rewards(self) -> np.ndarray:
@@ -262,6 +270,22 @@ class BatchedMettaGrid:
             out = {k: v[sl] for k, v in out.items()}
         return out
 
+    def set_inventory(self, env: int, agent_id: int, inventory: dict) -> None:
+        """``MettaGrid.set_inventory`` (cpp/bindings/mettagrid_py.cpp:203-207) for agent ``agent_id`` of env ``env``;
+        ``inventory`` maps resource ids to amounts.  The reference walks the std::unordered_map pybind11 builds from
+        the dict, so the items are applied in that map's iteration order (mettagrid_amd/umap.py)."""
+        from .umap import from_pydict
+        ids = [int(k) for k in inventory]
+        order = from_pydict(ids).keys()
+        items = np.asarray(order, dtype=np.int32)
+        amounts = np.asarray([int(inventory[k]) for k in order], dtype=np.int32)
+        _check(self.L.mgx_set_inventory(self.h, int(env), int(agent_id), items.ctypes.data, amounts.ctypes.data, len(order)))
+
+    def count_objects_with_tag(self, env: int, tag_id: int) -> int:
+        out = C.c_int32(0)
+        _check(self.L.mgx_count_objects_with_tag(self.h, int(env), int(tag_id), C.byref(out)))
+        return out.value
+
     def set_profiling(self, on: bool) -> None:
         _check(self.L.mgx_set_profiling(self.h, 1 if on else 0))
 
@@ -299,6 +323,7 @@ class MettaGrid:
         self.object_type_names = list(prog.type_names)
         self.resource_names = list(prog.resource_names)
         self._num_agents = prog.num_agents
+        self._profiling = False
 
     # -- buffers --
     def set_buffers(self, observations, terminals, truncations, rewards, actions, vibe_actions=None) -> None:
@@ -356,6 +381,45 @@ class MettaGrid:
     @property
     def current_step(self) -> int:
         return int(self._b.current_steps()[0])
+
+    def set_inventory(self, agent_id: int, inventory: dict) -> None:
+        self._b.set_inventory(0, agent_id, inventory)
+
+    def tag_index(self):
+        from .mettagrid_c import TagIndex
+        return TagIndex(self)
+
+    # -- profiling properties (cpp/bindings/profiling_py.cpp:8-30); device time of the most recent step --
+    def _timing(self) -> dict:
+        if not self._profiling:
+            self._b.set_profiling(True)
+            self._profiling = True
+            return {k: 0.0 for k in self._b.TIMING_SEGMENTS}
+        try:
+            return self._b.step_timing_segments_ms()
+        except (MgxError, ValueError, RuntimeError):
+            return {k: 0.0 for k in self._b.TIMING_SEGMENTS}
+
+    @property
+    def step_timing(self):
+        """StepTimingStats: the fields of the reference's struct, filled from the engine's timing segments (a segment
+        that covers several reference phases is reported under the first of them; see include/mgx.h MGX_T_*)."""
+        t = self._timing()
+        ns = {k: int(v * 1e6) for k, v in t.items()}
+        from types import SimpleNamespace
+        return SimpleNamespace(reset_ns=0, events_ns=0, actions_ns=ns["actions"], on_tick_ns=ns["tail"], aoe_ns=ns["aoe"],
+                               observations_ns=ns["obs"], rewards_ns=ns["rewards"], truncation_ns=0, total_ns=sum(ns.values()))
+
+    @property
+    def last_obs_time_ns(self) -> int:
+        return int(self._timing()["obs"] * 1e6)
+
+    @property
+    def obs_validation_stats(self):
+        """The reference compares its two observation code paths when validation is compiled in; there is one path
+        here, so the counters stay zero."""
+        from types import SimpleNamespace
+        return SimpleNamespace(comparison_count=0, mismatch_count=0, original_time_ns=0, optimized_time_ns=0)
 
     def grid_objects(self, min_row=-1, max_row=-1, min_col=-1, max_col=-1, ignore_types=()):
         objs = self._b.grid_objects(0)

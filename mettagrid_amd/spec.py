@@ -140,12 +140,14 @@ class ResourceFilter:
 @dataclass
 class SharedTagPrefixFilter:
     prefix: str
+    tags: Optional[list] = None   # explicit tag names (what the reference's C++ config carries); overrides the prefix
 
 
 @dataclass
 class TagPrefixFilter:
     entity: str
     prefix: str
+    tags: Optional[list] = None
 
 
 @dataclass
@@ -257,6 +259,7 @@ class RemoveTag:
 class RemoveTagsWithPrefix:
     entity: str
     prefix: str
+    tags: Optional[list] = None   # explicit tag names, in removal order
 
 
 @dataclass
@@ -373,6 +376,7 @@ class TerritoryControl:
 @dataclass
 class TerritorySpec:
     tag_prefix: str
+    tags: Optional[list] = None   # explicit tag names; overrides the prefix
     on_enter: list = field(default_factory=list)   # list[Handler]
     on_exit: list = field(default_factory=list)
     presence: list = field(default_factory=list)
@@ -399,7 +403,7 @@ class ObjectSpec:
     on_use: object = None
     aoes: list = field(default_factory=list)                 # list[AOESpec]
     territory_controls: list = field(default_factory=list)   # list[TerritoryControl]
-    on_tag_add: dict = field(default_factory=dict)           # tag prefix -> Handler
+    on_tag_add: dict = field(default_factory=dict)           # tag prefix (or tuple of tag names) -> Handler
     on_tag_remove: dict = field(default_factory=dict)
 
     @property

@@ -1281,6 +1281,22 @@ void mgxo_reward_state(void* h, float* current_stat_reward) {  // systems/reward
     current_stat_reward[i] = t;
   }
 }
+// MettaGrid::set_inventory -> Agent::set_inventory (cpp/bindings/mettagrid_py.cpp:203-207, objects/agent.cpp:86-104):
+// every held item is removed through Inventory::update and its "<res>.amount" stat set to 0, then the given items are set
+// one by one; `items` / `amounts` come in the iteration order of the unordered_map the reference receives.
+void mgxo_set_inventory(void* h, int agent, const int32_t* items, const int32_t* amounts, int n) {
+  Engine* e = (Engine*)h;
+  if (agent < 0 || agent >= e->A) return;
+  const int oi = e->agents[agent].obj;
+  uint8_t held[MGX_MAX_RESOURCES];
+  const int nh = e->objs[oi].norder;
+  std::memcpy(held, e->objs[oi].order, nh);
+  for (int i = 0; i < nh; i++) {
+    e->inv_update(oi, held[i], -(int)e->objs[oi].inv[held[i]]);
+    e->agents[agent].stats.set(e->wk(MGX_S_RES_AMOUNT_BASE) + held[i], 0.f);
+  }
+  for (int i = 0; i < n; i++) e->inv_update(oi, items[i], amounts[i] - (int)e->objs[oi].inv[items[i]]);
+}
 // Self-check of the restated RNG against this toolchain's libstdc++ (the reference's actual dependency).
 int mgxo_selftest_shuffle(uint32_t seed, int n, int rounds) {
   MT mine; mine.seed(seed);

@@ -48,6 +48,7 @@ def lib():
         L.mgxo_stats.argtypes = [C.c_void_p] + [C.c_void_p] * 4
         L.mgxo_reward_state.argtypes = [C.c_void_p, C.c_void_p]
         L.mgxo_selftest_shuffle.argtypes = [C.c_uint32, C.c_int, C.c_int]
+        L.mgxo_set_inventory.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
         _lib = L
     return _lib
 
@@ -82,6 +83,15 @@ class OracleSim:
         a = np.ascontiguousarray(actions, dtype=np.int32)
         v = np.zeros(self.A, np.int32) if vibe_actions is None else np.ascontiguousarray(vibe_actions, dtype=np.int32)
         self.L.mgxo_step(self.h, a.ctypes.data, v.ctypes.data)
+
+    def set_inventory(self, agent_id: int, inventory: dict) -> None:
+        """``MettaGrid.set_inventory``; items are applied in the iteration order of the std::unordered_map the reference
+        builds from the dict (mettagrid_amd/umap.py)."""
+        from mettagrid_amd.umap import from_pydict
+        order = from_pydict([int(k) for k in inventory]).keys()
+        items = np.asarray(order, dtype=np.int32)
+        amounts = np.asarray([int(inventory[k]) for k in order], dtype=np.int32)
+        self.L.mgxo_set_inventory(self.h, int(agent_id), items.ctypes.data, amounts.ctypes.data, len(order))
 
     def snapshot(self) -> dict:
         A, T, L, h = self.A, self.T, self.L, self.h
