@@ -12,7 +12,8 @@ from mettagrid_amd.compiler import compile_spec
 from mettagrid_amd.engine import BatchedMettaGrid
 
 pytestmark = pytest.mark.gpu
-GOLD = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "*.npz")))
+GOLD = sorted(p for p in glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "*.npz"))
+              if not os.path.basename(p).startswith("ref_"))  # ref_*: fixtures of test_reference_config.py
 
 
 @pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p)[:-4] for p in GOLD])
