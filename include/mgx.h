@@ -70,6 +70,23 @@ void* mgx_stream(mgx_engine* e);
  * seeds:      uint32 [E] host memory or NULL (= reuse each env's current seed); only masked envs are read. */
 int mgx_reset_envs(mgx_engine* e, const uint8_t* env_mask, const uint16_t* class_maps, const uint32_t* seeds);
 
+/* Device-resident map pool.  The reference builds a map on the host for every new episode
+ * (simulator.py:83); here the host uploads `n_maps` finished maps once — uint16 [n_maps][H][W], class index + 1 — and
+ * episodes restart from them without touching the host again.  Source counts / token lists of every pool map are checked
+ * against the capacities sized at mgx_create. */
+int mgx_set_map_pool(mgx_engine* e, const uint16_t* class_maps, int32_t n_maps);
+/* mgx_reset_envs with the new maps named by pool index: int32 [E] host memory (only masked envs are read), seeds as above. */
+int mgx_reset_envs_from_pool(mgx_engine* e, const uint8_t* env_mask, const int32_t* pool_index, const uint32_t* seeds);
+/* Lazy auto-reset on the device — MettaGridPufferEnv.step (mettagrid_puffer_env.py:299-302): an env whose agents are all
+ * terminal or all truncated is restarted at the START of the next mgx_step (next pool map: (env + episode * pool_stride)
+ * mod n_maps; same seed, like the reference's _current_seed), then stepped.  No host round trip per step.
+ * early_end_steps: uint32 [E] host memory or NULL — the step at which each env's FIRST episode is truncated early
+ * (EarlyResetHandler, python/src/mettagrid/envs/early_reset_handler.py:6-22: desynchronises envs that share max_steps);
+ * 0 = no early end for that env. */
+int mgx_set_auto_reset(mgx_engine* e, int32_t enabled, int32_t pool_stride, const uint32_t* early_end_steps);
+/* Episodes started by auto-reset and the pool map of the current episode, per env (either pointer may be NULL). */
+int mgx_get_episodes(mgx_engine* e, uint32_t* episodes, int32_t* map_index);
+
 /* Pointers to the currently bound buffers (observations(), rewards(), ... accessors, mettagrid_py.cpp:291-299);
  * device or host according to mem_kind. */
 int mgx_get_buffers(mgx_engine* e, uint8_t** observations, uint8_t** terminals, uint8_t** truncations,

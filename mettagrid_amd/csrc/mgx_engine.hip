@@ -131,6 +131,24 @@ struct mgx_engine {
   uint8_t* dmask = nullptr;
   struct Row { void* base; size_t row_bytes; int fill; };
   std::vector<Row> rows_state;  // per-env state arrays (env-major) that an episode restart clears
+  MgxRow* d_rows = nullptr;     // device table: rows_state + the caller-visible terminals / truncations / rewards rows
+  int n_rows = 0;
+  std::vector<MgxRow> rows_host;
+  // device-resident map pool + auto-reset
+  uint16_t* d_pool = nullptr;   // [n_pool][H][W]
+  int n_pool = 0;
+  int32_t* d_map_index = nullptr;   // [E] pool map of each env's current episode
+  uint32_t* d_episodes = nullptr;   // [E] episodes started by auto-reset
+  uint8_t* d_next_mask = nullptr;   // [E] envs found done at the end of the last step
+  uint32_t* d_early = nullptr;      // [E] step at which each env's FIRST episode ends early (desync), or nullptr
+  uint32_t* d_counters = nullptr;   // [2] done count, block ticket
+  uint32_t* h_flags = nullptr;      // pinned + mapped: [0] sequence number of the last finished step, [1] its done count
+  uint32_t* h_flags_dev = nullptr;  // device address of h_flags
+  bool auto_reset = false;
+  int pool_stride = 1;
+  uint32_t step_seq = 0;
+  void* d_stage = nullptr;          // staging for contiguous uploads of restart arguments
+  size_t stage_bytes = 0;
   bool profiling = false;
   hipEvent_t ev[MGX_T_COUNT + 1] = {};  // boundaries of the timing segments of the most recent step (profiling only)
 
@@ -264,6 +282,13 @@ int mgx_create(const int32_t* program, size_t program_words, const uint16_t* cla
       P[MGX_H_WIDTH] > 255 || P[MGX_H_NUM_AGENTS] < 1 || P[MGX_H_TOKEN_BASE] < 2 || P[MGX_H_TOKEN_BASE] > 256 ||
       P[MGX_H_NUM_TOKENS] < 1 || P[MGX_H_OBS_HEIGHT] > 15 || P[MGX_H_OBS_WIDTH] > 15)
     return fail(MGX_ERR_PROGRAM, "mgx_create: program exceeds engine limits (resources<=13, agents<255, map<=255x255)");
+  {
+    const size_t hw = (size_t)P[MGX_H_HEIGHT] * P[MGX_H_WIDTH];
+    for (size_t i = 0; i < (size_t)num_envs * hw; i++)
+      if (class_maps[i] > P[MGX_H_NUM_CLASSES])
+        return fail(MGX_ERR_BAD_ARG, "mgx_create: class map holds id " + std::to_string(class_maps[i]) + " but the program has " +
+                                         std::to_string(P[MGX_H_NUM_CLASSES]) + " classes");
+  }
   HIP_TRY(hipSetDevice(device));
   mgx_engine* e = new mgx_engine();
   e->device = device;
@@ -563,8 +588,8 @@ int mgx_create(const int32_t* program, size_t program_words, const uint16_t* cla
   if (he != hipSuccess) { mgx_destroy(e); return fail(MGX_ERR_HIP, std::string("mgx_create upload: ") + hipGetErrorString(he)); }
   e->dmaps = dmaps;
   e->dseeds = dseeds;
-  hipLaunchKernelGGL(mgx_init_kernel, dim3((d.E + MGX_WAVE - 1) / MGX_WAVE), dim3(MGX_WAVE), 0, e->stream, dev_copy(e), dmaps, dseeds,
-                     (const uint8_t*)nullptr);
+  hipLaunchKernelGGL(mgx_init_kernel, dim3((d.E + MGX_WAVE - 1) / MGX_WAVE), dim3(MGX_WAVE), 0, e->stream, dev_copy(e), (const uint16_t*)dmaps,
+                     (const int32_t*)nullptr, (const uint32_t*)dseeds, (const uint8_t*)nullptr);
   he = hipGetLastError();
   if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
   if (he != hipSuccess) { mgx_destroy(e); return fail(MGX_ERR_HIP, std::string("mgx_init_kernel: ") + hipGetErrorString(he)); }
@@ -581,6 +606,9 @@ void mgx_destroy(mgx_engine* e) {
   (void)hipSetDevice(e->device);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   for (void* p : e->allocs) (void)hipFree(p);
+  if (e->d_pool) (void)hipFree(e->d_pool);
+  if (e->d_stage) (void)hipFree(e->d_stage);
+  if (e->h_flags) (void)hipHostFree(e->h_flags);
   for (int i = 0; i <= MGX_T_COUNT; i++) if (e->ev[i]) (void)hipEventDestroy(e->ev[i]);
   if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
@@ -624,16 +652,94 @@ int mgx_set_buffers(mgx_engine* e, uint8_t* observations, uint8_t* terminals, ui
   return init_buffers(e);
 }
 
-int mgx_reset_envs(mgx_engine* e, const uint8_t* env_mask, const uint16_t* class_maps, const uint32_t* seeds) {
-  if (!e || !env_mask) return fail(MGX_ERR_BAD_ARG, "mgx_reset_envs: null argument");
-  HIP_TRY(hipSetDevice(e->device));
+// Table of the arrays a restart clears, on the device (rebuilt when the bound caller buffers change).
+static int upload_rows(mgx_engine* e) {
   const MgxDev& d = e->d;
-  const size_t E = d.E, HW = (size_t)d.H * d.W, A = d.A;
-  int first = -1, last = -1;
-  for (size_t i = 0; i < E; i++) if (env_mask[i]) { if (first < 0) first = (int)i; last = (int)i; }
-  if (first < 0) return MGX_OK;
-  if (class_maps && e->pool_from_maps) {  // new maps may hold more non-static objects than any map seen so far
-    const long long bound = e->list_tokens_bound(class_maps, (size_t)first, (size_t)(last - first + 1), env_mask);
+  std::vector<MgxRow> rows;
+  for (const auto& r : e->rows_state) rows.push_back({(uint8_t*)r.base, (unsigned long long)r.row_bytes, r.fill, 0});
+  // caller-visible rows of the restarted envs: terminals / truncations / rewards cleared (_init_buffers :294-319)
+  rows.push_back({(uint8_t*)d.terminals, (unsigned long long)d.A, 0, 0});
+  rows.push_back({(uint8_t*)d.truncations, (unsigned long long)d.A, 0, 0});
+  rows.push_back({(uint8_t*)d.rewards, (unsigned long long)d.A * 4, 0, 0});
+  if (rows.size() == e->rows_host.size() && memcmp(rows.data(), e->rows_host.data(), rows.size() * sizeof(MgxRow)) == 0) return MGX_OK;
+  if (!e->d_rows) { int rc = e->alloc(&e->d_rows, rows.size()); if (rc) return rc; }
+  HIP_TRY(hipMemcpyAsync(e->d_rows, rows.data(), rows.size() * sizeof(MgxRow), hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));  // `rows` is a local
+  e->rows_host = rows;
+  e->n_rows = (int)rows.size();
+  return MGX_OK;
+}
+static int stage(mgx_engine* e, size_t bytes) {
+  if (bytes <= e->stage_bytes) return MGX_OK;
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  if (e->d_stage) (void)hipFree(e->d_stage);
+  e->d_stage = nullptr;
+  e->stage_bytes = 0;
+  HIP_TRY(hipMalloc(&e->d_stage, bytes));
+  e->stage_bytes = bytes;
+  return MGX_OK;
+}
+// Restart the envs of a DEVICE mask: clear their state rows, rebuild them (construction kernel), initial observations.
+// from_pool: maps come from the pool through d_map_index; bump: auto-reset bookkeeping (episode counter, next pool map).
+static int restart_masked(mgx_engine* e, const uint8_t* dmask, bool from_pool, bool bump) {
+  const MgxDev& d = e->d;
+  int rc = upload_rows(e);
+  if (rc) return rc;
+  hipLaunchKernelGGL(mgx_clear_rows_kernel, dim3((unsigned)d.E), dim3(256), 0, e->stream, (const MgxRow*)e->d_rows, e->n_rows, dmask, d.E,
+                     bump ? e->d_episodes : (uint32_t*)nullptr, bump ? e->d_map_index : (int32_t*)nullptr, e->n_pool, e->pool_stride);
+  HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(mgx_init_kernel, dim3((d.E + MGX_WAVE - 1) / MGX_WAVE), dim3(MGX_WAVE), 0, e->stream, dev_copy(e),
+                     (const uint16_t*)(from_pool ? e->d_pool : e->dmaps), (const int32_t*)(from_pool ? e->d_map_index : nullptr),
+                     (const uint32_t*)e->dseeds, dmask);
+  HIP_TRY(hipGetLastError());
+  return launch_obs(e, false, dmask);
+}
+// Class ids of maps handed over by the caller: 0 = empty, else class index + 1.
+static int validate_maps(const mgx_engine* e, const uint16_t* maps, size_t n_maps, const uint8_t* mask, const char* who) {
+  const size_t hw = (size_t)e->d.H * e->d.W;
+  const int nc = e->prog[MGX_H_NUM_CLASSES];
+  for (size_t m = 0; m < n_maps; m++) {
+    if (mask && !mask[m]) continue;
+    for (size_t i = 0; i < hw; i++)
+      if (maps[m * hw + i] > nc)
+        return fail(MGX_ERR_BAD_ARG, std::string(who) + ": class map holds id " + std::to_string(maps[m * hw + i]) +
+                                         " but the program has " + std::to_string(nc) + " classes");
+  }
+  return MGX_OK;
+}
+// AoE / territory source counts of a set of maps against the capacities sized at mgx_create, and the observation kernel's
+// token pool against their object lists.
+static int fit_maps(mgx_engine* e, const uint16_t* maps, size_t first, size_t count, const uint8_t* mask, const char* who) {
+  const MgxDev& d = e->d;
+  const int32_t* P = e->prog.data();
+  const int nc = P[MGX_H_NUM_CLASSES];
+  const size_t hw = (size_t)d.H * d.W;
+  if (d.X && (d.NF || d.NM || d.NTS || mgx_sec_cnt(P, MGX_SEC_AOES) > 0 || d.NT > 0)) {
+    std::vector<int> cf(nc, 0), cm(nc, 0), ct(nc, 0);
+    for (int c = 0; c < nc; c++) {
+      const int32_t* C = P + d.sec[MGX_SEC_CLASSES] + c * MGX_C_WORDS;
+      for (int i = 0; i < C[MGX_C_AOE_COUNT]; i++)
+        (P[d.sec[MGX_SEC_AOES] + (C[MGX_C_AOE_START] + i) * MGX_AO_WORDS + MGX_AO_STATIC] ? cf[c] : cm[c])++;
+      ct[c] = C[MGX_C_TERR_COUNT];
+    }
+    const int spare_f = P[MGX_H_SPAWNS] ? 0 : 0;
+    (void)spare_f;
+    for (size_t m = first; m < first + count; m++) {
+      if (mask && !mask[m]) continue;
+      int f = 0, mo = 0, t = 0;
+      for (size_t i = 0; i < hw; i++) {
+        const int k = maps[m * hw + i];
+        if (k > 0 && k <= nc) { f += cf[k - 1]; mo += cm[k - 1]; t += ct[k - 1]; }
+      }
+      if (f > d.NF || mo > d.NM || t > d.NTS)
+        return fail(MGX_ERR_PROGRAM, std::string(who) + ": a map holds more AoE / territory sources (" + std::to_string(f) + " fixed, " +
+                                         std::to_string(mo) + " mobile, " + std::to_string(t) + " territory) than any map given to "
+                                         "mgx_create (capacity " + std::to_string(d.NF) + " / " + std::to_string(d.NM) + " / " +
+                                         std::to_string(d.NTS) + "): create the engine with a map that has the maximum");
+    }
+  }
+  if (e->pool_from_maps) {  // new maps may hold more non-static objects than any map seen so far
+    const long long bound = e->list_tokens_bound(maps, first, count, mask);
     const int need = (e->pool_prefix + (int)std::min<long long>(bound, 16384) + 7) & ~7;
     if (need > e->pool_tokens) {
       e->pool_tokens = need;
@@ -641,37 +747,160 @@ int mgx_reset_envs(mgx_engine* e, const uint8_t* env_mask, const uint16_t* class
       if (rcl) return rcl;
     }
   }
-  HIP_TRY(hipMemcpyAsync(e->dmask, env_mask, E, hipMemcpyHostToDevice, e->stream));
-  for (int i = first; i <= last; i++) {
-    if (!env_mask[i]) continue;
-    if (class_maps) HIP_TRY(hipMemcpyAsync(e->dmaps + (size_t)i * HW, class_maps + (size_t)i * HW, HW * 2, hipMemcpyHostToDevice, e->stream));
-    if (seeds) HIP_TRY(hipMemcpyAsync(e->dseeds + i, seeds + i, 4, hipMemcpyHostToDevice, e->stream));
+  return MGX_OK;
+}
+
+int mgx_reset_envs(mgx_engine* e, const uint8_t* env_mask, const uint16_t* class_maps, const uint32_t* seeds) {
+  if (!e || !env_mask) return fail(MGX_ERR_BAD_ARG, "mgx_reset_envs: null argument");
+  HIP_TRY(hipSetDevice(e->device));
+  const MgxDev& d = e->d;
+  const size_t E = d.E, HW = (size_t)d.H * d.W, A = d.A;
+  std::vector<int32_t> idx;
+  for (size_t i = 0; i < E; i++) if (env_mask[i]) idx.push_back((int32_t)i);
+  if (idx.empty()) return MGX_OK;
+  const size_t n = idx.size();
+  if (class_maps) {
+    int rc = validate_maps(e, class_maps, E, env_mask, "mgx_reset_envs");
+    if (!rc) rc = fit_maps(e, class_maps, 0, E, env_mask, "mgx_reset_envs");
+    if (rc) return rc;
   }
-  for (const auto& r : e->rows_state) {
-    int bx = (int)std::min<size_t>((r.row_bytes + 255) / 256, 64);
-    hipLaunchKernelGGL(mgx_fill_rows_kernel, dim3(bx, (unsigned)E), dim3(256), 0, e->stream, (uint8_t*)r.base, r.row_bytes, r.fill,
-                       (const uint8_t*)e->dmask, (int)E);
+  // ONE contiguous upload: [indices | packed seeds | packed maps] of the masked envs, scattered on the device
+  const size_t off_seeds = n * 4, off_maps = (off_seeds + (seeds ? n * 4 : 0) + 15) & ~(size_t)15;
+  const size_t total = off_maps + (class_maps ? n * HW * 2 : 0);
+  std::vector<uint8_t> host(total);
+  memcpy(host.data(), idx.data(), n * 4);
+  for (size_t k = 0; k < n; k++) {
+    if (seeds) memcpy(host.data() + off_seeds + k * 4, seeds + idx[k], 4);
+    if (class_maps) memcpy(host.data() + off_maps + k * HW * 2, class_maps + (size_t)idx[k] * HW, HW * 2);
   }
-  // caller-visible rows of the restarted envs: terminals / truncations / rewards cleared (_init_buffers)
-  hipLaunchKernelGGL(mgx_fill_rows_kernel, dim3(1, (unsigned)E), dim3(256), 0, e->stream, (uint8_t*)d.terminals, A, 0, (const uint8_t*)e->dmask, (int)E);
-  hipLaunchKernelGGL(mgx_fill_rows_kernel, dim3(1, (unsigned)E), dim3(256), 0, e->stream, (uint8_t*)d.truncations, A, 0, (const uint8_t*)e->dmask, (int)E);
-  hipLaunchKernelGGL(mgx_fill_rows_kernel, dim3(1, (unsigned)E), dim3(256), 0, e->stream, (uint8_t*)d.rewards, A * 4, 0, (const uint8_t*)e->dmask, (int)E);
-  HIP_TRY(hipGetLastError());
-  hipLaunchKernelGGL(mgx_init_kernel, dim3((d.E + MGX_WAVE - 1) / MGX_WAVE), dim3(MGX_WAVE), 0, e->stream, dev_copy(e), e->dmaps, e->dseeds,
-                     (const uint8_t*)e->dmask);
-  HIP_TRY(hipGetLastError());
-  int rc = launch_obs(e, false, e->dmask);
+  int rc = stage(e, total);
   if (rc) return rc;
-  if (e->mem_kind == MGX_MEM_HOST) {
-    for (int i = first; i <= last; i++) {
-      if (!env_mask[i]) continue;
-      size_t r0 = (size_t)i * A;
-      HIP_TRY(hipMemcpyAsync(e->h_obs + r0 * d.T * 3, d.obs + r0 * d.T * 3, A * d.T * 3, hipMemcpyDeviceToHost, e->stream));
-      HIP_TRY(hipMemcpyAsync(e->h_term + r0, d.terminals + r0, A, hipMemcpyDeviceToHost, e->stream));
-      HIP_TRY(hipMemcpyAsync(e->h_trunc + r0, d.truncations + r0, A, hipMemcpyDeviceToHost, e->stream));
-      HIP_TRY(hipMemcpyAsync(e->h_rew + r0, d.rewards + r0, A * 4, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipMemcpyAsync(e->dmask, env_mask, E, hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(hipMemcpyAsync(e->d_stage, host.data(), total, hipMemcpyHostToDevice, e->stream));
+  const uint8_t* st = (const uint8_t*)e->d_stage;
+  if (seeds) hipLaunchKernelGGL(mgx_scatter_words_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->stream, e->dseeds,
+                                (const uint32_t*)(st + off_seeds), (const int32_t*)st, (int)n);
+  if (class_maps) hipLaunchKernelGGL(mgx_scatter_maps_kernel, dim3(4, (unsigned)n), dim3(256), 0, e->stream, e->dmaps,
+                                     (const uint16_t*)(st + off_maps), (const int32_t*)st, (int)n, (int)HW);
+  HIP_TRY(hipGetLastError());
+  rc = restart_masked(e, e->dmask, false, false);
+  if (rc) return rc;
+  if (e->mem_kind == MGX_MEM_HOST) {  // host buffers: the restarted rows, one copy per contiguous run of envs
+    for (size_t k = 0; k < n;) {
+      size_t j = k;
+      while (j + 1 < n && idx[j + 1] == idx[j] + 1) j++;
+      const size_t r0 = (size_t)idx[k] * A, rows = (size_t)(idx[j] - idx[k] + 1) * A;
+      HIP_TRY(hipMemcpyAsync(e->h_obs + r0 * d.T * 3, d.obs + r0 * d.T * 3, rows * d.T * 3, hipMemcpyDeviceToHost, e->stream));
+      HIP_TRY(hipMemcpyAsync(e->h_term + r0, d.terminals + r0, rows, hipMemcpyDeviceToHost, e->stream));
+      HIP_TRY(hipMemcpyAsync(e->h_trunc + r0, d.truncations + r0, rows, hipMemcpyDeviceToHost, e->stream));
+      HIP_TRY(hipMemcpyAsync(e->h_rew + r0, d.rewards + r0, rows * 4, hipMemcpyDeviceToHost, e->stream));
+      k = j + 1;
     }
   }
+  HIP_TRY(hipStreamSynchronize(e->stream));  // `host` is a local
+  return MGX_OK;
+}
+
+int mgx_set_map_pool(mgx_engine* e, const uint16_t* class_maps, int32_t n_maps) {
+  if (!e || !class_maps || n_maps <= 0) return fail(MGX_ERR_BAD_ARG, "mgx_set_map_pool: null/empty argument");
+  HIP_TRY(hipSetDevice(e->device));
+  const MgxDev& d = e->d;
+  const size_t HW = (size_t)d.H * d.W;
+  int rc = validate_maps(e, class_maps, (size_t)n_maps, nullptr, "mgx_set_map_pool");
+  if (!rc) rc = fit_maps(e, class_maps, 0, (size_t)n_maps, nullptr, "mgx_set_map_pool");
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  if (e->d_pool) (void)hipFree(e->d_pool);
+  e->d_pool = nullptr;
+  HIP_TRY(hipMalloc((void**)&e->d_pool, (size_t)n_maps * HW * 2));
+  HIP_TRY(hipMemcpyAsync(e->d_pool, class_maps, (size_t)n_maps * HW * 2, hipMemcpyHostToDevice, e->stream));
+  if (!e->d_map_index) {
+    rc = e->alloc(&e->d_map_index, (size_t)d.E);
+    if (!rc) rc = e->alloc(&e->d_episodes, (size_t)d.E);
+    if (rc) return rc;
+  }
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  e->n_pool = n_maps;
+  return MGX_OK;
+}
+
+int mgx_reset_envs_from_pool(mgx_engine* e, const uint8_t* env_mask, const int32_t* pool_index, const uint32_t* seeds) {
+  if (!e || !env_mask || !pool_index) return fail(MGX_ERR_BAD_ARG, "mgx_reset_envs_from_pool: null argument");
+  if (e->n_pool <= 0) return fail(MGX_ERR_BAD_ARG, "mgx_reset_envs_from_pool: no map pool (mgx_set_map_pool)");
+  HIP_TRY(hipSetDevice(e->device));
+  const MgxDev& d = e->d;
+  const size_t E = d.E;
+  std::vector<int32_t> idx;
+  std::vector<uint32_t> vals;
+  for (size_t i = 0; i < E; i++) if (env_mask[i]) {
+    if (pool_index[i] < 0 || pool_index[i] >= e->n_pool) return fail(MGX_ERR_BAD_ARG, "mgx_reset_envs_from_pool: pool index out of range");
+    idx.push_back((int32_t)i);
+  }
+  if (idx.empty()) return MGX_OK;
+  const size_t n = idx.size();
+  std::vector<uint8_t> host(n * 12);
+  memcpy(host.data(), idx.data(), n * 4);
+  for (size_t k = 0; k < n; k++) {
+    memcpy(host.data() + n * 4 + k * 4, pool_index + idx[k], 4);
+    if (seeds) memcpy(host.data() + n * 8 + k * 4, seeds + idx[k], 4);
+  }
+  int rc = stage(e, host.size());
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(e->dmask, env_mask, E, hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(hipMemcpyAsync(e->d_stage, host.data(), host.size(), hipMemcpyHostToDevice, e->stream));
+  const uint8_t* st = (const uint8_t*)e->d_stage;
+  const dim3 g((unsigned)((n + 255) / 256)), b(256);
+  hipLaunchKernelGGL(mgx_scatter_words_kernel, g, b, 0, e->stream, (uint32_t*)e->d_map_index, (const uint32_t*)(st + n * 4), (const int32_t*)st, (int)n);
+  if (seeds) hipLaunchKernelGGL(mgx_scatter_words_kernel, g, b, 0, e->stream, e->dseeds, (const uint32_t*)(st + n * 8), (const int32_t*)st, (int)n);
+  HIP_TRY(hipGetLastError());
+  rc = restart_masked(e, e->dmask, true, false);
+  if (rc) return rc;
+  if (e->mem_kind == MGX_MEM_HOST) {
+    const size_t rows = E * d.A;
+    HIP_TRY(hipMemcpyAsync(e->h_obs, d.obs, rows * d.T * 3, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipMemcpyAsync(e->h_term, d.terminals, rows, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipMemcpyAsync(e->h_trunc, d.truncations, rows, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipMemcpyAsync(e->h_rew, d.rewards, rows * 4, hipMemcpyDeviceToHost, e->stream));
+  }
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return MGX_OK;
+}
+
+int mgx_set_auto_reset(mgx_engine* e, int32_t enabled, int32_t pool_stride, const uint32_t* early_end_steps) {
+  if (!e) return fail(MGX_ERR_BAD_ARG, "mgx_set_auto_reset: null engine");
+  HIP_TRY(hipSetDevice(e->device));
+  if (!enabled) { e->auto_reset = false; return MGX_OK; }
+  if (e->n_pool <= 0) return fail(MGX_ERR_BAD_ARG, "mgx_set_auto_reset: no map pool (mgx_set_map_pool)");
+  const MgxDev& d = e->d;
+  int rc = MGX_OK;
+  if (!e->d_next_mask) {
+    rc = e->alloc(&e->d_next_mask, (size_t)d.E);
+    if (!rc) rc = e->alloc(&e->d_counters, 2);
+    if (rc) return rc;
+    HIP_TRY(hipHostMalloc((void**)&e->h_flags, 8, hipHostMallocMapped));
+    e->h_flags[0] = 0xFFFFFFFFu; e->h_flags[1] = 0;
+    HIP_TRY(hipHostGetDevicePointer((void**)&e->h_flags_dev, e->h_flags, 0));
+  }
+  if (early_end_steps) {
+    if (!e->d_early) { rc = e->alloc(&e->d_early, (size_t)d.E); if (rc) return rc; }
+    HIP_TRY(hipMemcpyAsync(e->d_early, early_end_steps, (size_t)d.E * 4, hipMemcpyHostToDevice, e->stream));
+  } else if (e->d_early) {
+    HIP_TRY(hipMemsetAsync(e->d_early, 0, (size_t)d.E * 4, e->stream));
+  }
+  HIP_TRY(hipMemsetAsync(e->d_next_mask, 0, (size_t)d.E, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  e->pool_stride = pool_stride > 0 ? pool_stride : 1;
+  e->auto_reset = true;
+  e->h_flags[0] = e->step_seq; e->h_flags[1] = 0;  // nothing is done before the first step
+  return MGX_OK;
+}
+
+int mgx_get_episodes(mgx_engine* e, uint32_t* episodes, int32_t* map_index) {
+  if (!e || (!episodes && !map_index)) return fail(MGX_ERR_BAD_ARG, "mgx_get_episodes: null argument");
+  if (!e->d_episodes) return fail(MGX_ERR_BAD_ARG, "mgx_get_episodes: no map pool (mgx_set_map_pool)");
+  HIP_TRY(hipSetDevice(e->device));
+  if (episodes) HIP_TRY(hipMemcpyAsync(episodes, e->d_episodes, (size_t)e->d.E * 4, hipMemcpyDeviceToHost, e->stream));
+  if (map_index) HIP_TRY(hipMemcpyAsync(map_index, e->d_map_index, (size_t)e->d.E * 4, hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));
   return MGX_OK;
 }
@@ -684,6 +913,16 @@ int mgx_step(mgx_engine* e) {
   if (e->mem_kind == MGX_MEM_HOST) {
     HIP_TRY(hipMemcpyAsync(e->own_act, e->h_act, rows * 4, hipMemcpyHostToDevice, e->stream));
     HIP_TRY(hipMemcpyAsync(e->own_vact, e->h_vact, rows * 4, hipMemcpyHostToDevice, e->stream));
+  }
+  if (e->auto_reset) {
+    // Lazy auto-reset (mettagrid_puffer_env.py:299-302): envs found done at the end of the previous step are restarted
+    // first, then stepped.  The previous step published its done count in host-visible memory; when the host has
+    // already synchronised with it and nothing was done, the restart launches are skipped altogether.
+    const bool known_none = e->h_flags[0] == e->step_seq && e->h_flags[1] == 0;
+    if (!known_none) {
+      int rrc = restart_masked(e, e->d_next_mask, true, true);
+      if (rrc) return rrc;
+    }
   }
   // timing segments (profiling only): event k closes segment k - 1 of include/mgx.h MGX_T_*
 #define MGX_MARK(k) do { if (e->profiling) HIP_TRY(hipEventRecord(e->ev[k], e->stream)); } while (0)
@@ -720,6 +959,18 @@ int mgx_step(mgx_engine* e) {
   if (e->rewards_ext) { mgx_launch_values(e->stream, e->d, dev_copy(e), 1, nullptr); HIP_TRY(hipGetLastError()); }
   MGX_MARK(5);
 #undef MGX_MARK
+  if (e->auto_reset) {
+    e->step_seq++;
+#ifdef MGX_CPU_EMU
+    const unsigned bt = 1;  // the sanitizer build runs work-items one after another: one env per workgroup
+#else
+    const unsigned bt = 256;
+#endif
+    hipLaunchKernelGGL(mgx_episode_end_kernel, dim3((d.E + bt - 1) / bt), dim3(bt), 0, e->stream, dev_copy(e), (const uint32_t*)e->d_early,
+                       (const uint32_t*)e->d_episodes, e->d_next_mask, e->d_counters, (volatile uint32_t*)e->h_flags_dev, e->step_seq,
+                       e->d_counters + 1);
+    HIP_TRY(hipGetLastError());
+  }
   if (e->mem_kind == MGX_MEM_HOST) {
     HIP_TRY(hipMemcpyAsync(e->h_obs, d.obs, rows * d.T * 3, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipMemcpyAsync(e->h_term, d.terminals, rows, hipMemcpyDeviceToHost, e->stream));

@@ -2289,8 +2289,11 @@ bool mgx_aoe_is_target_local(const int32_t* program);
 #ifndef MGX_WORLD_FAST_TU
 // Construction: MettaGrid ctor + _init_grid (mettagrid_c.cpp:42-191, 200-269).  One lane per env scans the class
 // map in row-major order; object slot = reference object id - 1; agent index = order of appearance.
+// class_maps + map_index: env e is built from map `map_index ? map_index[e] : e` of `class_maps` (the engine's per-env
+// maps, or its device-resident map pool: mgx_set_map_pool).
 __global__ void __launch_bounds__(MGX_WAVE) mgx_init_kernel(const MgxDev* __restrict__ dp, const uint16_t* class_maps,
-                                                            const uint32_t* seeds, const uint8_t* env_mask) {
+                                                            const int32_t* map_index, const uint32_t* seeds,
+                                                            const uint8_t* env_mask) {
   const MgxDev& d = *dp;  // per-engine copy in device memory (see mgx_world_x.hip)
   const int env = blockIdx.x * MGX_WAVE + threadIdx.x;
   if (env >= d.E) return;
@@ -2310,7 +2313,7 @@ __global__ void __launch_bounds__(MGX_WAVE) mgx_init_kernel(const MgxDev* __rest
   e.gstat_touch(d.wk[MGX_S_GAME_TOKENS_DROPPED]);
   e.gstat_touch(d.wk[MGX_S_GAME_TOKENS_FREE]);
   const int HW = d.H * d.W;
-  const uint16_t* cm = class_maps + (size_t)env * HW;
+  const uint16_t* cm = class_maps + (size_t)(map_index ? map_index[env] : env) * HW;
   int nobj = 0, nag = 0, nf = 0, nm = 0, nts = 0;
   for (int cellidx = 0; cellidx < HW; cellidx++) {
     int k = cm[cellidx];
@@ -2406,12 +2409,82 @@ __global__ void __launch_bounds__(MGX_WAVE) mgx_init_kernel(const MgxDev* __rest
   }
 }
 
-// Fills the rows of the masked envs of one state array (episode restart): row_bytes per env, byte value `fill`.
-__global__ void mgx_fill_rows_kernel(uint8_t* base, size_t row_bytes, int fill, const uint8_t* env_mask, int E) {
-  const int env = blockIdx.y;
+// ---- episode restart on the device -----------------------------------------------------------------------------------
+struct MgxRow { uint8_t* base; unsigned long long row_bytes; int fill; int pad; };  // one env-major state array
+// One workgroup per env: for a masked env, fill its row of every state array in the table (what a fresh construction
+// would find there) and — auto-reset mode — start its next episode: bump the episode counter and pick the next map of
+// the pool, (env + episode * stride) mod pool size.
+__global__ void __launch_bounds__(256) mgx_clear_rows_kernel(const MgxRow* rows, int n_rows, const uint8_t* env_mask, int E,
+                                                             uint32_t* episodes, int32_t* map_index, int pool_size,
+                                                             int pool_stride) {
+  const int env = blockIdx.x;
   if (env >= E || !env_mask[env]) return;
-  uint8_t* row = base + (size_t)env * row_bytes;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < row_bytes; i += (size_t)gridDim.x * blockDim.x) row[i] = (uint8_t)fill;
+  for (int k = 0; k < n_rows; k++) {
+    uint8_t* row = rows[k].base + (size_t)env * rows[k].row_bytes;
+    const size_t n = (size_t)rows[k].row_bytes;
+    const uint8_t f = (uint8_t)rows[k].fill;
+    if (((uintptr_t)row & 15) == 0 && (n & 15) == 0) {
+      const uint32_t f4 = f * 0x01010101u;
+      uint4* r16 = (uint4*)row;
+      for (size_t i = threadIdx.x; i < n / 16; i += blockDim.x) r16[i] = make_uint4(f4, f4, f4, f4);
+    } else {
+      for (size_t i = threadIdx.x; i < n; i += blockDim.x) row[i] = f;
+    }
+  }
+  if (episodes && threadIdx.x == blockDim.x - 1) {
+    const uint32_t ep = episodes[env] + 1;
+    episodes[env] = ep;
+    if (map_index && pool_size > 0) map_index[env] = (int32_t)(((unsigned long long)env + (unsigned long long)ep * (unsigned)pool_stride) % (unsigned)pool_size);
+  }
+}
+// Masked scatter of host-packed values (k-th packed entry belongs to env idx[k]): per-env maps / seeds / pool indices of
+// the envs being restarted arrive in ONE contiguous upload each.
+__global__ void mgx_scatter_maps_kernel(uint16_t* dmaps, const uint16_t* packed, const int32_t* idx, int n, int HW) {
+  const int k = blockIdx.y;
+  if (k >= n) return;
+  uint16_t* dst = dmaps + (size_t)idx[k] * HW;
+  const uint16_t* src = packed + (size_t)k * HW;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += gridDim.x * blockDim.x) dst[i] = src[i];
+}
+__global__ void mgx_scatter_words_kernel(uint32_t* dst, const uint32_t* packed, const int32_t* idx, int n) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n) dst[idx[k]] = packed[k];
+}
+// End of a step in auto-reset mode: the one-off early end of every env's first episode (EarlyResetHandler,
+// python/src/mettagrid/envs/early_reset_handler.py:6-22: truncations set once current_step >= the drawn step), then the
+// env-is-done test of Simulation.is_done (simulator.py:145-146) -> mask of the envs to restart at the start of the next
+// step (lazy auto-reset, mettagrid_puffer_env.py:299-302).  The number of done envs and the step's sequence number go to
+// host-visible memory, so a host that has already synchronised with this step knows without a copy whether the restart
+// launches are needed at all.
+__global__ void __launch_bounds__(256) mgx_episode_end_kernel(const MgxDev* __restrict__ dp, const uint32_t* early_steps,
+                                                              const uint32_t* episodes, uint8_t* next_mask,
+                                                              uint32_t* done_count, volatile uint32_t* host_flags, uint32_t seq,
+                                                              uint32_t* blocks_done) {
+  const MgxDev& d = *dp;
+  const int env = blockIdx.x * blockDim.x + threadIdx.x;
+  if (env < d.E) {
+    const size_t r0 = (size_t)env * d.A;
+    if (early_steps && episodes[env] == 0 && early_steps[env] > 0 && d.step[env] >= early_steps[env])
+      for (int a = 0; a < d.A; a++) d.truncations[r0 + a] = 1;
+    bool all_term = true, all_trunc = true;
+    for (int a = 0; a < d.A; a++) { all_term = all_term && d.terminals[r0 + a]; all_trunc = all_trunc && d.truncations[r0 + a]; }
+    const bool done = all_term || all_trunc;
+    next_mask[env] = done ? 1 : 0;
+    if (done) atomicAdd(done_count, 1u);
+  }
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t ticket = atomicAdd(blocks_done, 1u);
+    if (ticket == gridDim.x - 1) {  // the last workgroup publishes the totals
+      __threadfence();
+      host_flags[1] = atomicAdd(done_count, 0u);
+      __threadfence_system();
+      host_flags[0] = seq;
+      *done_count = 0;
+      *blocks_done = 0;
+    }
+  }
 }
 
 #endif  // !MGX_WORLD_FAST_TU

@@ -67,6 +67,10 @@ def load_lib():
     L.mgx_get_reward_state.argtypes = [vp, i32, vp]
     L.mgx_poll_errors.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(i32)]
     L.mgx_set_inventory.argtypes = [vp, i32, i32, vp, vp, i32]
+    L.mgx_set_map_pool.argtypes = [vp, vp, i32]
+    L.mgx_reset_envs_from_pool.argtypes = [vp, vp, vp, vp]
+    L.mgx_set_auto_reset.argtypes = [vp, i32, i32, vp]
+    L.mgx_get_episodes.argtypes = [vp, vp, vp]
     L.mgx_count_objects_with_tag.argtypes = [vp, i32, i32, C.POINTER(i32)]
     L.mgx_set_profiling.argtypes = [vp, i32]
     L.mgx_get_step_timing.argtypes = [vp, vp]
@@ -188,9 +192,65 @@ class BatchedMettaGrid:
             sd_ptr = sd.ctypes.data
         _check(self.L.mgx_reset_envs(self.h, mask.ctypes.data, cm_ptr, sd_ptr))
 
+    # ---- device-resident map pool + auto-reset ----
+    def set_map_pool(self, class_maps) -> None:
+        """Upload finished maps once (uint16 [M, H, W], class index + 1); episodes then restart from them on the device."""
+        cm = np.ascontiguousarray(class_maps, dtype=np.uint16)
+        H, W = int(self.prog.words[K.H_HEIGHT]), int(self.prog.words[K.H_WIDTH])
+        if cm.ndim != 3 or cm.shape[1:] != (H, W):
+            raise ValueError(f"map pool must have shape [M, {H}, {W}]")
+        _check(self.L.mgx_set_map_pool(self.h, cm.ctypes.data, cm.shape[0]))
+        self.pool_size = cm.shape[0]
+
+    def reset_envs_from_pool(self, env_mask, pool_index, seeds=None) -> None:
+        mask = np.ascontiguousarray(np.asarray(env_mask, dtype=np.uint8).reshape(self.E))
+        idx = np.ascontiguousarray(np.broadcast_to(np.asarray(pool_index, dtype=np.int32), (self.E,)))
+        sd_ptr = None
+        if seeds is not None:
+            sd = np.ascontiguousarray(np.broadcast_to(np.asarray(seeds, dtype=np.uint32), (self.E,)))
+            sd_ptr = sd.ctypes.data
+        _check(self.L.mgx_reset_envs_from_pool(self.h, mask.ctypes.data, idx.ctypes.data, sd_ptr))
+
+    def set_auto_reset(self, enabled: bool = True, pool_stride: int = 1, early_end_steps=None) -> None:
+        """Lazy auto-reset on the device (MettaGridPufferEnv.step, mettagrid_puffer_env.py:299-302); ``early_end_steps``
+        [E]: step at which each env's first episode is truncated early (EarlyResetHandler), 0 = never."""
+        ptr = None
+        if early_end_steps is not None:
+            ee = np.ascontiguousarray(np.asarray(early_end_steps, dtype=np.uint32).reshape(self.E))
+            ptr = ee.ctypes.data
+        _check(self.L.mgx_set_auto_reset(self.h, 1 if enabled else 0, int(pool_stride), ptr))
+
+    def episodes(self):
+        ep, mi = np.empty(self.E, np.uint32), np.empty(self.E, np.int32)
+        _check(self.L.mgx_get_episodes(self.h, ep.ctypes.data, mi.ctypes.data))
+        return ep, mi
+
     @property
     def stream(self) -> int:
         return int(self.L.mgx_stream(self.h) or 0)
+
+    # ---- ordering against the caller's torch stream (device buffers) ----
+    def _ext_stream(self):
+        import torch
+        if getattr(self, "_ext", None) is None:
+            self._ext = torch.cuda.ExternalStream(self.stream, device=torch.device("cuda", self.device))
+        return self._ext
+
+    def wait_for_caller(self) -> None:
+        """Order the engine's stream behind everything the caller has enqueued on its current torch stream (the action
+        writes): the engine's kernels then read the actions the caller meant."""
+        import torch
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        self._ext_stream().wait_event(ev)
+
+    def caller_waits(self) -> None:
+        """Order the caller's current torch stream behind the engine's stream: tensors returned after ``step`` hold the
+        step's results for any kernel the caller enqueues next (no host synchronisation)."""
+        import torch
+        ev = torch.cuda.Event()
+        ev.record(self._ext_stream())
+        torch.cuda.current_stream(self.device).wait_event(ev)
 
     def poll_errors(self):
         bits, first = C.c_uint32(0), C.c_int32(-1)

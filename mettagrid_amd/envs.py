@@ -70,21 +70,58 @@ def decode_actions(actions, num_primary: int, vibe_action_ids, xp=np):
     return core, vibe
 
 
+def decode_actions_unchecked(a, num_primary: int, vibe_action_ids):
+    """decode_actions for torch tensors without the range checks (each of them is a device->host read)."""
+    import torch
+    num_vibe = len(vibe_action_ids)
+    if a.ndim == 2:
+        if a.shape[1] == 1:
+            return a[:, 0], None
+        return a[:, 0], vibe_action_ids[a[:, 1].to(torch.int64)]
+    a64 = a.to(torch.int64)
+    if num_vibe <= 0:
+        return a64, None
+    enc = a64 >= num_primary
+    off = (a64 - num_primary).clamp(min=0)
+    core = torch.where(enc, off // num_vibe, a64)
+    vibe = torch.where(enc, vibe_action_ids[(off % num_vibe) * enc], torch.zeros_like(a64))
+    return core, vibe
+
+
 class MettaGridBatchedEnv:
     """E envs x A agents behind the PufferEnv call pattern.
 
-    ``map_fn(env_index, episode_index) -> uint16 class map [H, W]`` supplies the map of every new episode (maps are
-    built on the host once per episode, as in the reference: simulator.py:83); ``seed_fn`` likewise for engine seeds
-    (default: the seed given to ``reset`` plus the env index, constant across auto-resets like the reference's
-    ``_current_seed``).
+    Two sources of maps for new episodes:
+
+    * ``map_pool`` (uint16 [M, H, W], class index + 1): the maps are uploaded to the GPU once and finished envs restart
+      ON THE DEVICE (``mgx_set_map_pool`` / ``mgx_set_auto_reset``): no host round trip per step, episode ``k`` of env
+      ``e`` plays pool map ``(e + k * pool_stride) mod M``.  ``desync=True`` ends every env's FIRST episode early at a
+      step drawn like the reference's ``EarlyResetHandler`` (envs/early_reset_handler.py:6-22:
+      ``default_rng(seed).integers(1, max_steps + 1)``), so that envs sharing ``max_steps`` do not all restart on the
+      same step.
+    * ``map_fn(env_index, episode_index) -> uint16 class map [H, W]``: maps built on the host once per episode, as in the
+      reference (simulator.py:83); the done test then costs a device->host read per step.
+
+    Engine seeds: ``seed_fn(base, env, episode)`` (default: the seed given to ``reset`` plus the env index, constant
+    across auto-resets like the reference's ``_current_seed``).
+
+    With device buffers the returned tensors are ordered on the caller's current torch stream (no host synchronisation);
+    ``validate_actions=False`` also skips the reference's range checks on the action tensor, which need a host read.
     """
 
-    def __init__(self, prog: Program, num_envs: int, map_fn: Callable[[int, int], np.ndarray],
+    def __init__(self, prog: Program, num_envs: int, map_fn: Optional[Callable[[int, int], np.ndarray]] = None,
                  seed_fn: Optional[Callable[[int, int, int], int]] = None, device: int = 0, seed: int = 0,
-                 buffers: str = "device") -> None:
+                 buffers: str = "device", map_pool: Optional[np.ndarray] = None, pool_stride: int = 1,
+                 desync: bool = False, validate_actions: bool = True) -> None:
+        if (map_fn is None) == (map_pool is None):
+            raise ValueError("give exactly one of map_fn and map_pool")
         self.prog = prog
         self.E = num_envs
         self.map_fn = map_fn
+        self.map_pool = None if map_pool is None else np.ascontiguousarray(map_pool, dtype=np.uint16)
+        self.pool_stride = pool_stride
+        self.desync = desync
+        self.validate_actions = validate_actions
         self.seed_fn = seed_fn or (lambda base, env, episode: (base + env) & 0xFFFFFFFF)
         self._seed = seed
         self._device = device
@@ -119,18 +156,33 @@ class MettaGridBatchedEnv:
     def _seeds(self) -> np.ndarray:
         return np.array([self.seed_fn(self._seed, e, int(self.episode[e])) for e in range(self.E)], dtype=np.uint32)
 
+    def early_end_steps(self) -> np.ndarray:
+        """EarlyResetHandler.on_episode_start for every env: one draw from a generator seeded with the env's seed."""
+        ms = int(self.prog.words[11])   # MGX_H_MAX_STEPS
+        if ms <= 0:
+            return np.zeros(self.E, np.uint32)
+        return np.array([int(np.random.default_rng(int(s)).integers(1, ms + 1)) for s in self._seeds()], dtype=np.uint32)
+
     def reset(self, seed: Optional[int] = None):
         if seed is not None:
             self._seed = seed
         if self._eng is not None:
             self._eng.close()
         self.episode[:] = 0
-        self._eng = BatchedMettaGrid(self.prog, self._maps(range(self.E)), self._seeds(), device=self._device,
-                                     buffers=self._kind)
+        if self.map_pool is not None:
+            M = self.map_pool.shape[0]
+            first = self.map_pool[np.arange(self.E) % M]
+            self._eng = BatchedMettaGrid(self.prog, first, self._seeds(), device=self._device, buffers=self._kind)
+            self._eng.set_map_pool(self.map_pool)
+            self._eng.set_auto_reset(True, self.pool_stride, self.early_end_steps() if self.desync else None)
+        else:
+            self._eng = BatchedMettaGrid(self.prog, self._maps(range(self.E)), self._seeds(), device=self._device,
+                                         buffers=self._kind)
         ids = [self.prog.action_names.index(n) for n in self.vibe_action_names]
         if self._kind == "device":
             import torch
             self._vibe_ids = torch.tensor(ids, dtype=torch.int64, device=self._eng.obs.device)
+            self._eng.caller_waits()
         else:
             self._vibe_ids = np.asarray(ids, dtype=np.int64)
         return self._eng.obs, {}
@@ -152,15 +204,19 @@ class MettaGridBatchedEnv:
 
     def step(self, actions):
         eng = self.engine
-        done = self._done_envs()
-        if done.any():  # lazy auto-reset at the start of the next step (mettagrid_puffer_env.py:299-302)
-            idx = np.nonzero(done)[0]
-            self.episode[idx] += 1
-            eng.reset_envs(done, self._maps(idx), self._seeds())
+        if self.map_pool is None:  # host map source: the done test needs the flags on the host
+            done = self._done_envs()
+            if done.any():  # lazy auto-reset at the start of the next step (mettagrid_puffer_env.py:299-302)
+                idx = np.nonzero(done)[0]
+                self.episode[idx] += 1
+                eng.reset_envs(done, self._maps(idx), self._seeds())
         if self._kind == "device":
             import torch
             a = actions if isinstance(actions, torch.Tensor) else torch.as_tensor(np.asarray(actions), device=eng.obs.device)
-            core, vibe = decode_actions(a, len(self.action_names), self._vibe_ids, xp=torch)
+            if self.validate_actions:
+                core, vibe = decode_actions(a, len(self.action_names), self._vibe_ids, xp=torch)
+            else:
+                core, vibe = decode_actions_unchecked(a, len(self.action_names), self._vibe_ids)
             if tuple(core.shape) != tuple(eng.actions.shape):
                 raise ValueError(f"Expected {tuple(eng.actions.shape)} core actions, got {tuple(core.shape)}")
             eng.actions.copy_(core.to(torch.int32))
@@ -168,7 +224,9 @@ class MettaGridBatchedEnv:
                 eng.vibe_actions.copy_(vibe.to(torch.int32))
             else:
                 eng.vibe_actions.zero_()
-            torch.cuda.synchronize(eng.obs.device)
+            eng.wait_for_caller()   # the engine's kernels read the actions written on the caller's stream ...
+            eng.step()
+            eng.caller_waits()      # ... and whatever the caller enqueues next sees this step's results
         else:
             a = np.asarray(actions)
             core, vibe = decode_actions(a, len(self.action_names), self._vibe_ids, xp=np)
@@ -179,7 +237,7 @@ class MettaGridBatchedEnv:
                 np.copyto(eng.vibe_actions, vibe.astype(np.int32))
             else:
                 eng.vibe_actions.fill(0)
-        eng.step()
+            eng.step()
         return eng.obs, eng.rewards, eng.terminals, eng.truncations, {}
 
     def close(self) -> None:

@@ -83,6 +83,12 @@ enum { hipEventDisableTiming = 2 };
   } while (0)
 
 static inline void __syncthreads() {}
+static inline void __threadfence() {}
+static inline void __threadfence_system() {}
+enum { hipHostMallocMapped = 2 };
+static inline hipError_t hipHostMalloc(void** p, size_t n, unsigned) { *p = malloc(n); return *p ? hipSuccess : 1; }
+static inline hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
+static inline hipError_t hipHostGetDevicePointer(void** d, void* h, unsigned) { *d = h; return hipSuccess; }
 static inline float __fadd_rn(float a, float b) { return a + b; }
 static inline float __fsub_rn(float a, float b) { return a - b; }
 static inline float __fmul_rn(float a, float b) { return a * b; }

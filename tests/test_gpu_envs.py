@@ -122,3 +122,100 @@ def test_reset_with_denser_maps_grows_the_token_pool():
         for k, i in enumerate(np.flatnonzero(mask)):
             assert np.array_equal(snap["obs"][i * A:(i + 1) * A], ref["obs"][k * A:(k + 1) * A]), i
     assert eng.poll_errors()[0] == 0 and fresh.poll_errors()[0] == 0
+
+
+def _pool_env_against_oracle(buffers: str, steps: int = 45, check=None):
+    """MettaGridBatchedEnv with a device-resident map pool, device-side lazy auto-reset and the EarlyResetHandler desync,
+    against per-env oracles that are rebuilt on the host exactly when the reference wrapper would build a new Simulation
+    (mettagrid_puffer_env.py:299-302)."""
+    import oracle_py as op
+    spec = presets.rung2_spec()
+    spec.max_steps = 11
+    spec.episode_truncates = True
+    E, M, stride = 5, 7, 3
+    prog = compile_spec(spec, 32, 32, max_objects=192)
+    pool = np.stack([prog.class_map(presets.rung2_map(50 + m)) for m in range(M)])
+    env = MettaGridBatchedEnv(prog, E, map_pool=pool, pool_stride=stride, desync=True, seed=7, buffers=buffers)
+    env.reset()
+    early = env.early_end_steps()
+    assert (early >= 1).all() and (early <= 11).all() and len(set(early.tolist())) > 1
+    A = prog.num_agents
+    seeds = [(7 + e) & 0xFFFFFFFF for e in range(E)]
+    episode = [0] * E
+    oracles = [op.OracleSim(prog, pool[e % M], seeds[e]) for e in range(E)]
+    for o in oracles:
+        o.reinit_buffers()
+    ended = [False] * E      # env is done: restarts at the start of the next step
+    rng = np.random.default_rng(3)
+    n_primary, n_vibe = len(env.action_names), len(env.vibe_action_names)
+    restarts = 0
+    for t in range(steps):
+        a = rng.integers(0, n_primary * (n_vibe + 1), size=E * A)
+        for e in range(E):
+            if ended[e]:
+                episode[e] += 1
+                restarts += 1
+                oracles[e] = op.OracleSim(prog, pool[(e + episode[e] * stride) % M], seeds[e])
+                oracles[e].reinit_buffers()
+                ended[e] = False
+        core, vibe = np.where(a >= n_primary, (a - n_primary) // n_vibe, a), np.zeros_like(a)
+        enc = a >= n_primary
+        vibe_ids = np.array([prog.action_names.index(n) for n in env.vibe_action_names])
+        vibe[enc] = vibe_ids[(a[enc] - n_primary) % n_vibe]
+        if buffers == "device":
+            import torch
+            obs, rew, term, trunc, _ = env.step(torch.as_tensor(a, device="cuda"))
+        else:
+            obs, rew, term, trunc, _ = env.step(a)
+        for e, o in enumerate(oracles):
+            o.step(core[e * A:(e + 1) * A].astype(np.int32), vibe[e * A:(e + 1) * A].astype(np.int32))
+        check(env, oracles, episode, early, t, obs, rew, term, trunc)
+        for e, o in enumerate(oracles):
+            s = o.snapshot()
+            early_end = episode[e] == 0 and o.current_step >= early[e]
+            ended[e] = bool(s["truncations"].all() or s["terminals"].all() or early_end)
+    assert restarts >= 2 * E    # several episodes per env, not all on the same step
+    ep, mi = env.engine.episodes()
+    assert ep.tolist() == episode and mi.tolist() == [(e + episode[e] * stride) % M for e in range(E)]
+    return env
+
+
+def test_device_pool_auto_reset_and_desync_against_oracle():
+    """Device buffers, no manual synchronisation anywhere: the tensors returned by step() are read on the caller's torch
+    stream right away (the ordering the advisor found missing in round 1)."""
+    def check(env, oracles, episode, early, t, obs, rew, term, trunc):
+        A = env.prog.num_agents
+        obs_h, rew_h, term_h, trunc_h = obs.cpu().numpy(), rew.cpu().numpy(), term.cpu().numpy(), trunc.cpu().numpy()
+        for e, o in enumerate(oracles):
+            s = o.snapshot()
+            sl = slice(e * A, (e + 1) * A)
+            where = f"env {e} episode {episode[e]} step {t}"
+            assert np.array_equal(s["obs"], obs_h[sl]), where
+            assert np.array_equal(s["rewards"], rew_h[sl]), where
+            assert np.array_equal(s["terminals"], term_h[sl]), where
+            want_trunc = s["truncations"] | (episode[e] == 0 and o.current_step >= early[e])
+            assert np.array_equal(want_trunc, trunc_h[sl]), where
+    _pool_env_against_oracle("device", check=check)
+
+
+def test_host_pool_auto_reset_against_oracle():
+    def check(env, oracles, episode, early, t, obs, rew, term, trunc):
+        A = env.prog.num_agents
+        for e, o in enumerate(oracles):
+            s = o.snapshot()
+            sl = slice(e * A, (e + 1) * A)
+            assert np.array_equal(s["obs"], obs[sl]) and np.array_equal(s["rewards"], rew[sl]), (e, t)
+    _pool_env_against_oracle("host", check=check)
+
+
+def test_map_pool_rejects_maps_beyond_capacity_and_bad_ids():
+    spec = presets.rung2_spec()
+    prog = compile_spec(spec, 32, 32, max_objects=192)
+    maps = np.stack([prog.class_map(presets.rung2_map(s)) for s in range(2)])
+    eng = BatchedMettaGrid(prog, maps, [1, 2], buffers="host")
+    bad = maps.copy()
+    bad[0, 3, 3] = 999
+    with pytest.raises(ValueError):
+        eng.set_map_pool(bad)
+    with pytest.raises(ValueError):
+        BatchedMettaGrid(prog, bad, [1, 2], buffers="host")
