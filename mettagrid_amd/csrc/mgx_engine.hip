@@ -150,6 +150,7 @@ struct mgx_engine {
   void* d_stage = nullptr;          // staging for contiguous uploads of restart arguments
   size_t stage_bytes = 0;
   bool profiling = false;
+  bool timing_valid = false;   // a step has been recorded since profiling was switched on
   hipEvent_t ev[MGX_T_COUNT + 1] = {};  // boundaries of the timing segments of the most recent step (profiling only)
 
   template <class T>
@@ -959,6 +960,7 @@ int mgx_step(mgx_engine* e) {
   if (e->rewards_ext) { mgx_launch_values(e->stream, e->d, dev_copy(e), 1, nullptr); HIP_TRY(hipGetLastError()); }
   MGX_MARK(5);
 #undef MGX_MARK
+  if (e->profiling) e->timing_valid = true;
   if (e->auto_reset) {
     e->step_seq++;
 #ifdef MGX_CPU_EMU
@@ -1175,11 +1177,16 @@ int mgx_poll_errors(mgx_engine* e, uint32_t* bits, int32_t* first_env) {
 int mgx_set_profiling(mgx_engine* e, int32_t enabled) {
   if (!e) return fail(MGX_ERR_BAD_ARG, "mgx_set_profiling: null engine");
   e->profiling = enabled != 0;
+  e->timing_valid = false;
   return MGX_OK;
 }
 int mgx_get_step_timing(mgx_engine* e, float* ms_out) {
   if (!e || !ms_out) return fail(MGX_ERR_BAD_ARG, "mgx_get_step_timing: null argument");
   if (!e->profiling) return fail(MGX_ERR_BAD_ARG, "mgx_get_step_timing: profiling is off");
+  if (!e->timing_valid) {  // no step since profiling was switched on: nothing recorded yet
+    for (int k = 0; k < MGX_T_COUNT; k++) ms_out[k] = 0.f;
+    return MGX_OK;
+  }
   HIP_TRY(hipSetDevice(e->device));
   HIP_TRY(hipEventSynchronize(e->ev[MGX_T_COUNT]));
   for (int k = 0; k < MGX_T_COUNT; k++) HIP_TRY(hipEventElapsedTime(&ms_out[k], e->ev[k], e->ev[k + 1]));
