@@ -122,6 +122,14 @@ int mgx_set_inventory(mgx_engine* e, int32_t env, int32_t agent_id, const int32_
 /* tag_index().count_objects_with_tag(tag_id) — mettagrid_py.cpp:312,377-380: objects of env `env` registered under a tag. */
 int mgx_count_objects_with_tag(mgx_engine* e, int32_t env, int32_t tag_id, int32_t* out);
 
+/* Policy-side token decode — GridObsWrapper._convert, python/src/mettagrid/envs/grid_obs_wrapper.py:57-95:
+ * token rows u8 [n_rows][T][3] -> dense box f32 [n_rows][num_features][obs_height][obs_width] in DEVICE memory,
+ * box[row][f][y][x] += value / scale[f] for every token in row order (global tokens on the centre cell, padding skipped).
+ * tokens: device pointer, or NULL = the engine's bound observation buffer (device buffers) / its device mirror (host
+ * buffers), n_rows = E*A.  scale: float32 [256] HOST memory, scale[f] = max(normalization of feature f, 1)
+ * (grid_obs_wrapper.py:39-44; the Python mirror derives it from the compiled program).  Enqueued on the engine's stream. */
+int mgx_decode_obs(mgx_engine* e, const uint8_t* tokens, int64_t n_rows, float* box, int32_t num_features, const float* scale);
+
 /* OR of the per-env error bits over all envs; if first_env != NULL receives the first env with a bit set (or -1).
  * Replaces the exceptions thrown from inside step() in the reference. */
 int mgx_poll_errors(mgx_engine* e, uint32_t* bits, int32_t* first_env);

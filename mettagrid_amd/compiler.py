@@ -107,6 +107,7 @@ class Program:
     action_names: list
     feature_ids: dict                  # feature name -> id
     max_objects: int = 0
+    feature_norms: list = field(default_factory=list)   # id -> the reference's normalisation constant (id_map.py)
 
     @property
     def num_agents(self) -> int:
@@ -719,31 +720,37 @@ class _Compiler:
             raise UnsupportedFeature("token_value_base too small")
 
         # ---- feature ids (python/src/mettagrid/config/id_map.py:161-235) ----
+        # (name -> id, and the normalisation constant the reference attaches to each feature, id_map.py:161-235: what the
+        # policy-side decoders divide token values by)
         feats: dict[str, int] = {}
+        norms: list[float] = []
 
-        def add_feature(name: str) -> None:
+        def add_feature(name: str, normalization: float) -> None:
             feats[name] = len(feats)
+            norms.append(float(normalization))
 
-        for n in ("agent:group", "episode_completion_pct", "last_action", "last_reward", "goal", "vibe", "tag",
-                  "lp:east", "lp:west", "lp:north", "lp:south", "agent_id"):
-            add_feature(n)
+        for n, z in (("agent:group", 10.0), ("episode_completion_pct", 255.0), ("last_action", 10.0), ("last_reward", 100.0),
+                     ("goal", 100.0), ("vibe", 255.0), ("tag", 10.0), ("lp:east", 255.0), ("lp:west", 255.0), ("lp:north", 255.0),
+                     ("lp:south", 255.0), ("agent_id", 255.0)):
+            add_feature(n, z)
         for r in sp.resource_names:
-            add_feature(f"inv:{r}")
+            add_feature(f"inv:{r}", float(base))
             for p in range(1, digits):
-                add_feature(f"inv:{r}:p{p}")
+                add_feature(f"inv:{r}:p{p}", float(base))
         if sp.protocol_details_obs:
             for r in sp.resource_names:
-                add_feature(f"protocol_input:{r}")
+                add_feature(f"protocol_input:{r}", 100.0)
             for r in sp.resource_names:
-                add_feature(f"protocol_output:{r}")
+                add_feature(f"protocol_output:{r}", 100.0)
         for name in obs.values:
-            add_feature(name)
+            add_feature(name, float(base))
             for p in range(1, digits):
-                add_feature(f"{name}:p{p}")
+                add_feature(f"{name}:p{p}", float(base))
         if obs.aoe_mask:
-            add_feature("aoe_mask")
+            add_feature("aoe_mask", 3.0)
         if obs.last_action_move:
-            add_feature("last_action_move")
+            add_feature("last_action_move", 1.0)
+        self.feature_norms = norms
         if len(feats) > 255:
             raise ValueError("too many observation features")
         self.feats = feats
@@ -1065,4 +1072,4 @@ def compile_spec(spec: S.GameSpec, height: int, width: int, max_objects: int | N
                    tag_names=c.tag_names, type_names=c.type_names, class_cells=class_cells,
                    cell_to_class=cell_to_class, agent_rename=agent_rename, agent_stat_names=list(c.agent_stats),
                    game_stat_names=list(c.game_stats), action_names=action_names, feature_ids=dict(c.feats),
-                   max_objects=slots)
+                   max_objects=slots, feature_norms=list(c.feature_norms))

@@ -147,6 +147,9 @@ struct mgx_engine {
   bool auto_reset = false;
   int pool_stride = 1;
   uint32_t step_seq = 0;
+  float* d_scale = nullptr;         // per-feature scale of the token decode (mgx_decode_obs)
+  float scale_host[256] = {};
+  bool scale_valid = false;
   void* d_stage = nullptr;          // staging for contiguous uploads of restart arguments
   size_t stage_bytes = 0;
   bool profiling = false;
@@ -1155,6 +1158,27 @@ int mgx_count_objects_with_tag(mgx_engine* e, int32_t env, int32_t tag_id, int32
     count += (w >> (tag_id & 31)) & 1u;
   }
   *out = count;
+  return MGX_OK;
+}
+
+int mgx_launch_decode(hipStream_t stream, const uint8_t* tokens, float* box, const float* scale_dev, long long rows, int T, int C, int H, int W);
+
+int mgx_decode_obs(mgx_engine* e, const uint8_t* tokens, int64_t n_rows, float* box, int32_t num_features, const float* scale) {
+  if (!e || !box || !scale || num_features < 1 || num_features > 256) return fail(MGX_ERR_BAD_ARG, "mgx_decode_obs: bad argument");
+  HIP_TRY(hipSetDevice(e->device));
+  const MgxDev& d = e->d;
+  if (!tokens) { tokens = d.obs; n_rows = (int64_t)d.E * d.A; }
+  if (n_rows <= 0) return fail(MGX_ERR_BAD_ARG, "mgx_decode_obs: no rows");
+  if (!e->d_scale) { int rc = e->alloc(&e->d_scale, 256); if (rc) return rc; }
+  if (!e->scale_valid || memcmp(e->scale_host, scale, sizeof e->scale_host) != 0) {
+    memcpy(e->scale_host, scale, sizeof e->scale_host);
+    HIP_TRY(hipMemcpyAsync(e->d_scale, e->scale_host, sizeof e->scale_host, hipMemcpyHostToDevice, e->stream));
+    e->scale_valid = true;
+  }
+  const int rc = mgx_launch_decode(e->stream, tokens, box, e->d_scale, (long long)n_rows, d.T, num_features, e->prog[MGX_H_OBS_HEIGHT],
+                                   e->prog[MGX_H_OBS_WIDTH]);
+  if (rc == -1) return fail(MGX_ERR_PROGRAM, "mgx_decode_obs: the box of one agent does not fit the decode kernel's LDS");
+  if (rc) return fail(MGX_ERR_HIP, "mgx_decode_obs: launch failed");
   return MGX_OK;
 }
 

@@ -67,6 +67,7 @@ def load_lib():
     L.mgx_get_reward_state.argtypes = [vp, i32, vp]
     L.mgx_poll_errors.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(i32)]
     L.mgx_set_inventory.argtypes = [vp, i32, i32, vp, vp, i32]
+    L.mgx_decode_obs.argtypes = [vp, vp, i64, vp, i32, vp]
     L.mgx_set_map_pool.argtypes = [vp, vp, i32]
     L.mgx_reset_envs_from_pool.argtypes = [vp, vp, vp, vp]
     L.mgx_set_auto_reset.argtypes = [vp, i32, i32, vp]
@@ -345,6 +346,36 @@ class BatchedMettaGrid:
         out = C.c_int32(0)
         _check(self.L.mgx_count_objects_with_tag(self.h, int(env), int(tag_id), C.byref(out)))
         return out.value
+
+    # ---- policy-side token decode ----
+    def feature_scale(self) -> np.ndarray:
+        """scale[f] = max(normalization of feature f, 1) (grid_obs_wrapper.py:39-44), from the compiled program."""
+        scale = np.ones(256, np.float32)
+        for i, z in enumerate(self.prog.feature_norms):
+            scale[i] = max(float(z), 1.0)
+        return scale
+
+    def decode_obs(self, out=None, tokens=None):
+        """Dense float32 box [rows, C, H, W] of the current observations (``GridObsWrapper._convert``), computed on the
+        GPU and ordered on the engine's stream.  ``out``: torch CUDA tensor to fill (allocated if None); ``tokens``: another
+        token tensor u8 [rows, T, 3] on the device instead of the engine's own observation buffer."""
+        import torch
+        Cn = len(self.prog.feature_norms)
+        Hh, Ww = int(self.prog.words[K.H_OBS_HEIGHT]), int(self.prog.words[K.H_OBS_WIDTH])
+        dev = torch.device("cuda", self.device)
+        rows = self.E * self.A if tokens is None else int(tokens.shape[0])
+        if out is None:
+            out = torch.empty((rows, Cn, Hh, Ww), dtype=torch.float32, device=dev)
+        if tuple(out.shape) != (rows, Cn, Hh, Ww) or out.dtype != torch.float32 or not out.is_contiguous():
+            raise ValueError(f"out must be a contiguous float32 tensor of shape {(rows, Cn, Hh, Ww)}")
+        scale = self.feature_scale()
+        tok_ptr = None
+        if tokens is not None:
+            if tokens.dtype != torch.uint8 or not tokens.is_contiguous() or tokens.shape[1:] != (self.T, 3):
+                raise ValueError("tokens must be a contiguous uint8 tensor [rows, T, 3]")
+            tok_ptr = tokens.data_ptr()
+        _check(self.L.mgx_decode_obs(self.h, tok_ptr, rows, out.data_ptr(), Cn, scale.ctypes.data))
+        return out
 
     def set_profiling(self, on: bool) -> None:
         _check(self.L.mgx_set_profiling(self.h, 1 if on else 0))
