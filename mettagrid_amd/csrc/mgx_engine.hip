@@ -63,6 +63,9 @@ __global__ void mgx_set_inventory_kernel(const MgxDev* __restrict__ dp, int env,
   for (int i = 0; i < n; i++) e.inv_update<1>(slot, items[i], amounts[i] - (int)e.inv(slot, items[i]));
 }
 
+// token decode kernel (mgx_decode.hip)
+int mgx_launch_decode(hipStream_t stream, const uint8_t* tokens, float* box, const float* scale_dev, long long rows, int T, int C, int H, int W);
+
 static thread_local std::string g_err;
 static int fail(int code, const std::string& msg) {
   g_err = msg;
@@ -1160,8 +1163,6 @@ int mgx_count_objects_with_tag(mgx_engine* e, int32_t env, int32_t tag_id, int32
   *out = count;
   return MGX_OK;
 }
-
-int mgx_launch_decode(hipStream_t stream, const uint8_t* tokens, float* box, const float* scale_dev, long long rows, int T, int C, int H, int W);
 
 int mgx_decode_obs(mgx_engine* e, const uint8_t* tokens, int64_t n_rows, float* box, int32_t num_features, const float* scale) {
   if (!e || !box || !scale || num_features < 1 || num_features > 256) return fail(MGX_ERR_BAD_ARG, "mgx_decode_obs: bad argument");
