@@ -130,6 +130,13 @@ int mgx_count_objects_with_tag(mgx_engine* e, int32_t env, int32_t tag_id, int32
  * (grid_obs_wrapper.py:39-44; the Python mirror derives it from the compiled program).  Enqueued on the engine's stream. */
 int mgx_decode_obs(mgx_engine* e, const uint8_t* tokens, int64_t n_rows, float* box, int32_t num_features, const float* scale);
 
+/* One 64-bit digest per env (uint64 [E], host memory) of everything the episode signature is made of: the
+ * mgx_get_objects records of the live slots, every stat value and "key exists" flag (mgx_get_stats), episode rewards,
+ * action_success, current_stat_reward (mgx_get_reward_state) and the current step — FNV-1a over 32-bit words, restated in
+ * mettagrid_amd/signature.py::state_digest.  grid_objects() / the signature script at scale: two states
+ * with equal payloads have equal digests, computed for all envs by one kernel. */
+int mgx_state_digests(mgx_engine* e, uint64_t* out);
+
 /* OR of the per-env error bits over all envs; if first_env != NULL receives the first env with a bit set (or -1).
  * Replaces the exceptions thrown from inside step() in the reference. */
 int mgx_poll_errors(mgx_engine* e, uint32_t* bits, int32_t* first_env);

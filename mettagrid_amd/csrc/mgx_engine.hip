@@ -63,6 +63,83 @@ __global__ void mgx_set_inventory_kernel(const MgxDev* __restrict__ dp, int env,
   for (int i = 0; i < n; i++) e.inv_update<1>(slot, items[i], amounts[i] - (int)e.inv(slot, items[i]));
 }
 
+// ---- batched state digests --------------------------------------------------------------------------
+// One 64-bit digest per env over exactly what the episode signature is made of — the mgx_get_objects records, every stat
+// value + "key exists" flag, episode rewards, action_success, current_stat_reward, current step — so that the signature of
+// all 65 536 envs costs one kernel and one 512 KB copy instead of 65 536 round trips.  FNV-1a over 32-bit words; the
+// objects are hashed per slot by the lanes of a wavefront and the slot hashes chained in slot order.
+__device__ __forceinline__ unsigned long long mgx_fnv(unsigned long long h, uint32_t w) {
+  return (h ^ (unsigned long long)w) * 1099511628211ull;
+}
+#define MGX_FNV_BASIS 14695981039346656037ull
+__global__ void __launch_bounds__(MGX_WAVE) mgx_digest_kernel(const MgxDev* __restrict__ dp, unsigned long long* out) {
+  const MgxDev& d = *dp;
+  __shared__ unsigned long long slot_hash[MGX_WAVE];
+  const int env = blockIdx.x, lane = threadIdx.x;
+  MgxEnvX e(d, d.P, env);
+  const int n = (int)d.num_objs[env];
+  unsigned long long h = MGX_FNV_BASIS;
+  h = mgx_fnv(h, d.step[env]);
+  h = mgx_fnv(h, (uint32_t)n);
+  for (int s0 = 0; s0 < n; s0 += MGX_WAVE) {
+    const int s = s0 + lane;
+    unsigned long long hs = MGX_FNV_BASIS;
+    if (s < n) {   // the 42 words of the slot's mgx_get_objects record
+      const size_t o = e.so(s);
+      const uint16_t cls = d.obj_cls[o], rc = d.obj_rc[o];
+      const uint8_t oflags = d.obj_flags ? d.obj_flags[o] : 0;
+      const uint8_t ag = d.obj_agent[o];
+      const unsigned long long ord = d.obj_order[o];
+      hs = mgx_fnv(hs, (uint32_t)(s + 1)); hs = mgx_fnv(hs, cls); hs = mgx_fnv(hs, rc >> 8); hs = mgx_fnv(hs, rc & 0xFF);
+      hs = mgx_fnv(hs, d.obj_vibe[o]); hs = mgx_fnv(hs, (cls != MGX_DEAD_CLASS && !(oflags & 1)) ? 1u : 0u);
+      hs = mgx_fnv(hs, ag == MGX_NO_AGENT ? 0xFFFFFFFFu : (uint32_t)ag);
+      int cnt = 0;
+      uint32_t items[MGX_MAX_RESOURCES];
+      bool ended = false;
+#pragma unroll
+      for (int k = 0; k < MGX_MAX_RESOURCES; k++) {
+        const int item = (int)((ord >> (4 * k)) & 0xF);
+        ended = ended || item == 0xF;
+        items[k] = ended ? 0xFFFFFFFFu : (uint32_t)item;
+        cnt += ended ? 0 : 1;
+      }
+      hs = mgx_fnv(hs, (uint32_t)cnt);
+#pragma unroll
+      for (int k = 0; k < MGX_MAX_RESOURCES; k++) hs = mgx_fnv(hs, items[k]);
+      for (int k = 0; k < MGX_MAX_RESOURCES; k++) hs = mgx_fnv(hs, k < d.R ? (uint32_t)d.obj_inv[o * MGX_INV_PITCH + k] : 0u);
+      for (int k = 0; k < MGX_TAG_WORDS; k++)
+        hs = mgx_fnv(hs, d.obj_tags ? d.obj_tags[o * MGX_TAG_WORDS + k]
+                                     : (cls != MGX_DEAD_CLASS ? (uint32_t)mgx_cls(d, cls)[MGX_C_TAGS + k] : 0u));
+    }
+    slot_hash[lane] = hs;
+    __syncthreads();
+    if (lane == 0)
+      for (int k = 0; k < MGX_WAVE && s0 + k < n; k++) { h = mgx_fnv(h, (uint32_t)slot_hash[k]); h = mgx_fnv(h, (uint32_t)(slot_hash[k] >> 32)); }
+    __syncthreads();
+  }
+  if (lane != 0) return;
+  for (int i = 0; i < d.NG; i++) {   // game stats: value bits + key exists (mgx_get_stats)
+    const float v = d.game_stats[(size_t)env * d.NG + i];
+    const uint32_t t = ((d.game_touched[(size_t)env * d.NGW + (i >> 5)] >> (i & 31)) & 1u) | (v != 0.f ? 1u : 0u);
+    h = mgx_fnv(h, __float_as_uint(v)); h = mgx_fnv(h, t);
+  }
+  for (int a = 0; a < d.A; a++) {
+    for (int i = 0; i < d.NS; i++) {
+      const float v = d.ag_stats[e.ao(a) * d.NSP + i];
+      const uint32_t t = ((d.ag_touched[e.ao(a) * d.NSW + (i >> 5)] >> (i & 31)) & 1u) | (v != 0.f ? 1u : 0u);
+      h = mgx_fnv(h, __float_as_uint(v)); h = mgx_fnv(h, t);
+    }
+    h = mgx_fnv(h, __float_as_uint(d.episode_rewards[e.ao(a)]));
+    h = mgx_fnv(h, (uint32_t)d.success[e.ao(a)]);
+    const uint16_t c = d.obj_cls[e.so(d.ag_obj[e.ao(a)])];   // current_stat_reward (systems/reward.hpp:36-42)
+    const int nrw = c == MGX_DEAD_CLASS ? 0 : mgx_cls(d, c)[MGX_C_REWARD_COUNT];
+    float tot = 0.f;
+    for (int k = 0; k < nrw; k++) tot = __fadd_rn(tot, d.ag_rprev[e.ao(a) * d.NRW + k]);
+    h = mgx_fnv(h, __float_as_uint(tot));
+  }
+  out[env] = h;
+}
+
 // token decode kernel (mgx_decode.hip)
 int mgx_launch_decode(hipStream_t stream, const uint8_t* tokens, float* box, const float* scale_dev, long long rows, int T, int C, int H, int W);
 
@@ -150,6 +227,7 @@ struct mgx_engine {
   bool auto_reset = false;
   int pool_stride = 1;
   uint32_t step_seq = 0;
+  unsigned long long* d_digest = nullptr;   // [E] mgx_state_digests
   float* d_scale = nullptr;         // per-feature scale of the token decode (mgx_decode_obs)
   float scale_host[256] = {};
   bool scale_valid = false;
@@ -1162,6 +1240,15 @@ int mgx_count_objects_with_tag(mgx_engine* e, int32_t env, int32_t tag_id, int32
   }
   *out = count;
   return MGX_OK;
+}
+
+int mgx_state_digests(mgx_engine* e, uint64_t* out) {
+  if (!e || !out) return fail(MGX_ERR_BAD_ARG, "mgx_state_digests: null argument");
+  HIP_TRY(hipSetDevice(e->device));
+  if (!e->d_digest) { int rc = e->alloc(&e->d_digest, (size_t)e->d.E); if (rc) return rc; }
+  hipLaunchKernelGGL(mgx_digest_kernel, dim3((unsigned)e->d.E), dim3(MGX_WAVE), 0, e->stream, dev_copy(e), e->d_digest);
+  HIP_TRY(hipGetLastError());
+  return d2h(e, out, e->d_digest, (size_t)e->d.E * 8);
 }
 
 int mgx_decode_obs(mgx_engine* e, const uint8_t* tokens, int64_t n_rows, float* box, int32_t num_features, const float* scale) {

@@ -68,6 +68,7 @@ def load_lib():
     L.mgx_poll_errors.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(i32)]
     L.mgx_set_inventory.argtypes = [vp, i32, i32, vp, vp, i32]
     L.mgx_decode_obs.argtypes = [vp, vp, i64, vp, i32, vp]
+    L.mgx_state_digests.argtypes = [vp, vp]
     L.mgx_set_map_pool.argtypes = [vp, vp, i32]
     L.mgx_reset_envs_from_pool.argtypes = [vp, vp, vp, vp]
     L.mgx_set_auto_reset.argtypes = [vp, i32, i32, vp]
@@ -346,6 +347,12 @@ class BatchedMettaGrid:
         out = C.c_int32(0)
         _check(self.L.mgx_count_objects_with_tag(self.h, int(env), int(tag_id), C.byref(out)))
         return out.value
+
+    def state_digests(self) -> np.ndarray:
+        """uint64 [E]: digest of every env's signature state (objects, stats, rewards, success, step) in one kernel."""
+        out = np.empty(self.E, np.uint64)
+        _check(self.L.mgx_state_digests(self.h, out.ctypes.data))
+        return out
 
     # ---- policy-side token decode (SURVEY.md §8f-3) ----
     def feature_scale(self) -> np.ndarray:

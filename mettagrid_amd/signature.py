@@ -78,3 +78,33 @@ def payload(objects: dict, stats: dict, action_success, episode_rewards, steps: 
 
 def signature(p: dict) -> str:
     return hashlib.sha256(json.dumps(p, sort_keys=True, separators=(",", ":")).encode("utf-8")).hexdigest()
+
+
+# ---- batched state digest (include/mgx.h mgx_state_digests) ------------------------------------------------------------
+_FNV_BASIS, _FNV_PRIME, _M64 = 14695981039346656037, 1099511628211, (1 << 64) - 1
+
+
+def _fnv(h: int, w: int) -> int:
+    return ((h ^ (int(w) & 0xFFFFFFFF)) * _FNV_PRIME) & _M64
+
+
+def state_digest(raw_objects: np.ndarray, raw_stats, episode_rewards, action_success, current_stat_reward, step: int) -> int:
+    """The digest mgx_state_digests computes for one env, from the raw dumps every engine offers (the HIP engine through
+    mgx_get_objects / mgx_get_stats / ..., the CPU oracle through its mgxo_* twins)."""
+    gv, gt, av, at = raw_stats
+    h = _fnv(_fnv(_FNV_BASIS, step), len(raw_objects))
+    for rec in raw_objects:
+        hs = _FNV_BASIS
+        for w in rec:
+            hs = _fnv(hs, int(w))
+        h = _fnv(_fnv(h, hs & 0xFFFFFFFF), hs >> 32)
+    bits = lambda x: int(np.float32(x).view(np.uint32))  # noqa: E731
+    for i in range(len(gv)):
+        h = _fnv(_fnv(h, bits(gv[i])), int(bool(gt[i]) or gv[i] != 0))
+    for a in range(av.shape[0]):
+        for i in range(av.shape[1]):
+            h = _fnv(_fnv(h, bits(av[a, i])), int(bool(at[a, i]) or av[a, i] != 0))
+        h = _fnv(h, bits(episode_rewards[a]))
+        h = _fnv(h, int(bool(action_success[a])))
+        h = _fnv(h, bits(current_stat_reward[a]))
+    return h
