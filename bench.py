@@ -93,7 +93,8 @@ def main() -> None:
     ap.add_argument("--envs", type=int, default=65536, help="envs per GPU")
     ap.add_argument("--rung", type=int, default=3, help="3 = BASELINE.json configs[2] (the headline metric), 4 = configs[3]")
     ap.add_argument("--gather", choices=["none", "scalars", "obs"], default="none",
-                    help="optional per-step RCCL all_gather of rewards/terminals/truncations (+obs)")
+                    help="optional per-step gather of rewards/terminals/truncations (+obs) to rank 0: grouped RCCL "
+                         "send/recv over xGMI on a side stream, overlapped with the next step (mettagrid_amd/dist.py)")
     ap.add_argument("--cpu-steps", type=int, default=0, help="CPU baseline sample (default: about 10 s of one host core)")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
@@ -111,15 +112,15 @@ def main() -> None:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from mettagrid_amd.compiler import compile_spec
+    from mettagrid_amd.dist import GatherToRoot, env_shard, shard_seeds
     from mettagrid_amd.engine import BatchedMettaGrid
     from mettagrid_amd.mapgen import random_class_maps
 
     spec, H, W, S, objs, agents, mapf, desc, per = workload(args.rung)
     prog = compile_spec(spec, H, W, max_objects=S)
     E, A, T = args.envs, prog.num_agents, prog.num_tokens
-    env0 = rank * E
-    cms = random_class_maps(prog, H, W, objs, agents, range(env0, env0 + E))
-    seeds = np.arange(env0, env0 + E, dtype=np.uint32)
+    cms = random_class_maps(prog, H, W, objs, agents, env_shard(rank, world, E))   # map seed = global env index
+    seeds = shard_seeds(rank, world, E)
     eng = BatchedMettaGrid(prog, cms, seeds, device=local_rank, buffers="device")
     del cms
 
@@ -132,25 +133,20 @@ def main() -> None:
     ext = torch.cuda.ExternalStream(eng.stream, device=torch.device("cuda", local_rank))
     torch.cuda.synchronize()
 
-    gathered = None
+    gather = None
     if world > 1 and args.gather != "none":
-        gathered = [torch.empty(world * E * A, dtype=torch.float32, device="cuda"),
-                    torch.empty(world * E * A, dtype=torch.bool, device="cuda"),
-                    torch.empty(world * E * A, dtype=torch.bool, device="cuda")]
-        if args.gather == "obs":
-            gathered.append(torch.empty((world * E * A, T, 3), dtype=torch.uint8, device="cuda"))
+        gather = GatherToRoot(dist, root=0, device=torch.device("cuda", local_rank), producer_stream=ext)
 
     def one_step(t: int) -> None:
         with torch.cuda.stream(ext):  # everything is ordered on the engine's stream
             eng.actions.copy_(pre_a[t % cycle], non_blocking=True)
             eng.vibe_actions.copy_(pre_v[t % cycle], non_blocking=True)
             eng.step()
-            if gathered is not None:
-                dist.all_gather_into_tensor(gathered[0], eng.rewards)
-                dist.all_gather_into_tensor(gathered[1], eng.terminals)
-                dist.all_gather_into_tensor(gathered[2], eng.truncations)
-                if args.gather == "obs":
-                    dist.all_gather_into_tensor(gathered[3], eng.obs)
+        if gather is not None:   # staging copy + grouped send/recv on the side stream; step t+1 is not held back
+            out = {"rewards": eng.rewards, "terminals": eng.terminals, "truncations": eng.truncations}
+            if args.gather == "obs":
+                out["observations"] = eng.obs
+            gather.submit(out)
 
     for t in range(args.warmup):
         one_step(t)
@@ -167,6 +163,8 @@ def main() -> None:
     with torch.cuda.stream(ext):
         ev1.record(ext)
     eng.sync()
+    if gather is not None:
+        gather.finish()
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1)

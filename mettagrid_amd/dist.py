@@ -1,10 +1,12 @@
 """Multi-GPU sharding of the step path: one process per GPU, envs partitioned by index, no exchange inside a tick.
 
 Envs are fully independent (no cross-env state, per-env RNG), so rank r of W owns the global envs
-[r*E, (r+1)*E).  The tick itself needs no collective.  What a trainer may want afterwards is the rank-ordered
-concatenation of the small per-agent outputs (rewards f32, terminals/truncations bool) and — optionally — of the
-observation buffer; ``gather_outputs`` does that with ``all_gather_into_tensor`` (RCCL over xGMI on GPUs, gloo on
-CPU in the tests).  Rows keep the global order: row = global_env * A + agent.
+[r*E, (r+1)*E) and the tick needs no collective.  What a consumer may want afterwards is the rank-ordered
+concatenation of the per-agent outputs on ONE rank (the trainer): ``GatherToRoot`` ships them with grouped point-to-point
+sends — every peer writes its rows straight to the root over its own xGMI link (7 links x ~153 GB/s into the root), which
+is what SURVEY.md §8e prescribes for the 629 MB/GPU observation payload; a ring all-gather would be bound by one link.
+The sends run on a side stream from double-buffered staging copies, so step k+1 overlaps the gather of step k.
+Rows keep the global order: row = global_env * A + agent.  (gloo on CPU in the tests, RCCL = backend "nccl" on GPUs.)
 """
 from __future__ import annotations
 
@@ -24,24 +26,84 @@ def shard_seeds(rank: int, world: int, envs_per_rank: int) -> np.ndarray:
     return np.arange(r.start, r.stop, dtype=np.uint32)
 
 
-def gather_outputs(dist, rewards, terminals, truncations, observations=None):
-    """all_gather the per-rank output rows into rank-major global tensors.  ``dist`` is ``torch.distributed``."""
-    import torch
-    world = dist.get_world_size()
+class GatherToRoot:
+    """Per-step gather of named per-rank tensors to ``root`` (rank-major rows), pipelined behind the producer.
 
-    def gather(t):
-        out = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-        if t.dtype == torch.bool:  # gloo has no bool all_gather; ship as u8
-            tmp = torch.empty(out.shape, dtype=torch.uint8, device=t.device)
-            dist.all_gather_into_tensor(tmp, t.to(torch.uint8).contiguous())
-            return tmp.to(torch.bool)
-        dist.all_gather_into_tensor(out, t.contiguous())
-        return out
+    ``submit(tensors)`` — called right after the producing work has been enqueued on ``producer_stream`` — copies the
+    tensors into staging slot ``k % 2`` and issues the grouped send/recv on a side stream; it never blocks the producer
+    stream, which is only made to wait before a staging slot is reused two submits later.  ``result()`` returns the root's
+    view of the most recent completed gather (dict name -> tensor of world * rows) or None on the other ranks.
+    On CPU tensors (gloo) everything is synchronous.
+    """
 
-    res = {"rewards": gather(rewards), "terminals": gather(terminals), "truncations": gather(truncations)}
-    if observations is not None:
-        res["observations"] = gather(observations)
-    return res
+    def __init__(self, dist, root: int = 0, device=None, producer_stream=None) -> None:
+        import torch
+        self.dist, self.root, self.torch = dist, root, torch
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.device = device
+        self.cuda = device is not None and torch.device(device).type == "cuda"
+        self.producer = producer_stream
+        self.side = torch.cuda.Stream(device=device) if self.cuda else None
+        self.stage = [None, None]
+        self.out = [None, None]
+        self.done = [None, None]
+        self.k = 0
+
+    def _alloc(self, tensors: dict) -> None:
+        torch = self.torch
+        for s in range(2):
+            self.stage[s] = {n: torch.empty_like(t, dtype=torch.uint8 if t.dtype == torch.bool else t.dtype) for n, t in tensors.items()}
+            if self.rank == self.root:
+                self.out[s] = {n: torch.empty((self.world * t.shape[0],) + tuple(t.shape[1:]), dtype=self.stage[s][n].dtype,
+                                              device=t.device) for n, t in tensors.items()}
+
+    def submit(self, tensors: dict) -> None:
+        torch, dist = self.torch, self.dist
+        if self.stage[0] is None:
+            self._alloc(tensors)
+        s = self.k % 2
+        self.k += 1
+        if self.cuda:
+            if self.done[s] is not None:
+                self.done[s].synchronize() if self.producer is None else self.producer.wait_event(self.done[s])
+            ready = torch.cuda.Event()
+            ready.record(self.producer if self.producer is not None else torch.cuda.current_stream(self.device))
+            self.side.wait_event(ready)
+            ctx = torch.cuda.stream(self.side)
+        else:
+            import contextlib
+            ctx = contextlib.nullcontext()
+        with ctx:
+            for n, t in tensors.items():
+                self.stage[s][n].copy_(t)          # bool -> u8 here (gloo has no bool transport)
+            ops = []
+            for n, st in self.stage[s].items():
+                if self.rank == self.root:
+                    rows = st.shape[0]
+                    self.out[s][n][self.root * rows:(self.root + 1) * rows].copy_(st)
+                    for peer in range(self.world):
+                        if peer != self.root:
+                            ops.append(dist.P2POp(dist.irecv, self.out[s][n][peer * rows:(peer + 1) * rows], peer))
+                else:
+                    ops.append(dist.P2POp(dist.isend, st, self.root))
+            if ops:
+                for req in dist.batch_isend_irecv(ops):   # one ncclGroupStart/End: all peers write concurrently
+                    req.wait()
+            if self.cuda:
+                self.done[s] = torch.cuda.Event()
+                self.done[s].record(self.side)
+        self.last = s
+
+    def result(self, bool_names=("terminals", "truncations")):
+        if self.k == 0 or self.rank != self.root:
+            return None
+        if self.cuda:
+            self.done[self.last].synchronize()
+        return {n: (t.to(self.torch.bool) if n in bool_names else t) for n, t in self.out[self.last].items()}
+
+    def finish(self) -> None:
+        if self.cuda and self.k:
+            self.side.synchronize()
 
 
 def max_over_ranks(dist, seconds: float, device="cpu") -> float:

@@ -70,6 +70,32 @@ def decode_actions(actions, num_primary: int, vibe_action_ids, xp=np):
     return core, vibe
 
 
+def split_supervisor_actions_inplace(teacher_actions, vibe_actions, *, num_primary_actions: int, vibe_action_ids_by_index) -> None:
+    """Supervisor (teacher) labels in split-action id space -> primary labels + the simulator's vibe stream, in place:
+    ``split_supervisor_actions_inplace`` of the reference (python/src/mettagrid/policy/supervisor_actions.py:8-40).  Labels
+    in [0, P) are primary actions; labels in [P, P + V) are vibe v = label - P and fill ``vibe_actions`` with that vibe's
+    engine action id, 0 elsewhere.  numpy arrays or torch tensors (torch: the range check is one device->host read)."""
+    is_np = isinstance(teacher_actions, np.ndarray)
+    t64 = teacher_actions.astype(np.int64) if is_np else teacher_actions.long()
+    n_vibe = int(len(vibe_action_ids_by_index))
+    max_id = num_primary_actions + n_vibe - 1
+    invalid = (t64 < 0) | (t64 > max_id)
+    if bool(invalid.any()):
+        bad = int(np.flatnonzero(invalid)[0]) if is_np else int(invalid.nonzero()[0, 0])
+        raise ValueError(f"Supervisor produced invalid action id {int(teacher_actions[bad])} for agent {bad}")
+    primary = t64 < num_primary_actions
+    if is_np:
+        vibe_actions.fill(0)
+        idx = t64[~primary] - num_primary_actions
+        vibe_actions[~primary] = np.asarray(vibe_action_ids_by_index)[idx].astype(vibe_actions.dtype)
+    else:
+        import torch
+        ids = torch.as_tensor(vibe_action_ids_by_index, device=teacher_actions.device).long()
+        idx = (t64 - num_primary_actions).clamp(min=0)
+        vibe_actions.copy_(torch.where(primary, torch.zeros_like(t64), ids[idx * (~primary)] if n_vibe else torch.zeros_like(t64))
+                           .to(vibe_actions.dtype))
+
+
 def decode_actions_unchecked(a, num_primary: int, vibe_action_ids):
     """decode_actions for torch tensors without the range checks (each of them is a device->host read)."""
     import torch
@@ -131,6 +157,29 @@ class MettaGridBatchedEnv:
         self.episode = np.zeros(num_envs, np.int64)
         self._eng: Optional[BatchedMettaGrid] = None
         self._vibe_ids = None
+        self.supervisor = None          # object with step_batch(raw_observations, teacher_actions), see set_supervisor
+        self.teacher_actions = None
+
+    def set_supervisor(self, supervisor) -> None:
+        """Supervisor-policy path of MettaGridPufferEnv (mettagrid_puffer_env.py:399-426): after every step
+        ``supervisor.step_batch(observations, teacher_actions)`` fills ``teacher_actions`` (split-action id space) and the
+        vibe labels are routed into the engine's vibe stream for the next step."""
+        self.supervisor = supervisor
+
+    def disable_supervisor(self) -> None:
+        self.supervisor = None
+
+    def _compute_supervisor_actions(self) -> None:
+        eng = self.engine
+        if self.teacher_actions is None:
+            if self._kind == "device":
+                import torch
+                self.teacher_actions = torch.zeros(self.num_agents, dtype=torch.int32, device=eng.obs.device)
+            else:
+                self.teacher_actions = np.zeros(self.num_agents, np.int32)
+        self.supervisor.step_batch(eng.obs, self.teacher_actions)
+        split_supervisor_actions_inplace(self.teacher_actions, eng.vibe_actions, num_primary_actions=len(self.action_names),
+                                         vibe_action_ids_by_index=self._vibe_ids if self._kind != "device" else self._vibe_ids)
 
     # spaces (shapes only; gymnasium is not a dependency)
     @property
@@ -227,6 +276,8 @@ class MettaGridBatchedEnv:
             eng.wait_for_caller()   # the engine's kernels read the actions written on the caller's stream ...
             eng.step()
             eng.caller_waits()      # ... and whatever the caller enqueues next sees this step's results
+            if self.supervisor is not None:
+                self._compute_supervisor_actions()
         else:
             a = np.asarray(actions)
             core, vibe = decode_actions(a, len(self.action_names), self._vibe_ids, xp=np)
@@ -238,9 +289,80 @@ class MettaGridBatchedEnv:
             else:
                 eng.vibe_actions.fill(0)
             eng.step()
+            if self.supervisor is not None:
+                self._compute_supervisor_actions()
         return eng.obs, eng.rewards, eng.terminals, eng.truncations, {}
 
     def close(self) -> None:
         if self._eng is not None:
             self._eng.close()
             self._eng = None
+
+
+class MettaGridParallelEnv:
+    """PettingZoo ``ParallelEnv`` call pattern over ONE env of the engine — the surface of the reference's
+    ``MettaGridPettingZooEnv`` (python/src/mettagrid/envs/pettingzoo_env.py:22-230): integer agent ids, ``reset(seed) ->
+    (obs dict, info dict)``, ``step({agent: action}) -> (obs, rewards, terminations, truncations, infos)`` as dicts keyed by
+    agent id, finished agents dropped from ``agents``, one shared observation / action space for all agents.  pettingzoo and
+    gymnasium themselves are not imported: spaces are described by shape / size."""
+
+    def __init__(self, env_cfg, map, seed: int = 0, device: int = 0) -> None:  # noqa: A002 - reference argument name
+        from .engine import MettaGrid
+        self._make = lambda s: MettaGrid(env_cfg, map, s, device=device)
+        self._seed = seed
+        self._sim = self._make(seed)
+        names = self._sim.prog.action_names
+        self._action_indices = list(range(len(names)))      # PolicyEnvInterface.action_names -> engine action ids
+        self.possible_agents = list(range(self._sim._num_agents))
+        self.agents = list(self.possible_agents)
+        self.observation_shape = (self._sim.prog.num_tokens, 3)
+
+    def reset(self, seed: Optional[int] = None, options=None):
+        if seed is not None:
+            self._seed = seed
+        self._sim._b.close()
+        self._sim = self._make(self._seed)
+        self.agents = list(self.possible_agents)
+        obs = self._sim.observations()
+        return {a: obs[a] for a in self.agents}, {a: {} for a in self.agents}
+
+    def step(self, actions: dict):
+        sim = self._sim
+        arr = sim.actions()
+        for a in self.agents:
+            if a in actions:
+                idx = int(np.asarray(actions[a], dtype=np.int32).reshape(()).item())
+                if idx < 0 or idx >= len(self._action_indices):
+                    raise ValueError(f"Action index {idx} out of range for PettingZoo action space.")
+                arr[a] = self._action_indices[idx]
+        sim.step()
+        obs, rew, term, trunc = sim.observations(), sim.rewards(), sim.terminals(), sim.truncations()
+        out = ({a: obs[a] for a in self.agents}, {a: float(rew[a]) for a in self.agents}, {a: bool(term[a]) for a in self.agents},
+               {a: bool(trunc[a]) for a in self.agents}, {a: {} for a in self.agents})
+        self.agents = [a for a in self.agents if not (out[2][a] or out[3][a])]
+        return out
+
+    def observation_space_shape(self, agent: int):
+        return self.observation_shape
+
+    def action_space_n(self, agent: int) -> int:
+        return len(self._action_indices)
+
+    def state(self) -> np.ndarray:   # pettingzoo_env.py:178-190: a zero vector of the flattened observation size
+        return np.zeros(len(self.possible_agents) * int(np.prod(self.observation_shape)), np.uint8)
+
+    @property
+    def max_num_agents(self) -> int:
+        return len(self.possible_agents)
+
+    @property
+    def max_steps(self) -> int:
+        return self._sim.max_steps
+
+    def render(self) -> None:
+        pass
+
+    def close(self) -> None:
+        if self._sim is not None:
+            self._sim._b.close()
+            self._sim = None

@@ -1,5 +1,6 @@
-"""N>1 path on CPU: world_size-2 gloo.  Each rank steps the oracle on ITS env shard; the gathered outputs must equal
-a single-process run over all envs (checks shard mapping, seed assignment and rank-major row order)."""
+"""N>1 path on CPU: world_size-2 gloo, driving the code bench.py itself uses for N > 1 (mettagrid_amd/dist.py: env_shard,
+shard_seeds, GatherToRoot).  Each rank steps the oracle on ITS env shard; what the root gathers — over several pipelined
+submits — must equal a single-process run over all envs (shard mapping, seed assignment, rank-major row order)."""
 import os
 import socket
 import sys
@@ -27,27 +28,37 @@ def _run_envs(env_ids):
     cms = random_class_maps(prog, 32, 32, {"wall": 40, "extractor": 8, "chest": 4}, {"red": 8, "blue": 8}, env_ids)
     sims = [op.OracleSim(prog, cms[i], int(e)) for i, e in enumerate(env_ids)]
     A, n = prog.num_agents, len(prog.action_names)
+    per_step = []
     for t in range(STEPS):
         for i, e in enumerate(env_ids):
             rng = np.random.RandomState(1000 * int(e) + t)
             sims[i].step(rng.randint(0, n, A), rng.randint(0, n, A))
-    snaps = [s.snapshot() for s in sims]
-    return {k: np.concatenate([s[k] for s in snaps]) for k in ("rewards", "terminals", "truncations", "obs")}
+        snaps = [s.snapshot() for s in sims]
+        per_step.append({k: np.concatenate([s[k] for s in snaps]) for k in ("rewards", "terminals", "truncations", "obs")})
+    return per_step
 
 
 def _worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     sys.path.insert(0, ROOT)
-    from mettagrid_amd.dist import env_shard, gather_outputs, max_over_ranks, shard_seeds
+    from mettagrid_amd.dist import GatherToRoot, env_shard, max_over_ranks, shard_seeds
     ids = list(env_shard(rank, world, E_PER_RANK))
     assert list(shard_seeds(rank, world, E_PER_RANK)) == ids
-    out = _run_envs(ids)
-    g = gather_outputs(dist, torch.from_numpy(out["rewards"]), torch.from_numpy(out["terminals"]),
-                       torch.from_numpy(out["truncations"]), torch.from_numpy(out["obs"]))
+    steps = _run_envs(ids)
+    gather = GatherToRoot(dist, root=0)
+    got = []
+    for out in steps:                      # one submit per step, like bench.py --gather obs
+        gather.submit({"rewards": torch.from_numpy(out["rewards"]), "terminals": torch.from_numpy(out["terminals"]),
+                       "truncations": torch.from_numpy(out["truncations"]), "observations": torch.from_numpy(out["obs"])})
+        res = gather.result()
+        assert (res is None) == (rank != 0)
+        if res is not None:
+            got.append({k: v.numpy().copy() for k, v in res.items()})
+    gather.finish()
     t = max_over_ranks(dist, 1.0 + rank)
     if rank == 0:
-        q.put(({k: v.numpy() for k, v in g.items()}, t))
+        q.put((got, t))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -69,8 +80,10 @@ def test_two_rank_shard_and_gather():
         assert p.exitcode == 0
     sys.path.insert(0, ROOT)
     single = _run_envs(list(range(world * E_PER_RANK)))
-    assert np.array_equal(gathered["rewards"], single["rewards"])
-    assert np.array_equal(gathered["terminals"], single["terminals"])
-    assert np.array_equal(gathered["truncations"], single["truncations"])
-    assert np.array_equal(gathered["observations"], single["obs"])
+    assert len(gathered) == STEPS
+    for t in range(STEPS):
+        assert np.array_equal(gathered[t]["rewards"], single[t]["rewards"])
+        assert np.array_equal(gathered[t]["terminals"], single[t]["terminals"])
+        assert np.array_equal(gathered[t]["truncations"], single[t]["truncations"])
+        assert np.array_equal(gathered[t]["observations"], single[t]["obs"])
     assert tmax == 2.0

@@ -219,3 +219,57 @@ def test_map_pool_rejects_maps_beyond_capacity_and_bad_ids():
         eng.set_map_pool(bad)
     with pytest.raises(ValueError):
         BatchedMettaGrid(prog, bad, [1, 2], buffers="host")
+
+
+def test_pettingzoo_surface_and_supervisor_hook():
+    """MettaGridParallelEnv (pettingzoo_env.py call pattern) on one env against the oracle; the supervisor hook of the batched
+    env routes teacher vibe labels into the vibe stream (mettagrid_puffer_env.py:410-426)."""
+    import oracle_py as op
+    from mettagrid_amd.envs import MettaGridParallelEnv
+    spec = presets.rung2_spec()
+    spec.max_steps = 9
+    spec.episode_truncates = True
+    cells = presets.rung2_map(4)
+    prog = compile_spec(spec, *cells.shape)
+    env = MettaGridParallelEnv(prog, cells, seed=5)
+    obs, infos = env.reset(seed=5)
+    assert sorted(obs) == env.possible_agents == list(range(prog.num_agents)) and env.max_steps == 9
+    o = op.OracleSim(prog, prog.class_map(cells), 5)
+    o.reinit_buffers()
+    rng = np.random.default_rng(0)
+    n = env.action_space_n(0)
+    for t in range(9):
+        acts = {a: int(rng.integers(0, n)) for a in env.agents}
+        obs, rew, term, trunc, infos = env.step(acts)
+        arr = np.zeros(prog.num_agents, np.int32)
+        for a, v in acts.items():
+            arr[a] = v
+        o.step(arr, np.zeros(prog.num_agents, np.int32))
+        s = o.snapshot()
+        for a in obs:
+            assert np.array_equal(obs[a], s["obs"][a]) and rew[a] == float(s["rewards"][a]) and trunc[a] == bool(s["truncations"][a])
+    assert env.agents == [] and all(trunc.values())      # every agent truncated at max_steps and dropped from the list
+    with pytest.raises(ValueError):
+        env.reset()
+        env.step({0: n})
+    env.close()
+
+    class Teacher:      # labels: agent i gets primary label i % P on even steps, vibe label P + (i % V) on odd ones
+        def __init__(self, P, V):
+            self.P, self.V, self.t = P, V, 0
+
+        def step_batch(self, raw_obs, teacher_actions):
+            i = np.arange(teacher_actions.shape[0])
+            teacher_actions[:] = (i % self.P) if self.t % 2 == 0 else self.P + (i % self.V)
+            self.t += 1
+    benv = MettaGridBatchedEnv(prog, 2, map_fn=lambda e, ep: prog.class_map(presets.rung2_map(e)), seed=1, buffers="host")
+    benv.reset()
+    P, V = len(benv.action_names), len(benv.vibe_action_names)
+    benv.set_supervisor(Teacher(P, V))
+    benv.step(np.zeros(benv.num_agents, np.int64))
+    assert benv.engine.vibe_actions.tolist() == [0] * benv.num_agents and benv.teacher_actions.max() < P
+    benv.step(np.zeros(benv.num_agents, np.int64))
+    vibe_ids = [prog.action_names.index(nm) for nm in benv.vibe_action_names]
+    assert benv.engine.vibe_actions.tolist() == [vibe_ids[i % V] for i in range(benv.num_agents)]
+    benv.disable_supervisor()
+    benv.close()

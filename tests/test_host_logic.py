@@ -116,3 +116,20 @@ def test_random_class_maps_equal_reference_builder_semantics():
     for s in range(5):
         assert np.array_equal(cms[s], prog.class_map(presets.rung3_map(s)))
     assert int((cms[0] > 0).sum()) == 124 + 40 + 8 + 4 + 16
+
+
+def test_split_supervisor_actions_inplace_known_answers():
+    """python/src/mettagrid/policy/supervisor_actions.py:8-40 restated: primary labels stay, vibe labels move to the vibe
+    stream as engine action ids, anything outside [0, P + V) raises."""
+    from mettagrid_amd.envs import split_supervisor_actions_inplace
+    teacher = np.array([0, 4, 5, 7, 2, 6], np.int32)           # P = 5 primary actions, V = 3 vibes
+    vibe = np.full(6, 99, np.int32)
+    ids = np.array([9, 10, 11])                                # engine ids of change_vibe_<v>
+    split_supervisor_actions_inplace(teacher, vibe, num_primary_actions=5, vibe_action_ids_by_index=ids)
+    assert vibe.tolist() == [0, 0, 9, 11, 0, 10] and teacher.tolist() == [0, 4, 5, 7, 2, 6]
+    with pytest.raises(ValueError, match="invalid action id 8 for agent 1"):
+        split_supervisor_actions_inplace(np.array([1, 8], np.int32), np.zeros(2, np.int32), num_primary_actions=5,
+                                         vibe_action_ids_by_index=ids)
+    with pytest.raises(ValueError):
+        split_supervisor_actions_inplace(np.array([-1], np.int32), np.zeros(1, np.int32), num_primary_actions=5,
+                                         vibe_action_ids_by_index=ids)
