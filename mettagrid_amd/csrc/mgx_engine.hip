@@ -156,6 +156,7 @@ static int fail(int code, const std::string& msg) {
   } while (0)
 
 struct mgx_engine {
+  int num_tags = 0;  // MGX_H_NUM_TAGS
   MgxDev d{};
   MgxDev* d_dev = nullptr;     // copy of `d` in device memory for the kernels that take it by pointer (extended path)
   MgxDev d_dev_host{};         // what d_dev holds
@@ -263,7 +264,8 @@ struct mgx_engine {
 // a larger pool).
 static int size_obs_lds(mgx_engine* e) {
   const MgxDev& d = e->d;
-  e->lds_obs = (size_t)mgx_obs_lds_layout(d.H * d.W, d.NOFF, d.S, d.A, d.T, e->pool_tokens, d.X != 0, d.n_obs_values,
+  const int xmode = mgx_obs_xmode(d.X != 0, d.X && d.aoe_mask_feat != 0 && d.NT > 0, d.S, e->num_tags);
+  e->lds_obs = (size_t)mgx_obs_lds_layout(d.H * d.W, d.NOFF, d.S, d.A, d.T, e->pool_tokens, xmode, d.n_obs_values,
                                           e->obs_blk_lds ? e->obs_blk_words : 0, mgx_obs_gt(d.n_obs_values, d.base),
                                           e->rewards_early).total;
   if (e->lds_obs > 160 * 1024)
@@ -412,6 +414,7 @@ int mgx_create(const int32_t* program, size_t program_words, const uint16_t* cla
   d.n_events = P[MGX_H_NUM_EVENTS]; d.n_schedule = P[MGX_H_NUM_SCHEDULE]; d.n_matq = P[MGX_H_NUM_MATQ];
   d.NT = P[MGX_H_NUM_TERRITORIES]; d.game_on_tick = P[MGX_H_GAME_ON_TICK]; d.NL = P[MGX_H_NUM_INDEXED_TAGS];
   d.aoe_mask_feat = P[MGX_H_FEAT_BASE + MGX_F_AOE_MASK];
+  e->num_tags = P[MGX_H_NUM_TAGS];
   d.QD = std::max(1, (int)P[MGX_H_QUERY_DEPTH]) + 1;
   d.QB = 3 + 2 * (d.QD + 1);
   d.AW = (d.A + 31) / 32;
@@ -611,7 +614,7 @@ int mgx_create(const int32_t* program, size_t program_words, const uint16_t* cla
     for (int i = 0; i < n_code; i++)
       if (!reward_only[i] && code[i * MGX_GV_WORDS + MGX_GV_OP] == MGX_GOP_STAT && code[i * MGX_GV_WORDS + MGX_GV_A0] != 1)
         reads_agent_stats = true;
-    d.defer_book = (reads_agent_stats || d.X) ? 0 : 1;  // (the extended kernel's phases may run as separate launches)
+    d.defer_book = reads_agent_stats ? 0 : 1;  // (flushed at the end of the launch that runs the action phase)
   }
   {  // reward code made only of inventory / constant arithmetic reads nothing the observation kernel writes
     bool pure = !d.X;

@@ -112,9 +112,18 @@ __host__ __device__ inline int mgx_obs_gt(int NOV, int base) {
   for (unsigned long long v = 0xFFFFFFFFull / (unsigned)base; v > 0; v /= (unsigned)base) digits++;
   return 6 + NOV * digits;
 }
+// xmode of the extended variant: what the territory observability mask needs in LDS (0 = lean kernel)
+enum { MGX_OX_ON = 1, MGX_OX_MASK = 2, MGX_OX_PACK = 4, MGX_OX_OWNER8 = 8 };
+__host__ __device__ inline int mgx_obs_xmode(bool X, bool want_mask, int S, int num_tags) {
+  if (!X) return 0;
+  int m = MGX_OX_ON;
+  if (want_mask) m |= MGX_OX_MASK | (S + 1 < (1 << 14) ? MGX_OX_PACK : 0) | (num_tags <= 255 ? MGX_OX_OWNER8 : 0);
+  return m;
+}
 __host__ __device__ inline MgxObsLds mgx_obs_lds_layout(int HW, int NOFF, int S, int A, int T, int pool_tokens,
-                                                        bool X = false, int NOV = 0, int blk_words = 0, int GT = 6,
+                                                        int xmode = 0, int NOV = 0, int blk_words = 0, int GT = 6,
                                                         bool blk_early = false) {
+  const bool X = xmode != 0;
   MgxObsLds l;
   int o = 0;
   l.cp = (NOFF + 15) & ~15;
@@ -143,7 +152,7 @@ __host__ __device__ inline MgxObsLds mgx_obs_lds_layout(int HW, int NOFF, int S,
     l.grid = eo; eo += mgx_align16(HW * 2);
     l.offs = eo; eo += mgx_align16(NOFF * 2);
     l.dyn = eo; eo += mgx_align16(S * 2);
-    if (X) { l.owner = eo; eo += mgx_align16(HW * 2); }
+    if (xmode & MGX_OX_MASK) { l.owner = eo; eo += mgx_align16((xmode & MGX_OX_OWNER8) ? HW : HW * 2); }
     if (blk_early) { l.blk = eo; eo += mgx_align16(blk_words * 4); }
     const int early_bytes = eo - o;
     o += rows_bytes > early_bytes ? rows_bytes : early_bytes;
@@ -153,8 +162,10 @@ __host__ __device__ inline MgxObsLds mgx_obs_lds_layout(int HW, int NOFF, int S,
   l.vcount = o; o += mgx_align16(A * 4);
   l.vmask = l.obsval = l.tscore = l.agtags = 0;
   if (X) {
-    l.vmask = o; o += mgx_align16(A * l.cp);   // per visible cell: 0 no territory token, 1 friendly, 2 foreign owner
-    l.agtags = o; o += mgx_align16(A * MGX_TAG_WORDS * 4);  // the agents' own tag bitsets (friend / foe of a cell's owner tag)
+    // per visible cell: 0 no territory token, 1 friendly, 2 foreign owner — in bits 14-15 of the cell entry when slot
+    // numbers leave them free (MGX_OX_PACK), else a byte list of its own
+    if ((xmode & MGX_OX_MASK) && !(xmode & MGX_OX_PACK)) { l.vmask = o; o += mgx_align16(A * l.cp); }
+    if (xmode & MGX_OX_MASK) { l.agtags = o; o += mgx_align16(A * MGX_TAG_WORDS * 4); }  // the agents' own tag bitsets (friend / foe of a cell's owner tag)
     l.obsval = o; o += mgx_align16((A * NOV + 1) * 4);
   }
   if (!blk_early) { l.blk = o; o += mgx_align16(blk_words * 4); }
@@ -187,7 +198,10 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
   const int wave = __builtin_amdgcn_readfirstlane(tid / MGX_WAVE);  // wave-uniform: per-agent values and branches go scalar
   const int HW = d.H * d.W, A = d.A, S = d.S, T = d.T, NOFF = d.NOFF;
   const int GT = mgx_obs_gt(d.n_obs_values, d.base);
-  const MgxObsLds L = mgx_obs_lds_layout(HW, NOFF, S, A, T, pool_tokens, X, d.n_obs_values, PL ? blk_words : 0, GT,
+  const bool want_mask = X && d.aoe_mask_feat != 0 && d.NT > 0;
+  const int xmode = mgx_obs_xmode(X, want_mask, S, d.P[MGX_H_NUM_TAGS]);
+  const bool pack_mask = (xmode & MGX_OX_PACK) != 0, owner8 = (xmode & MGX_OX_OWNER8) != 0;
+  const MgxObsLds L = mgx_obs_lds_layout(HW, NOFF, S, A, T, pool_tokens, xmode, d.n_obs_values, PL ? blk_words : 0, GT,
                                          rewards_early != 0);
   const int CP = L.cp;
   uint16_t* s_grid = (uint16_t*)(smem + L.grid);
@@ -222,7 +236,7 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
   uint8_t* s_vmask = smem + L.vmask;
   uint32_t* s_agtags = (uint32_t*)(smem + L.agtags);
   uint32_t* s_obsval = (uint32_t*)(smem + L.obsval);
-  const bool want_mask = X && d.aoe_mask_feat != 0 && d.NT > 0;
+  uint8_t* s_owner8 = smem + L.owner;
   // Program view of the interpreted sections: LDS copy (PL) or the blob itself.
   typedef typename std::conditional<PL, MgxLdsProg, MgxGlobalProg>::type VP;
   VP vp;
@@ -481,7 +495,7 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
       for (int cellidx = tid; cellidx < HW; cellidx += MGX_OBS_THREADS) {
         uint16_t owner = 0xFFFF;
         for (int ti = 0; ti < d.NT && owner == 0xFFFF; ti++) owner = d.terr_owner[((size_t)env * d.NT + ti) * (size_t)HW + cellidx];
-        s_owner[cellidx] = owner;
+        if (owner8) s_owner8[cellidx] = (uint8_t)owner; else s_owner[cellidx] = owner;  // (0xFFFF -> 0xFF: tag ids stop at 254 then)
       }
       // the observers' own tag bitsets, once per env instead of one HBM round trip per masked window cell
       for (int i = tid; i < A * MGX_TAG_WORDS; i += MGX_OBS_THREADS) {
@@ -568,17 +582,17 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
         uint32_t mv = 0;  // _emit_tile_observability_tokens (:337-362): 1 = the cell's owner tag is one of mine, 2 = not
         if constexpr (X) {
           if (want_mask && inb) {
-            const uint16_t ow = s_owner[r * d.W + c];
-            if (ow != 0xFFFF) { mv = ((s_agtags[a * MGX_TAG_WORDS + (ow >> 5)] >> (ow & 31)) & 1u) ? 1u : 2u; keep = true; }  // mask-only cells still emit one token
+            const uint32_t ow = owner8 ? (uint32_t)s_owner8[r * d.W + c] : (uint32_t)s_owner[r * d.W + c];
+            if (ow != (owner8 ? 0xFFu : 0xFFFFu)) { mv = ((s_agtags[a * MGX_TAG_WORDS + (ow >> 5)] >> (ow & 31)) & 1u) ? 1u : 2u; keep = true; }  // mask-only cells still emit one token
           }
         }
         if (step > 0 && cs) atomicMin(&s_minobs[cs - 1], (uint32_t)a);
         const unsigned long long m = __ballot(keep);
         if (keep) {
           const int k = count + __popcll(m & ((1ull << lane) - 1ull));
-          s_cell[a * CP + k] = (uint16_t)cs;
+          s_cell[a * CP + k] = (uint16_t)(pack_mask ? cs | (mv << 14) : cs);
           s_vj[a * CP + k] = (uint8_t)j;
-          if constexpr (X) s_vmask[a * CP + k] = (uint8_t)mv;
+          if constexpr (X) { if (want_mask && !pack_mask) s_vmask[a * CP + k] = (uint8_t)mv; }
         }
         count += __popcll(m);
       }
@@ -661,7 +675,9 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
     for (int k0 = 0; k0 < nmax; k0 += 16) {
       const int kk = k0 + rl;
       const bool valid = kk < nvis;
-      const uint32_t cs = valid ? (uint32_t)s_cell[ac * CP + kk] : 0u;
+      uint32_t cs = valid ? (uint32_t)s_cell[ac * CP + kk] : 0u;
+      uint32_t pmask = 0;
+      if constexpr (X) { if (pack_mask) { pmask = cs >> 14; cs &= 0x3FFFu; } }
       const int j = s_vj[ac * CP + (valid ? kk : 0)];
       const bool has = cs != 0;
       const int slot = has ? (int)cs - 1 : 0;
@@ -676,7 +692,7 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
       }
       if constexpr (X) {
         if (want_mask) {  // the territory token comes before the cell's object tokens (:337-362); decided in phase 1
-          mask = valid ? (uint32_t)s_vmask[ac * CP + kk] : 0u;
+          mask = pack_mask ? pmask : valid ? (uint32_t)s_vmask[ac * CP + kk] : 0u;
           if (mask) n += 1;
         }
       }

@@ -1566,30 +1566,45 @@ struct MgxEnvT {  // per-lane view of one env
       const size_t fb = (size_t)envi() * d.NF;
       XL().def_delta[13 * XL().stride + XL().lane] = 0;
       XL().def_delta[14 * XL().stride + XL().lane] = 0;
-      for (int f = 0; f < nf; f++) {  // exits first
-        const uint32_t p = d.fx_pack[fb + f];
-        if (!((p >> 24) & 1u)) continue;
-        uint32_t* w = &d.fx_inside[(fb + f) * d.AW + (ai >> 5)];
-        if (!((*w >> (ai & 31)) & 1u)) continue;
-        if (!pack_covers(p, r, c)) { inside_set(w, ai, false); presence(aoe(d.fx_aoe[fb + f]), tgt, -1); }
+      // Scan first, act second: a light pass over the sources leaves each lane with the bit sets of ITS sources that need
+      // work (a handful out of nf); the costly paths then run once per set bit, every lane on its own source, instead of
+      // once per source for the whole wavefront whenever any lane is in that source's range.
+      for (int f0 = 0; f0 < nf; f0 += 32) {   // every exit of this agent first (registration order)
+        uint32_t exits = 0;
+        for (int q = 0; q < 32 && f0 + q < nf; q++) {
+          const uint32_t p = d.fx_pack[fb + f0 + q];
+          const bool was = (d.fx_inside[(fb + f0 + q) * d.AW + (ai >> 5)] >> (ai & 31)) & 1u;
+          if (((p >> 24) & 1u) && was && !pack_covers(p, r, c)) exits |= 1u << q;
+        }
+        while (exits) {
+          const int f = f0 + __ffs(exits) - 1;
+          exits &= exits - 1;
+          inside_set(&d.fx_inside[(fb + f) * d.AW + (ai >> 5)], ai, false);
+          presence(aoe(d.fx_aoe[fb + f]), tgt, -1);
+        }
       }
-      for (int f = 0; f < nf; f++) {
-        const uint32_t p = d.fx_pack[fb + f];
-        if (!pack_covers(p, r, c)) continue;
-        PP a = aoe(d.fx_aoe[fb + f]);
-        const int src = d.fx_obj[fb + f];
-        const bool skip_self = !a[MGX_AO_EFFECT_SELF] && src == tgt;
-        MgxCtx fc = mgx_ctx(src, tgt);
-        fc.deferred = true;
-        const bool passes = !skip_self && check_filters<0>(a[MGX_AO_FILTER_PC], fc, 0);
-        uint32_t* w = &d.fx_inside[(fb + f) * d.AW + (ai >> 5)];
-        const bool was = (*w >> (ai & 31)) & 1u;
-        if (passes && !was) { inside_set(w, ai, true); presence(a, tgt, +1); }
-        else if (!passes && was) { inside_set(w, ai, false); presence(a, tgt, -1); }
-        if (passes && a[MGX_AO_MUT_COUNT] > 0) {
-          MgxCtx ac = mgx_ctx(src, tgt);
-          ac.deferred = true;
-          apply_all_local(a[MGX_AO_FILTER_PC], a[MGX_AO_MUT_START], a[MGX_AO_MUT_COUNT], ac);
+      for (int f0 = 0; f0 < nf; f0 += 32) {
+        uint32_t covered = 0;
+        for (int q = 0; q < 32 && f0 + q < nf; q++)
+          if (pack_covers(d.fx_pack[fb + f0 + q], r, c)) covered |= 1u << q;
+        while (covered) {
+          const int f = f0 + __ffs(covered) - 1;
+          covered &= covered - 1;
+          PP a = aoe(d.fx_aoe[fb + f]);
+          const int src = d.fx_obj[fb + f];
+          const bool skip_self = !a[MGX_AO_EFFECT_SELF] && src == tgt;
+          MgxCtx fc = mgx_ctx(src, tgt);
+          fc.deferred = true;
+          const bool passes = !skip_self && check_filters<0>(a[MGX_AO_FILTER_PC], fc, 0);
+          uint32_t* w = &d.fx_inside[(fb + f) * d.AW + (ai >> 5)];
+          const bool was = (*w >> (ai & 31)) & 1u;
+          if (passes && !was) { inside_set(w, ai, true); presence(a, tgt, +1); }
+          else if (!passes && was) { inside_set(w, ai, false); presence(a, tgt, -1); }
+          if (passes && a[MGX_AO_MUT_COUNT] > 0) {
+            MgxCtx ac = mgx_ctx(src, tgt);
+            ac.deferred = true;
+            apply_all_local(a[MGX_AO_FILTER_PC], a[MGX_AO_MUT_START], a[MGX_AO_MUT_COUNT], ac);
+          }
         }
       }
       const int cnt = XL().def_delta[14 * XL().stride + XL().lane];
@@ -1627,28 +1642,30 @@ struct MgxEnvT {  // per-lane view of one env
     // `inside` words are independent, and only sources in range (or left since the last tick) take the full path. ----
     const int nm = d.NM ? d.mb_count[envi()] : 0;
     const size_t mb = (size_t)envi() * d.NM;
-    for (int m0 = 0; m0 < nm; m0 += 8) {
-      uint32_t p8[8], w8[8];
-#pragma unroll
-      for (int q = 0; q < 8; q++) {
-        const int m = min(m0 + q, nm - 1);
-        p8[q] = d.mb_pack[mb + m];
-        w8[q] = d.mb_inside[(mb + m) * d.AW + (ai >> 5)];
-      }
-#pragma unroll
-      for (int q = 0; q < 8; q++) {
+    for (int m0 = 0; m0 < nm; m0 += 32) {   // scan 32 sources (independent loads), then visit this agent's own few
+      uint32_t todo = 0, inr = 0;
+#pragma unroll 8
+      for (int q = 0; q < 32; q++) {
         const int m = m0 + q;
-        if (m >= nm) break;
-        const uint32_t p = p8[q];
-        if (!((p >> 24) & 1u)) continue;                       // unregistered source
-        const bool was = (w8[q] >> (ai & 31)) & 1u;
-        const bool in_range = pack_covers(p, r, c);
-        if (!in_range && !was) continue;
+        if (m < nm) {
+          const uint32_t p = d.mb_pack[mb + m];
+          const bool was = (d.mb_inside[(mb + m) * d.AW + (ai >> 5)] >> (ai & 31)) & 1u;
+          const bool in_range = pack_covers(p, r, c);
+          if (((p >> 24) & 1u) && (in_range || was)) todo |= 1u << q;
+          if (in_range) inr |= 1u << q;
+        }
+      }
+      while (todo) {
+        const int q = __ffs(todo) - 1;
+        todo &= todo - 1;
+        const int m = m0 + q;
+        const bool in_range = (inr >> q) & 1u;
         const int src = d.mb_obj[mb + m];
         PP a = aoe(d.mb_aoe[mb + m]);
         if (!a[MGX_AO_EFFECT_SELF] && src == tgt) continue;
         uint32_t* w = &d.mb_inside[(mb + m) * d.AW + (ai >> 5)];
-        if (!in_range) { inside_set(w, ai, false); presence(a, tgt, -1); continue; }
+        const bool was = (*w >> (ai & 31)) & 1u;
+        if (!in_range) { if (was) { inside_set(w, ai, false); presence(a, tgt, -1); } continue; }
         MgxCtx mc = mgx_ctx(src, tgt);
         if (check_filters<0>(a[MGX_AO_FILTER_PC], mc, 0)) {
           if (!was) { inside_set(w, ai, true); presence(a, tgt, +1); }
