@@ -95,6 +95,10 @@ def main() -> None:
     ap.add_argument("--gather", choices=["none", "scalars", "obs"], default="none",
                     help="optional per-step gather of rewards/terminals/truncations (+obs) to rank 0: grouped RCCL "
                          "send/recv over xGMI on a side stream, overlapped with the next step (mettagrid_amd/dist.py)")
+    ap.add_argument("--groups", type=int, default=1,
+                    help="env groups per GPU (mettagrid_amd/groups.py): 2 = the world update of one half of the envs runs "
+                         "beside the observation kernel of the other half (measured slower on MI355X: DESIGN.md); "
+                         "1 = one engine, kernels back to back")
     ap.add_argument("--cpu-steps", type=int, default=0, help="CPU baseline sample (default: about 10 s of one host core)")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
@@ -113,7 +117,7 @@ def main() -> None:
 
     from mettagrid_amd.compiler import compile_spec
     from mettagrid_amd.dist import GatherToRoot, env_shard, shard_seeds
-    from mettagrid_amd.engine import BatchedMettaGrid
+    from mettagrid_amd.groups import EnvGroups
     from mettagrid_amd.mapgen import random_class_maps
 
     spec, H, W, S, objs, agents, mapf, desc, per = workload(args.rung)
@@ -121,8 +125,9 @@ def main() -> None:
     E, A, T = args.envs, prog.num_agents, prog.num_tokens
     cms = random_class_maps(prog, H, W, objs, agents, env_shard(rank, world, E))   # map seed = global env index
     seeds = shard_seeds(rank, world, E)
-    eng = BatchedMettaGrid(prog, cms, seeds, device=local_rank, buffers="device")
+    grp = EnvGroups(prog, cms, seeds, device=local_rank, groups=args.groups)
     del cms
+    G = args.groups
 
     # pre-generated actions resident in HBM (protocol of python/src/mettagrid/perf/harness.py:32-34)
     n_actions = len(prog.action_names)
@@ -130,39 +135,47 @@ def main() -> None:
     gen = torch.Generator(device="cuda").manual_seed(42 + rank)
     pre_a = torch.randint(0, n_actions, (cycle, E * A), dtype=torch.int32, device="cuda", generator=gen)
     pre_v = torch.randint(0, n_actions, (cycle, E * A), dtype=torch.int32, device="cuda", generator=gen)
-    ext = torch.cuda.ExternalStream(eng.stream, device=torch.device("cuda", local_rank))
+    exts = [torch.cuda.ExternalStream(eng.stream, device=torch.device("cuda", local_rank)) for eng in grp.engines]
+    ext = exts[-1]   # the last group finishes a step last
     torch.cuda.synchronize()
 
     gather = None
     if world > 1 and args.gather != "none":
         gather = GatherToRoot(dist, root=0, device=torch.device("cuda", local_rank), producer_stream=ext)
 
-    def one_step(t: int) -> None:
-        with torch.cuda.stream(ext):  # everything is ordered on the engine's stream
-            eng.actions.copy_(pre_a[t % cycle], non_blocking=True)
-            eng.vibe_actions.copy_(pre_v[t % cycle], non_blocking=True)
-            eng.step()
+    def one_step(t: int, only=None) -> None:
+        for g, eng in enumerate(grp.engines):
+            if only is not None and g != only:
+                continue
+            rows = grp.rows(g)
+            with torch.cuda.stream(exts[g]):  # everything of a group is ordered on its engine's stream
+                eng.actions.copy_(pre_a[t % cycle][rows], non_blocking=True)
+                eng.vibe_actions.copy_(pre_v[t % cycle][rows], non_blocking=True)
+                eng.step()
         if gather is not None:   # staging copy + grouped send/recv on the side stream; step t+1 is not held back
-            out = {"rewards": eng.rewards, "terminals": eng.terminals, "truncations": eng.truncations}
+            if G > 1:            # the gather reads all groups' rows: order the last stream behind the others
+                for g in range(G - 1):
+                    ev = torch.cuda.Event()
+                    ev.record(exts[g])
+                    ext.wait_event(ev)
+            out = {"rewards": grp.rewards, "terminals": grp.terminals, "truncations": grp.truncations}
             if args.gather == "obs":
-                out["observations"] = eng.obs
+                out["observations"] = grp.obs
             gather.submit(out)
 
     for t in range(args.warmup):
         one_step(t)
-    eng.sync()
+    grp.sync()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
-    with torch.cuda.stream(ext):
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        ev0.record(ext)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record(exts[0])      # (all streams are idle here; the first group starts a step first ...)
     t0 = time.perf_counter()
     for t in range(args.steps):
         one_step(args.warmup + t)
-    with torch.cuda.stream(ext):
-        ev1.record(ext)
-    eng.sync()
+    ev1.record(ext)          # (... and the last group ends it)
+    grp.sync()
     if gather is not None:
         gather.finish()
     torch.cuda.synchronize()
@@ -173,20 +186,22 @@ def main() -> None:
         tmax = torch.tensor([wall], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         wall = float(tmax.item())
-    bits, first = eng.poll_errors()
+    bits, first = grp.poll_errors()
     if bits:
         raise SystemExit(f"engine reported env error bits {bits} (first env {first})")
 
     # per-kernel durations for the roofline line: HIP events between the two kernels on the engine stream
-    eng.set_profiling(True)
+    # (one group at a time, so that a duration is the kernel's own and not its share of an overlapped pair; a launch
+    # covers E / G envs)
+    grp.set_profiling(True)
     nprof = min(50, max(5, args.steps))
     seg = {}
     for t in range(nprof):
-        one_step(t)
-        for k, v in eng.step_timing_segments_ms().items():
-            seg[k] = seg.get(k, 0.0) + v / nprof
-    eng.set_profiling(False)
-    k_obs = seg["obs"]
+        for g, eng in enumerate(grp.engines):
+            one_step(t, only=g)
+            for k, v in eng.step_timing_segments_ms().items():   # waits for the step
+                seg[k] = seg.get(k, 0.0) + v / (nprof * G)
+    grp.set_profiling(False)
 
     if rank == 0:
         agent_steps = world * E * A * args.steps
@@ -197,7 +212,7 @@ def main() -> None:
         names = {"obs": "mgx_obs_kernel", "actions": "mgx_world_kernel_x" if args.rung == 4 else "mgx_world_kernel_fast"}
         dom = "obs" if seg["obs"] >= seg["actions"] else "actions"
         bytes_per_agent_step = per["obs"] if dom == "obs" else per["world"]
-        achieved = E * A * bytes_per_agent_step / (seg[dom] * 1e-3) / 1e9
+        achieved = (E // G) * A * bytes_per_agent_step / (seg[dom] * 1e-3) / 1e9
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
@@ -212,7 +227,8 @@ def main() -> None:
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": desc, "baseline_config": f"configs[{args.rung - 1}]",
                        "envs_per_gpu": E, "agents_per_env": A, "obs_tokens": T, "gather": args.gather,
-                       "parallelism": f"env-shard x{world}"},
+                       "parallelism": f"env-shard x{world}",
+                       "env_groups_per_gpu": G, "envs_per_launch": E // G},
             "device_ms_per_step": dev_ms / args.steps,
             "kernels_ms": {"world_actions": seg["actions"], "aoe": seg["aoe"], "world_tail": seg["tail"],
                            "mgx_obs_kernel": seg["obs"], "rewards_ext": seg["rewards"]},

@@ -61,6 +61,14 @@ int mgx_sync(mgx_engine* e);
 /* The engine's hipStream_t (as void*) so callers can order their own work / record events on it. */
 void* mgx_stream(mgx_engine* e);
 
+/* Two env groups on one GPU (two engines, each on its own stream): from now on every mgx_step of `e` holds its
+ * world-update kernels back until the world-update kernels of `after`'s most recent mgx_step have finished; its
+ * observation kernel is not held back.  Chained both ways (a after b, b after a) and stepped alternately, the latency-bound
+ * world update of one group always runs beside the issue-bound observation kernel of the other (DESIGN.md "Two env
+ * groups").  after = NULL removes the dependency.  `after` must outlive `e` or be unchained first.  No reference
+ * counterpart: the reference steps one env per process and overlaps processes. */
+int mgx_chain_world(mgx_engine* e, mgx_engine* after);
+
 /* Episode restart for a subset of envs, on the device.  The reference restarts an episode by
  * constructing a new MettaGrid (MettaGridPufferEnv._new_sim, python/src/mettagrid/envs/mettagrid_puffer_env.py:225-228,
  * 299-302); here the selected envs are rebuilt in place by the same construction kernel mgx_create uses, their rows of

@@ -236,6 +236,10 @@ struct mgx_engine {
   size_t stage_bytes = 0;
   bool profiling = false;
   bool timing_valid = false;   // a step has been recorded since profiling was switched on
+  hipEvent_t world_done = nullptr;   // recorded after the world-update kernels of every step (mgx_chain_world)
+  mgx_engine* world_after = nullptr;
+  bool world_chained = false;
+        // some engine waits on world_done // this engine's world kernels wait for that engine's most recent world_done
   hipEvent_t ev[MGX_T_COUNT + 1] = {};  // boundaries of the timing segments of the most recent step (profiling only)
 
   template <class T>
@@ -357,6 +361,9 @@ static int init_buffers(mgx_engine* e) {
 extern "C" {
 
 const char* mgx_last_error(void) { return g_err.c_str(); }
+
+static std::mutex g_live_mu;
+static std::vector<mgx_engine*> g_live;  // engines between mgx_create and mgx_destroy
 
 int mgx_create(const int32_t* program, size_t program_words, const uint16_t* class_maps, const uint32_t* seeds,
                int32_t num_envs, int32_t device, mgx_engine** out) {
@@ -683,14 +690,21 @@ int mgx_create(const int32_t* program, size_t program_words, const uint16_t* cla
   if (he != hipSuccess) { mgx_destroy(e); return fail(MGX_ERR_HIP, std::string("mgx_init_kernel: ") + hipGetErrorString(he)); }
   MGX_TRACE_POINT(e, "init kernel");
   for (int i = 0; i <= MGX_T_COUNT; i++) (void)hipEventCreate(&e->ev[i]);
+  (void)hipEventCreateWithFlags(&e->world_done, hipEventDisableTiming);
   rc = init_buffers(e);  // ctor -> _make_buffers -> set_buffers -> _init_buffers (mettagrid_c.cpp:190, 271-292)
   if (rc != MGX_OK) { mgx_destroy(e); return rc; }
+  { std::lock_guard<std::mutex> g(g_live_mu); g_live.push_back(e); }
   *out = e;
   return MGX_OK;
 }
 
 void mgx_destroy(mgx_engine* e) {
   if (!e) return;
+  {  // engines chained behind this one (mgx_chain_world) lose the dependency
+    std::lock_guard<std::mutex> g(g_live_mu);
+    g_live.erase(std::remove(g_live.begin(), g_live.end(), e), g_live.end());
+    for (mgx_engine* o : g_live) if (o->world_after == e) o->world_after = nullptr;
+  }
   (void)hipSetDevice(e->device);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   for (void* p : e->allocs) (void)hipFree(p);
@@ -698,6 +712,7 @@ void mgx_destroy(mgx_engine* e) {
   if (e->d_stage) (void)hipFree(e->d_stage);
   if (e->h_flags) (void)hipHostFree(e->h_flags);
   for (int i = 0; i <= MGX_T_COUNT; i++) if (e->ev[i]) (void)hipEventDestroy(e->ev[i]);
+  if (e->world_done) (void)hipEventDestroy(e->world_done);
   if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
 }
@@ -1017,6 +1032,7 @@ int mgx_step(mgx_engine* e) {
   MGX_MARK(0);
   {
     const int pw = e->prog_lds_words;
+    if (e->world_after) HIP_TRY(hipStreamWaitEvent(e->stream, e->world_after->world_done, 0));
     MGX_TRACE_POINT(e, "before world");
     if (!d.X) {
       if (e->slot == 0) mgx_launch_world_fast_s0(e->prog_in_lds, e->lds_world, e->stream, e->d, pw);
@@ -1038,6 +1054,7 @@ int mgx_step(mgx_engine* e) {
       MGX_MARK(1); MGX_MARK(2); MGX_MARK(3);
     }
     MGX_TRACE_POINT(e, "world kernel");
+    if (e->world_chained) HIP_TRY(hipEventRecord(e->world_done, e->stream));
   }
   HIP_TRY(hipGetLastError());
   int rc = launch_obs(e, true);   // (+ ownership map refresh and query-backed obs values in front of it)
@@ -1078,6 +1095,14 @@ int mgx_sync(mgx_engine* e) {
 }
 
 void* mgx_stream(mgx_engine* e) { return e ? (void*)e->stream : nullptr; }
+
+int mgx_chain_world(mgx_engine* e, mgx_engine* after) {
+  if (!e || e == after) return fail(MGX_ERR_BAD_ARG, "mgx_chain_world: needs two different engines");
+  if (after && after->device != e->device) return fail(MGX_ERR_BAD_ARG, "mgx_chain_world: engines live on different devices");
+  e->world_after = after;
+  if (after) after->world_chained = true;
+  return MGX_OK;
+}
 
 int mgx_get_buffers(mgx_engine* e, uint8_t** observations, uint8_t** terminals, uint8_t** truncations,
                     float** rewards, int32_t** actions, int32_t** vibe_actions, int32_t* mem_kind) {

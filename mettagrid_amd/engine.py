@@ -58,6 +58,7 @@ def load_lib():
     L.mgx_sync.argtypes = [vp]
     L.mgx_stream.argtypes = [vp]
     L.mgx_stream.restype = vp
+    L.mgx_chain_world.argtypes = [vp, vp]
     L.mgx_get_buffers.argtypes = [vp] + [C.POINTER(vp)] * 6 + [C.POINTER(i32)]
     L.mgx_get_episode_rewards.argtypes = [vp, vp]
     L.mgx_get_action_success.argtypes = [vp, vp]
@@ -128,7 +129,18 @@ class BatchedMettaGrid:
                                  C.byref(self.h)))
         self.kind = buffers
         rows = self.E * self.A
-        if buffers == "device":
+        if isinstance(buffers, dict):   # the caller's own device tensors (e.g. slices of one batch: EnvGroups)
+            self.kind = "device"
+            want = {"obs": ((rows, self.T, 3), "uint8"), "terminals": ((rows,), "bool"), "truncations": ((rows,), "bool"),
+                    "rewards": ((rows,), "float32"), "actions": ((rows,), "int32"), "vibe_actions": ((rows,), "int32")}
+            for name, (shape, dt) in want.items():
+                t = buffers[name]
+                if tuple(t.shape) != shape or str(t.dtype) != "torch." + dt or not t.is_contiguous() or t.device.index != device:
+                    raise ValueError(f"buffer {name!r} must be a contiguous {dt}{list(shape)} tensor on cuda:{device}")
+                setattr(self, name, t)
+            self._bind(*(t.data_ptr() for t in (self.obs, self.terminals, self.truncations, self.rewards,
+                                                self.actions, self.vibe_actions)), mem_kind=1)
+        elif buffers == "device":
             import torch
             dev = torch.device("cuda", device)
             self.obs = torch.empty((rows, self.T, 3), dtype=torch.uint8, device=dev)
@@ -176,6 +188,11 @@ class BatchedMettaGrid:
 
     def sync(self) -> None:
         _check(self.L.mgx_sync(self.h))
+
+    def chain_world_after(self, other: "BatchedMettaGrid | None") -> None:
+        """From now on this engine's world-update kernels start only when ``other``'s most recent ones have finished
+        (include/mgx.h mgx_chain_world): the building block of ``EnvGroups``."""
+        _check(self.L.mgx_chain_world(self.h, other.h if other is not None else None))
 
     def reset_envs(self, env_mask, class_maps=None, seeds=None) -> None:
         """Restart the selected envs in place on the device (new episode): optional new maps / seeds for them.
