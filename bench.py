@@ -57,24 +57,7 @@ def cpu_baseline(spec, prog, steps: int, cells) -> dict:
     n, A = len(prog.action_names), prog.num_agents
     acts = rng.randint(0, n, (steps, A)).astype(np.int32)
     vibes = rng.randint(0, n, (steps, A)).astype(np.int32)
-    try:
-        import ref_driver
-        if not ref_driver.ref_available():
-            raise RuntimeError("no _ref")
-        sim = ref_driver.RefSim(spec, cells, 42, prog)
-        kind = "reference"
-
-        def step(t):
-            sim.A[:] = acts[t]
-            sim.VA[:] = vibes[t]
-            sim.c.step()
-    except Exception:
-        import oracle_py
-        sim = oracle_py.OracleSim(prog, prog.class_map(cells), 42)
-        kind = "port"
-
-        def step(t):
-            sim.step(acts[t], vibes[t])
+    kind, step = _cpu_sim(spec, prog, cells, 42, acts, vibes)
     for t in range(min(500, steps)):
         step(t)
     t0 = time.perf_counter()
@@ -85,7 +68,100 @@ def cpu_baseline(spec, prog, steps: int, cells) -> dict:
             "sample": f"1 env (map seed 0) of the same workload, {steps} steps, random actions, 1 host core"}
 
 
+def cpu_worker(rung: int, steps: int, seed: int, start_at: float) -> None:
+    """One process of the whole-host baseline: its own env (map seed = worker index), starts stepping at ``start_at``."""
+    from mettagrid_amd.compiler import compile_spec
+    spec, H, W, S, objs, agents, mapf, desc, per = workload(rung)
+    prog = compile_spec(spec, H, W, max_objects=S)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    rng = np.random.RandomState(seed)
+    n, A = len(prog.action_names), prog.num_agents
+    acts = rng.randint(0, n, (steps, A)).astype(np.int32)
+    vibes = rng.randint(0, n, (steps, A)).astype(np.int32)
+    kind, step = _cpu_sim(spec, prog, mapf(seed), seed, acts, vibes)
+    for t in range(min(200, steps)):
+        step(t)
+    while time.time() < start_at:
+        time.sleep(0.005)
+    t0 = time.time()
+    for t in range(steps):
+        step(t)
+    print(json.dumps({"kind": kind, "agent_steps": steps * A, "t0": t0, "t1": time.time()}), flush=True)
+
+
+def host_cores() -> int:
+    """Cores this process may really use: the affinity mask cut down to the cgroup CPU quota, and to 16 — the CPU share
+    of one GPU on the bench boxes — unless MGX_BENCH_CORES says otherwise."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except (OSError, ValueError):
+            pass
+    return int(os.environ.get("MGX_BENCH_CORES", min(n, 16)))
+
+
+def cpu_baseline_host(rung: int, steps: int) -> dict:
+    """The same CPU engine on every host core at once: one process per core, one env each, started together.  Child
+    processes are started before this process touches the GPU."""
+    import subprocess
+    cores = host_cores()
+    start_at = time.time() + (20.0 if rung == 4 else 12.0)   # imports + map + program compile of every worker
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(rung), str(steps), str(i),
+                               repr(start_at)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+             for i in range(cores)]
+    outs = []
+    deadline = time.time() + 150
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=max(1.0, deadline - time.time()))
+        except subprocess.TimeoutExpired:
+            p.kill()
+            p.communicate()
+            continue
+        if p.returncode == 0 and o.strip():
+            outs.append(json.loads(o.strip().splitlines()[-1]))
+    if not outs:
+        return {"value": None, "cores": cores, "error": "no worker finished"}
+    late = sum(1 for o in outs if o["t0"] > start_at + 0.5)
+    span = max(o["t1"] for o in outs) - min(o["t0"] for o in outs)
+    return {"value": sum(o["agent_steps"] for o in outs) / span, "cores": len(outs), "kind": outs[0]["kind"],
+            "late_starters": late}
+
+
+def _cpu_sim(spec, prog, cells, seed, acts, vibes):
+    """(kind, step(t)) of the reference C++ engine (oracle/_ref) or, where that build is absent, the CPU restatement."""
+    try:
+        import ref_driver
+        if not ref_driver.ref_available():
+            raise RuntimeError("no _ref")
+        sim = ref_driver.RefSim(spec, cells, seed, prog)
+
+        def step(t):
+            sim.A[:] = acts[t]
+            sim.VA[:] = vibes[t]
+            sim.c.step()
+        return "reference", step
+    except Exception:
+        import oracle_py
+        sim = oracle_py.OracleSim(prog, prog.class_map(cells), seed)
+
+        def step(t):
+            sim.step(acts[t], vibes[t])
+        return "port", step
+
+
 def main() -> None:
+    if len(sys.argv) > 1 and sys.argv[1] == "--cpu-worker":
+        cpu_worker(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), float(sys.argv[5]))
+        return
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -107,6 +183,23 @@ def main() -> None:
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    cpu = None
+    if not args.no_cpu and world == 1:
+        # CPU baseline first: its worker processes are started before this process initialises the GPU.  One core:
+        # about 10 s; then every host core at once, one env per process, about 5 s of stepping each.
+        from mettagrid_amd.compiler import compile_spec as _cs
+        spec_c, H_c, W_c, S_c, _, _, mapf_c, _, _ = workload(args.rung)
+        prog_c = _cs(spec_c, H_c, W_c, max_objects=S_c)
+        cpu_steps = args.cpu_steps or (300000 if args.rung == 3 else 25000)
+        one = cpu_baseline(spec_c, prog_c, cpu_steps, mapf_c(0))
+        host = cpu_baseline_host(args.rung, max(1000, cpu_steps // 2))
+        if host.get("value"):
+            cpu = {"value": host["value"], "unit": "agent-steps/s", "cores": host["cores"], "kind": host["kind"],
+                   "sample": f"{host['cores']} processes (one per host core), 1 env each (map seed = process index) of the "
+                             f"same workload, {max(1000, cpu_steps // 2)} steps each, random actions, started together",
+                   "one_core": one}
+        else:
+            cpu = one
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the step engine has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -237,9 +330,8 @@ def main() -> None:
                          "bytes_per_agent_step": bytes_per_agent_step,
                          "tick_bytes_per_agent_step": per["tick"]},
         }
-        if not args.no_cpu and world == 1:
-            cpu_steps = args.cpu_steps or (300000 if args.rung == 3 else 25000)
-            out["cpu_baseline"] = cpu_baseline(spec, prog, cpu_steps, mapf(0))
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

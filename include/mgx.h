@@ -118,6 +118,11 @@ int mgx_get_stats(mgx_engine* e, int32_t env, float* game_values, uint8_t* game_
  * [34..41] tag bitset (8 x u32).
  * Returns the number of records written via *n_objects; `out` must hold MAX_OBJECTS records. */
 #define MGX_OBJ_RECORD_WORDS 42
+/* "action.invalid_index.<k>" for action indices outside the fixed stat columns (k < -16 or k >= n_actions + 16): the
+ * reference creates one stat key per distinct k (mettagrid_c.cpp:914-919); the engine keeps MGX_INVALID_EXTRA (k, count)
+ * pairs per agent and episode (a fifth distinct k raises env error bit 2).  k_out / n_out: [A][MGX_INVALID_EXTRA] host
+ * memory; pairs with n == 0 are unused. */
+int mgx_get_invalid_index_extra(mgx_engine* e, int32_t env, int32_t* k_out, float* n_out);
 int mgx_get_objects(mgx_engine* e, int32_t env, int32_t* out, int32_t* n_objects);
 /* current_stat_reward per agent of env `env` (RewardHelper::current_reward, systems/reward.hpp:36-42). f32 [A]. */
 int mgx_get_reward_state(mgx_engine* e, int32_t env, float* out);

@@ -23,7 +23,8 @@
 #define MGX_MAX_RESOURCES 13 /* inventory order list = 4-bit ids in one u64, 0xF terminator; see DESIGN.md */
 #define MGX_TAG_WORDS 8      /* 256 tags = 8 x u32 (reference kMaxTags, core/types.hpp:62) */
 #define MGX_MAX_AGENTS 256
-#define MGX_INVALID_WINDOW 16 /* action.invalid_index.<k> tracked for k in [-16,-1] and [n_actions, n_actions+15] */
+#define MGX_INVALID_WINDOW 16 /* action.invalid_index.<k> is a fixed stat column for k in [-16,-1] and [n_actions, n_actions+15] */
+#define MGX_INVALID_EXTRA 4   /* ... and one of this many (k, count) pairs per agent and episode for any other k */
 
 /* ---- header word indices ------------------------------------------------------------------------------------- */
 enum {

@@ -53,6 +53,8 @@ struct MgxDev {
   uint16_t* ag_spawn;     // [E][A]
   uint16_t* ag_stepprev;  // [E][A] MettaGrid::_prev_agent_locations
   uint16_t* ag_covrc;     // [E][A] position at the last coverage update (0xFFFF = never)
+  int32_t* ag_invk;       // [E][A][MGX_INVALID_EXTRA] out-of-window invalid action indices seen this episode ...
+  float* ag_invn;         // ... and how often (0 = free pair)
   uint32_t* ag_swm;       // [E][A] steps_without_motion
   uint32_t* ag_maxdist;   // [E][A]
   uint32_t* ag_unique;    // [E][A]

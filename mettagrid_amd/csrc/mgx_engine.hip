@@ -483,6 +483,8 @@ int mgx_create(const int32_t* program, size_t program_words, const uint16_t* cla
   A_(e->alloc_env(&d.ag_spawn, A));
   A_(e->alloc_env(&d.ag_stepprev, A));
   A_(e->alloc_env(&d.ag_covrc, A, 0xFF));
+  A_(e->alloc_env(&d.ag_invk, A * MGX_INVALID_EXTRA));
+  A_(e->alloc_env(&d.ag_invn, A * MGX_INVALID_EXTRA));
   A_(e->alloc_env(&d.ag_swm, A));
   A_(e->alloc_env(&d.ag_maxdist, A));
   A_(e->alloc_env(&d.ag_unique, A));
@@ -1160,6 +1162,15 @@ int mgx_get_stats(mgx_engine* e, int32_t env, float* game_values, uint8_t* game_
     for (int i = 0; i < d.NS; i++) agent_touched[(size_t)a * d.NS + i] =
           ((at[(size_t)a * d.NSW + (i >> 5)] >> (i & 31)) & 1u) | (agent_values[(size_t)a * d.NS + i] != 0.f);
   return MGX_OK;
+}
+
+int mgx_get_invalid_index_extra(mgx_engine* e, int32_t env, int32_t* k_out, float* n_out) {
+  if (!e || !k_out || !n_out || env < 0 || env >= e->d.E) return fail(MGX_ERR_BAD_ARG, "mgx_get_invalid_index_extra: bad argument");
+  const MgxDev& d = e->d;
+  const size_t n = (size_t)d.A * MGX_INVALID_EXTRA;
+  int rc = d2h(e, k_out, d.ag_invk + (size_t)env * n, n * 4);
+  if (rc) return rc;
+  return d2h(e, n_out, d.ag_invn + (size_t)env * n, n * 4);
 }
 
 int mgx_get_objects(mgx_engine* e, int32_t env, int32_t* out, int32_t* n_objects) {

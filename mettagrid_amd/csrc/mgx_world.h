@@ -1840,6 +1840,16 @@ struct MgxEnvT {  // per-lane view of one env
     return ok;
   }
 
+  // "action.invalid_index.<k>" for a k without a stat column: one of the agent's (k, count) pairs (include/mgx.h)
+  __device__ void invalid_extra(int ai, int a) const {
+    int32_t* k = d.ag_invk + ao(ai) * MGX_INVALID_EXTRA;
+    float* n = d.ag_invn + ao(ai) * MGX_INVALID_EXTRA;
+    for (int q = 0; q < MGX_INVALID_EXTRA; q++) {
+      if (n[q] == 0.f) { k[q] = a; n[q] = 1.f; return; }
+      if (k[q] == a) { n[q] += 1.f; return; }
+    }
+    flag(2u);
+  }
   __device__ MGX_BIG void track_coverage(int ai) const {  // objects/agent.cpp:49-57
     uint16_t rc = AL().rc ? AL().rc[ai * MGX_WORLD_EPG + AL().lane] : d.obj_rc[so(d.ag_obj[ao(ai)])];
     // Unchanged position since the last call => the set is unchanged and both stats.set() calls would store the
@@ -2178,11 +2188,12 @@ __device__ __forceinline__ void mgx_world_body(const MgxDev& d, PP P, uint8_t* o
       int ai = order[k * MGX_WORLD_EPG + lane];
       int a = al.act[(stream * A + ai) * MGX_WORLD_EPG + lane];
       if (a < 0 || a >= d.nact) {  // _handle_invalid_action :914-919
+        a = (stream == 0 ? d.actions : d.vibe_actions)[e.ao(ai)];  // the raw index (the staged copy is saturated to int16)
         for (int rep = 0; rep < repeats; rep++) {
           e.astat_add(ai, d.wk[MGX_S_INVALID_INDEX], 1.f);
           if (a < 0 && a >= -MGX_INVALID_WINDOW) e.astat_add(ai, d.wk[MGX_S_INVALID_NEG_BASE] + a + MGX_INVALID_WINDOW, 1.f);
           else if (a >= d.nact && a < d.nact + MGX_INVALID_WINDOW) e.astat_add(ai, d.wk[MGX_S_INVALID_POS_BASE] + a - d.nact, 1.f);
-          else e.flag(2u);
+          else e.invalid_extra(ai, a);
         }
         d.success[e.ao(ai)] = 0;
         al.act[(stream * A + ai) * MGX_WORLD_EPG + lane] = 0;  // no handle_action call: empty result byte
@@ -2353,6 +2364,7 @@ __global__ void __launch_bounds__(MGX_WAVE) mgx_init_kernel(const MgxDev* __rest
       d.ag_spawn[e.ao(ai)] = rc;
       d.ag_stepprev[e.ao(ai)] = rc;
       d.ag_covrc[e.ao(ai)] = 0xFFFF;
+      for (int q = 0; q < MGX_INVALID_EXTRA; q++) d.ag_invn[e.ao(ai) * MGX_INVALID_EXTRA + q] = 0.f;
     }
     d.obj_agent[e.so(slot)] = ai < 0 ? MGX_NO_AGENT : (uint8_t)ai;
     const int32_t* ii = d.P + d.sec[MGX_SEC_INIT_INV] + C[MGX_C_INIT_INV_START] * MGX_II_WORDS;

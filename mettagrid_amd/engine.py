@@ -65,6 +65,7 @@ def load_lib():
     L.mgx_get_current_steps.argtypes = [vp, vp]
     L.mgx_get_stats.argtypes = [vp, i32, vp, vp, vp, vp]
     L.mgx_get_objects.argtypes = [vp, i32, vp, C.POINTER(i32)]
+    L.mgx_get_invalid_index_extra.argtypes = [vp, i32, vp, vp]
     L.mgx_get_reward_state.argtypes = [vp, i32, vp]
     L.mgx_poll_errors.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(i32)]
     L.mgx_set_inventory.argtypes = [vp, i32, i32, vp, vp, i32]
@@ -285,7 +286,8 @@ class BatchedMettaGrid:
         if bits & ENV_DEPTH:
             raise MgxError(f"env {first}: handler / inventory-limit recursion exceeds the engine's depth")
         if bits & ENV_INVALID_KEY_RANGE:
-            raise MgxError(f"env {first}: action index outside the tracked action.invalid_index window")
+            raise MgxError(f"env {first}: an agent sent more than {K.INVALID_EXTRA} distinct invalid action indices far outside "
+                           "the action table in one episode (action.invalid_index.<k> keys exhausted)")
         if bits & ENV_TOKEN_POOL:
             raise MgxError(f"env {first}: the observation kernel's per-env token cache is exhausted "
                            "(objects' token lists would be dropped from observations)")
@@ -315,8 +317,15 @@ class BatchedMettaGrid:
         _check(self.L.mgx_get_stats(self.h, env, gv.ctypes.data, gt.ctypes.data, av.ctypes.data, at.ctypes.data))
         return gv, gt, av, at
 
+    def invalid_index_extra(self, env: int = 0) -> list:
+        """Per agent {k: count} of "action.invalid_index.<k>" for the k that have no fixed stat column (mgx.h)."""
+        k = np.zeros((self.A, K.INVALID_EXTRA), np.int32)
+        n = np.zeros((self.A, K.INVALID_EXTRA), np.float32)
+        _check(self.L.mgx_get_invalid_index_extra(self.h, env, k.ctypes.data, n.ctypes.data))
+        return [{int(k[a, q]): float(n[a, q]) for q in range(K.INVALID_EXTRA) if n[a, q] != 0} for a in range(self.A)]
+
     def get_episode_stats(self, env: int = 0) -> dict:
-        return stats_dicts(self.prog, *self.raw_stats(env))
+        return stats_dicts(self.prog, *self.raw_stats(env), extra=self.invalid_index_extra(env))
 
     def raw_objects(self, env: int = 0) -> np.ndarray:
         out = np.zeros((self.prog.max_objects, OBJ_RECORD_WORDS), np.int32)

@@ -20,12 +20,15 @@ def _round(v) -> float:
     return round(float(v), 8)
 
 
-def stats_dicts(prog, gv, gt, av, at) -> dict:
+def stats_dicts(prog, gv, gt, av, at, extra=None) -> dict:
     """Raw stat arrays + touched flags -> {"game": {name: value}, "agent": [{...}]} (keys exist once touched:
     cpp/include/mettagrid/systems/stats_tracker.hpp:57-67,109-115)."""
     game = {prog.game_stat_names[i]: float(gv[i]) for i in range(len(gv)) if gt[i]}
     agents = [{prog.agent_stat_names[i]: float(av[a, i]) for i in range(av.shape[1]) if at[a, i]}
               for a in range(av.shape[0])]
+    for a, more in enumerate(extra or []):   # invalid action indices without a stat column: {k: count} per agent
+        for k, n in more.items():
+            agents[a][f"action.invalid_index.{k}"] = float(n)
     return {"game": game, "agent": agents}
 
 

@@ -113,6 +113,8 @@ struct Agent {
   std::vector<uint8_t> seen;  // unique_cells_visited
   std::vector<float> reward_prev;
   Stats stats;
+  int inv_k[MGX_INVALID_EXTRA] = {};      // "action.invalid_index.<k>" for k without a stat column (include/mgx.h)
+  float inv_n[MGX_INVALID_EXTRA] = {};
 };
 
 struct Deferred {  // AOETracker::apply_fixed accumulators (core/aoe_tracker.cpp:283-289)
@@ -1181,7 +1183,15 @@ struct Engine {
             st.add(wk(MGX_S_INVALID_INDEX), 1.f);
             if (a < 0 && a >= -MGX_INVALID_WINDOW) st.add(wk(MGX_S_INVALID_NEG_BASE) + a + MGX_INVALID_WINDOW, 1.f);
             else if (a >= nact && a < nact + MGX_INVALID_WINDOW) st.add(wk(MGX_S_INVALID_POS_BASE) + a - nact, 1.f);
-            else error |= 2;  // key outside the tracked window
+            else {  // a key of its own per distinct k (mettagrid_c.cpp:916-918); MGX_INVALID_EXTRA of them per agent
+              Agent& ag = agents[ai];
+              int q = 0;
+              for (; q < MGX_INVALID_EXTRA; q++) {
+                if (ag.inv_n[q] == 0.f) { ag.inv_k[q] = a; ag.inv_n[q] = 1.f; break; }
+                if (ag.inv_k[q] == a) { ag.inv_n[q] += 1.f; break; }
+              }
+              if (q == MGX_INVALID_EXTRA) error |= 2;
+            }
             action_success[ai] = 0;
             continue;
           }
@@ -1272,6 +1282,14 @@ void mgxo_stats(void* h, float* game_v, uint8_t* game_t, float* agent_v, uint8_t
     std::memcpy(agent_v + (size_t)i * na, e->agents[i].stats.v.data(), na * 4);
     std::memcpy(agent_t + (size_t)i * na, e->agents[i].stats.touched.data(), na);
   }
+}
+void mgxo_invalid_index_extra(void* h, int32_t* k_out, float* n_out) {
+  Engine* e = (Engine*)h;
+  for (int i = 0; i < e->A; i++)
+    for (int q = 0; q < MGX_INVALID_EXTRA; q++) {
+      k_out[i * MGX_INVALID_EXTRA + q] = e->agents[i].inv_k[q];
+      n_out[i * MGX_INVALID_EXTRA + q] = e->agents[i].inv_n[q];
+    }
 }
 void mgxo_reward_state(void* h, float* current_stat_reward) {  // systems/reward.hpp:36-42 current_reward()
   Engine* e = (Engine*)h;

@@ -46,6 +46,7 @@ def lib():
         L.mgxo_num_objects.argtypes = [C.c_void_p]
         L.mgxo_objects.argtypes = [C.c_void_p, C.c_void_p]
         L.mgxo_stats.argtypes = [C.c_void_p] + [C.c_void_p] * 4
+        L.mgxo_invalid_index_extra.argtypes = [C.c_void_p] * 3
         L.mgxo_reward_state.argtypes = [C.c_void_p, C.c_void_p]
         L.mgxo_selftest_shuffle.argtypes = [C.c_uint32, C.c_int, C.c_int]
         L.mgxo_set_inventory.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
@@ -122,6 +123,12 @@ class OracleSim:
         av, at = np.zeros((self.A, na), np.float32), np.zeros((self.A, na), np.uint8)
         self.L.mgxo_stats(self.h, gv.ctypes.data, gt.ctypes.data, av.ctypes.data, at.ctypes.data)
         return gv, gt, av, at
+
+    def invalid_index_extra(self) -> list:
+        from mettagrid_amd.fmt import K
+        k, n = np.zeros((self.A, K.INVALID_EXTRA), np.int32), np.zeros((self.A, K.INVALID_EXTRA), np.float32)
+        self.L.mgxo_invalid_index_extra(self.h, k.ctypes.data, n.ctypes.data)
+        return [{int(k[a, q]): float(n[a, q]) for q in range(K.INVALID_EXTRA) if n[a, q] != 0} for a in range(self.A)]
 
     def current_stat_reward(self) -> np.ndarray:
         out = np.zeros(self.A, np.float32)

@@ -369,3 +369,56 @@ def letterbox_map(seed: int) -> np.ndarray:
 
 
 SCENARIOS["letterbox"] = (letterbox_spec, letterbox_map, 40, False)
+
+
+def minmax_spec() -> S.GameSpec:
+    """The torture rules with MinValue everywhere a game value can stand (config/game_value_config.hpp MinValueConfig):
+    a per-tick reward, nested under MaxValue and RatioValue, as the threshold of a GameValueFilter and as an obs value."""
+    import dataclasses
+    base = torture_spec(40, True)
+    lo = S.MinValue([S.InventoryValue("hp"), S.InventoryValue("energy"), S.ConstValue(30.0)])
+    nested = S.MaxValue([S.MinValue([S.InventoryValue("gear"), S.InventoryValue("laser")]), S.ConstValue(0.5)])
+    agents = []
+    for a in base.agents:
+        rewards = [S.RewardSpec(lo, per_tick=True),
+                   S.RewardSpec(S.RatioValue(S.InventoryValue("ore"), nested)),
+                   S.RewardSpec(S.MinValue([S.StatValue("forged", "agent"), S.ConstValue(2.0)]))]
+        agents.append(dataclasses.replace(a, rewards=rewards))
+    A = S.ACTOR
+    gate = S.Handler([S.GameValueFilter(A, S.InventoryValue("hp"), S.MinValue([S.InventoryValue("energy"), S.ConstValue(25.0)]))],
+                     [S.ResourceDelta(A, "energy", 2)], "gate")
+    objects = dict(base.objects)
+    objects["shrine"] = dataclasses.replace(objects["shrine"], on_use=gate)
+    obs = dataclasses.replace(base.obs, values={"floor": lo, "pair": S.MinValue([S.InventoryValue("gear"), S.InventoryValue("laser")])})
+    return dataclasses.replace(base, agents=agents, objects=objects, obs=obs)
+
+
+SCENARIOS["minmax"] = (minmax_spec, torture_map, 45, False)
+
+
+def thirteen_spec() -> S.GameSpec:
+    """The torture rules at the engine's resource limit (13 = the bucket count of libstdc++'s smallest unordered_map
+    table): every agent starts with all five extra resources in a scrambled insertion order, the mine
+    drains some to zero (erase) and hands others back (re-insert at the list head), so inventory token order walks
+    through erase / insert at the highest ids.  R = 14 is refused (test_host_logic.py)."""
+    import dataclasses
+    base = torture_spec(40, True)
+    extra = ["x8", "x9", "x10", "x11", "x12"]
+    A, T = S.ACTOR, S.TARGET
+    agents = []
+    for i, a in enumerate(base.agents):
+        init = dict(a.inventory.initial)
+        for j in range(5):   # scrambled, agent-dependent insertion order
+            name = extra[(j * 2 + i) % 5]
+            init[name] = 1 + (i + j) % 3
+        agents.append(dataclasses.replace(a, inventory=dataclasses.replace(a.inventory, initial=init)))
+    mine_use = S.Handler([], [S.ResourceTransfer(A, T, "x12", -1), S.ResourceTransfer(A, T, "x9", 1),
+                              S.ResourceTransfer(T, A, "x8", 2), S.ResourceTransfer(T, A, "ore", 4),
+                              S.ResourceDelta(A, "x10", -1), S.ResourceDelta(A, "x11", 1)], "mine13")
+    objects = dict(base.objects)
+    objects["mine"] = dataclasses.replace(objects["mine"], on_use=mine_use,
+                                          inventory=S.Inventory(initial={"ore": 500, "x8": 40, "x12": 0}, default_limit=1000))
+    return dataclasses.replace(base, resource_names=list(base.resource_names) + extra, agents=agents, objects=objects)
+
+
+SCENARIOS["thirteen"] = (thirteen_spec, torture_map, 45, False)

@@ -58,7 +58,8 @@ class Sim:
     def stats(self):
         from mettagrid_amd.signature import stats_dicts
         raw = self.o.raw_stats() if self.backend == "oracle" else self.e.raw_stats(0)
-        return stats_dicts(self.prog, *raw)
+        extra = self.o.invalid_index_extra() if self.backend == "oracle" else self.e.invalid_index_extra(0)
+        return stats_dicts(self.prog, *raw, extra=extra)
 
     def agent_pos(self, i=0):
         for o in self.objects().values():
@@ -277,3 +278,31 @@ def test_invalid_action_index_counts_once_per_priority_level(backend):
     st = sim.stats()["agent"][0]
     assert st["action.invalid_index"] == 2.0 and st[f"action.invalid_index.{n + 3}"] == 2.0
     assert not sim.snap()["action_success"][0]
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_invalid_action_index_far_outside_the_action_table(backend):
+    """mettagrid_c.cpp:916-918 creates one "action.invalid_index.<k>" key per distinct k, whatever k is.  Indices next
+    to the action table have fixed stat columns; any other k takes one of the agent's MGX_INVALID_EXTRA (k, count)
+    pairs, and only a fifth distinct far k in one episode is refused (env error bit 2)."""
+    sim = Sim(backend, basic_spec(), ROOM)
+    n = len(sim.prog.action_names)
+
+    def step(a, v=0):
+        if backend == "oracle":
+            sim.o.step(np.array([a], np.int32), np.array([v], np.int32))
+        else:
+            sim.e.actions[:] = a
+            sim.e.vibe_actions[:] = v
+            sim.e.step()
+
+    for a in (1000, -500, 1000, n + 40):
+        step(a)
+    step(0, 2 ** 31 - 1)      # the vibe stream is checked the same way
+    st = sim.stats()["agent"][0]
+    assert st["action.invalid_index"] == 10.0
+    assert st["action.invalid_index.1000"] == 4.0 and st["action.invalid_index.-500"] == 2.0
+    assert st[f"action.invalid_index.{n + 40}"] == 2.0 and st[f"action.invalid_index.{2 ** 31 - 1}"] == 2.0
+    assert sim.error() == 0
+    step(-(2 ** 31))          # fifth distinct far index
+    assert sim.error() & 2

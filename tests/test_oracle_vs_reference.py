@@ -55,3 +55,25 @@ def test_reference_inventory_token_order_follows_emulated_unordered_map():
         ref = rd.RefSim(spec, cells, 1, prog)
         ora = op.OracleSim(prog, prog.class_map(cells), 1)
         assert np.array_equal(ref.snapshot()["obs"], ora.snapshot()["obs"]), initial
+
+
+def test_far_invalid_action_indices_match_reference_stat_keys():
+    """The reference keys "action.invalid_index.<k>" by the raw index (mettagrid_c.cpp:916-918); the oracle's (k, count)
+    pairs must produce the same stats dict."""
+    spec_f, map_f, _, _ = hp.SCENARIOS["rung1"]
+    spec, cells = spec_f(), map_f(0)
+    prog = hp.compile_scenario("rung1", spec, *cells.shape)
+    ref = rd.RefSim(spec, cells, 3, prog)
+    ora = op.OracleSim(prog, prog.class_map(cells), 3)
+    n, A = len(prog.action_names), prog.num_agents
+    for a, v in ((1000, 0), (-500, 0), (1000, 2 ** 31 - 1), (n + 40, -5)):
+        acts, vibes = np.full(A, a, np.int32), np.full(A, v, np.int32)
+        ref.step(acts, vibes)
+        ora.step(acts, vibes)
+    assert ora.error == 0
+    mine = sg.stats_dicts(prog, *ora.raw_stats(), extra=ora.invalid_index_extra())
+    theirs = ref.c.get_episode_stats()
+    for i in range(A):
+        want = {k: v for k, v in theirs["agent"][i].items() if k.startswith("action.invalid_index")}
+        got = {k: v for k, v in mine["agent"][i].items() if k.startswith("action.invalid_index")}
+        assert got == want
