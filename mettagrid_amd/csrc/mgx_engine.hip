@@ -362,6 +362,12 @@ extern "C" {
 
 const char* mgx_last_error(void) { return g_err.c_str(); }
 
+// construction / episode restart: one wavefront per env on the GPU, the lane-per-env statement in the CPU sanitizer build
+#ifdef MGX_CPU_EMU
+#define MGX_LAUNCH_INIT(stream, ...) hipLaunchKernelGGL(mgx_init_kernel, dim3((d.E + MGX_WAVE - 1) / MGX_WAVE), dim3(MGX_WAVE), 0, stream, __VA_ARGS__)
+#else
+#define MGX_LAUNCH_INIT(stream, ...) hipLaunchKernelGGL(mgx_init_wave_kernel, dim3(d.E), dim3(MGX_WAVE), 0, stream, __VA_ARGS__)
+#endif
 static std::mutex g_live_mu;
 static std::vector<mgx_engine*> g_live;  // engines between mgx_create and mgx_destroy
 
@@ -685,7 +691,7 @@ int mgx_create(const int32_t* program, size_t program_words, const uint16_t* cla
   if (he != hipSuccess) { mgx_destroy(e); return fail(MGX_ERR_HIP, std::string("mgx_create upload: ") + hipGetErrorString(he)); }
   e->dmaps = dmaps;
   e->dseeds = dseeds;
-  hipLaunchKernelGGL(mgx_init_kernel, dim3((d.E + MGX_WAVE - 1) / MGX_WAVE), dim3(MGX_WAVE), 0, e->stream, dev_copy(e), (const uint16_t*)dmaps,
+  MGX_LAUNCH_INIT(e->stream, dev_copy(e), (const uint16_t*)dmaps,
                      (const int32_t*)nullptr, (const uint32_t*)dseeds, (const uint8_t*)nullptr);
   he = hipGetLastError();
   if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
@@ -793,7 +799,7 @@ static int restart_masked(mgx_engine* e, const uint8_t* dmask, bool from_pool, b
   hipLaunchKernelGGL(mgx_clear_rows_kernel, dim3((unsigned)d.E), dim3(256), 0, e->stream, (const MgxRow*)e->d_rows, e->n_rows, dmask, d.E,
                      bump ? e->d_episodes : (uint32_t*)nullptr, bump ? e->d_map_index : (int32_t*)nullptr, e->n_pool, e->pool_stride);
   HIP_TRY(hipGetLastError());
-  hipLaunchKernelGGL(mgx_init_kernel, dim3((d.E + MGX_WAVE - 1) / MGX_WAVE), dim3(MGX_WAVE), 0, e->stream, dev_copy(e),
+  MGX_LAUNCH_INIT(e->stream, dev_copy(e),
                      (const uint16_t*)(from_pool ? e->d_pool : e->dmaps), (const int32_t*)(from_pool ? e->d_map_index : nullptr),
                      (const uint32_t*)e->dseeds, dmask);
   HIP_TRY(hipGetLastError());

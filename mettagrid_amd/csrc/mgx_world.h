@@ -2438,6 +2438,158 @@ __global__ void __launch_bounds__(MGX_WAVE) mgx_init_kernel(const MgxDev* __rest
   }
 }
 
+#ifndef MGX_CPU_EMU
+// The same construction with one WAVEFRONT per env (the kernel the engine launches; the lane-per-env kernel above is its
+// serial statement and what the CPU sanitizer build runs).  An episode restart rebuilds a few dozen envs per step; with
+// one lane per env that was a 0.6 ms chain of 1 024 dependent cell reads per restarted env, on the critical path of
+// every step of an auto-resetting batch.  Here 64 cells are read per pass; ballots give every occupied cell its object
+// slot (= number of occupied cells before it, the reference's object id - 1) and every agent cell its agent index, and
+// each lane initialises its own object.  What is order dependent — the registration lists of the extended variant
+// (tag index, AoE sources, territory sources, in object order) and the materialized queries — is done by lane 0 afterwards
+// over the objects, not the cells.  Object counts per class are whole numbers: atomic float adds are exact in any order.
+__global__ void __launch_bounds__(MGX_WAVE) mgx_init_wave_kernel(const MgxDev* __restrict__ dp, const uint16_t* class_maps,
+                                                                 const int32_t* map_index, const uint32_t* seeds,
+                                                                 const uint8_t* env_mask) {
+  const MgxDev& d = *dp;
+  const int env = blockIdx.x, lane = threadIdx.x;
+  if (env >= d.E) return;
+  if (env_mask && !env_mask[env]) return;
+  MgxEnvX e(d, d.P, env);
+  const size_t E = (size_t)d.E;
+  if (lane == 0) {
+    uint32_t x = seeds[env];  // std::mt19937(seed): bits/random.tcc seed()
+    d.mt[env] = x;
+    for (uint32_t i = 1; i < 624; i++) {
+      x = 1812433253u * (x ^ (x >> 30)) + i;
+      d.mt[i * E + env] = x;
+    }
+    d.mt_idx[env] = 0;
+    d.step[env] = 0;
+    d.err[env] = 0;
+    e.gstat_touch(d.wk[MGX_S_GAME_TOKENS_WRITTEN]);
+    e.gstat_touch(d.wk[MGX_S_GAME_TOKENS_DROPPED]);
+    e.gstat_touch(d.wk[MGX_S_GAME_TOKENS_FREE]);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // err = 0 / touched bits before any lane's atomicOr below
+  __builtin_amdgcn_wave_barrier();
+  const int HW = d.H * d.W;
+  const uint16_t* cm = class_maps + (size_t)(map_index ? map_index[env] : env) * HW;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  int nobj = 0, nag = 0;
+  bool overflow = false;
+  for (int base = 0; base < HW; base += MGX_WAVE) {
+    const int cellidx = base + lane;
+    const int k = cellidx < HW ? (int)cm[cellidx] : 0;
+    const unsigned long long occ = __ballot(k != 0);
+    const int32_t* C = mgx_cls(d, k ? k - 1 : 0);
+    const bool agent_cell = k != 0 && C[MGX_C_KIND] == MGX_KIND_AGENT;
+    const unsigned long long agm = __ballot(agent_cell);
+    const int slot = nobj + __popcll(occ & lt);
+    const int ai_raw = nag + __popcll(agm & lt);
+    nobj += __popcll(occ);
+    nag += __popcll(agm);
+    if (k == 0) continue;
+    if (slot >= d.S) { overflow = true; continue; }   // (the serial kernel stops at the first object that does not fit)
+    const int cls = k - 1;
+    const int r = cellidx / d.W, c = cellidx % d.W;
+    const uint16_t rc = (uint16_t)((r << 8) | c);
+    d.grid[(size_t)env * HW + cellidx] = (uint16_t)(slot + 1);
+    d.obj_cls[e.so(slot)] = (uint16_t)cls;
+    d.obj_rc[e.so(slot)] = rc;
+    d.obj_vibe[e.so(slot)] = (uint8_t)C[MGX_C_INITIAL_VIBE];
+    int ai = -1;
+    if (agent_cell && ai_raw < d.A) {
+      ai = ai_raw;
+      d.ag_obj[e.ao(ai)] = (uint16_t)slot;
+      d.ag_prev[e.ao(ai)] = rc;
+      d.ag_spawn[e.ao(ai)] = rc;
+      d.ag_stepprev[e.ao(ai)] = rc;
+      d.ag_covrc[e.ao(ai)] = 0xFFFF;
+      for (int q = 0; q < MGX_INVALID_EXTRA; q++) d.ag_invn[e.ao(ai) * MGX_INVALID_EXTRA + q] = 0.f;
+    }
+    d.obj_agent[e.so(slot)] = ai < 0 ? MGX_NO_AGENT : (uint8_t)ai;
+    const int32_t* ii = d.P + d.sec[MGX_SEC_INIT_INV] + C[MGX_C_INIT_INV_START] * MGX_II_WORDS;
+    for (int i = 0; i < C[MGX_C_INIT_INV_COUNT]; i++, ii += MGX_II_WORDS) {
+      e.inv_update<0>(slot, ii[MGX_II_ITEM], ii[MGX_II_AMOUNT], true, false);
+      if (ai >= 0) e.astat_set(ai, d.wk[MGX_S_RES_AMOUNT_BASE] + ii[MGX_II_ITEM], (float)ii[MGX_II_AMOUNT]);
+    }
+    const int os = C[MGX_C_OBJECTS_STAT];
+    if (os >= 0) {
+      atomicAdd(&d.game_stats[(size_t)env * d.NG + os], 1.f);
+      atomicOr(&d.game_touched[(size_t)env * d.NGW + (os >> 5)], 1u << (os & 31));
+    }
+    if (d.X && d.obj_tags)
+      for (int w = 0; w < MGX_TAG_WORDS; w++) d.obj_tags[e.so(slot) * MGX_TAG_WORDS + w] = (uint32_t)C[MGX_C_TAGS + w];
+  }
+  if (__ballot(overflow)) { if (lane == 0) atomicOr(&d.err[env], 8u); nobj = min(nobj, d.S); }
+  nag = min(nag, d.A);
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // the objects written by other lanes are read below
+  __builtin_amdgcn_wave_barrier();
+  if (lane == 0) {
+    d.num_objs[env] = (uint32_t)nobj;
+    if (d.X) {
+      int nf = 0, nm = 0, nts = 0;
+      for (int slot = 0; slot < nobj; slot++) {   // registrations in object order
+        const int32_t* C = mgx_cls(d, d.obj_cls[e.so(slot)]);
+        const uint16_t rc = d.obj_rc[e.so(slot)];
+        for (int t = 0; t < 256 && d.NL > 0; t++) {  // TagIndex::register_object (core/tag_index.cpp:9-19)
+          if (!(((uint32_t)C[MGX_C_TAGS + (t >> 5)] >> (t & 31)) & 1u)) continue;
+          int li = e.tag_list(t);
+          if (li >= 0) { uint16_t n = e.tl_count(li); e.tl_items(li)[n] = (uint16_t)slot; e.tl_count(li) = n + 1; }
+        }
+        for (int i = 0; i < C[MGX_C_AOE_COUNT]; i++) {  // AOETracker::register_source (mettagrid_c.cpp:249-252)
+          int a = C[MGX_C_AOE_START] + i;
+          const int32_t* AO = d.P + d.sec[MGX_SEC_AOES] + a * MGX_AO_WORDS;
+          if (AO[MGX_AO_STATIC]) {
+            if (nf < d.NF) { size_t q = (size_t)env * d.NF + nf; d.fx_obj[q] = (uint16_t)slot; d.fx_aoe[q] = (uint16_t)a; d.fx_rc[q] = rc; nf++; }
+            else e.flag(8u);
+          } else if (nm < d.NM) {
+            size_t q = (size_t)env * d.NM + nm; d.mb_obj[q] = (uint16_t)slot; d.mb_aoe[q] = (uint16_t)a; nm++;
+          } else {
+            e.flag(8u);
+          }
+        }
+        for (int i = 0; i < C[MGX_C_TERR_COUNT]; i++)  // TerritoryTracker::register_source (:254-257)
+          if (nts < d.NTS) { size_t q = (size_t)env * d.NTS + nts; d.ts_obj[q] = (uint16_t)slot; d.ts_ctrl[q] = (uint16_t)(C[MGX_C_TERR_START] + i); d.ts_rc[q] = rc; nts++; }
+          else e.flag(8u);
+      }
+      if (d.NF) d.fx_count[env] = (uint16_t)nf;
+      if (d.NM) d.mb_count[env] = (uint16_t)nm;
+      if (d.NTS) d.ts_count[env] = (uint16_t)nts;
+      for (int i = 0; i < d.A * d.NT; i++) d.terr_prev[(size_t)env * d.A * d.NT + i] = -1;
+      d.next_event[env] = 0;
+      const int32_t* mq = d.P + d.sec[MGX_SEC_MATQ];   // QuerySystem::compute_all (query_system.cpp:91-117)
+      for (int i = 0; i < d.n_matq; i++, mq += MGX_MQ_WORDS) {
+        int tag = mq[MGX_MQ_TAG];
+        int li = e.tag_list(tag);
+        if (li >= 0) {
+          uint16_t* lost = e.qbuf(MgxEnvX::QB_LOST);
+          int nl = e.tl_count(li);
+          for (int k = 0; k < nl; k++) lost[k] = e.tl_items(li)[k];
+          for (int k = 0; k < nl; k++) e.tag_clear(lost[k], tag);
+        }
+        MgxCtx g = mgx_ctx(MGX_SLOT_NONE, MGX_SLOT_NONE);
+        int n = e.eval_query<3>(mq[MGX_MQ_QUERY], g, 0);
+        uint16_t* keep = e.qbuf(MgxEnvX::QB_KEEP);
+        const uint16_t* res = e.qbuf(MgxEnvX::QB_BASE);
+        for (int k = 0; k < n; k++) keep[k] = res[k];
+        for (int k = 0; k < n; k++) e.tag_set(keep[k], tag);
+      }
+    }
+  }
+  for (int ai = lane; ai < nag; ai += MGX_WAVE) {   // per-agent tail: own rows only (game-scope touches are atomic)
+    e.track_coverage(ai);  // Agent::init -> reset_coverage_tracking (agent.cpp:25-28,41-47)
+    const int32_t* C = e.cls_of(d.ag_obj[e.ao(ai)]);
+    const int32_t* rw = d.P + d.sec[MGX_SEC_REWARDS] + C[MGX_C_REWARD_START] * MGX_RW_WORDS;
+    for (int i = 0; i < C[MGX_C_REWARD_COUNT]; i++, rw += MGX_RW_WORDS) {  // systems/reward.hpp:45-53
+      if (rw[MGX_RW_TOUCH_SCOPE] == 0) e.astat_touch(ai, rw[MGX_RW_TOUCH_STAT]);
+      else if (rw[MGX_RW_TOUCH_SCOPE] == 1)
+        atomicOr(&d.game_touched[(size_t)env * d.NGW + (rw[MGX_RW_TOUCH_STAT] >> 5)], 1u << (rw[MGX_RW_TOUCH_STAT] & 31));
+    }
+  }
+}
+#endif
+
 // ---- episode restart on the device -----------------------------------------------------------------------------------
 struct MgxRow { uint8_t* base; unsigned long long row_bytes; int fill; int pad; };  // one env-major state array
 // One workgroup per env: for a masked env, fill its row of every state array in the table (what a fresh construction
