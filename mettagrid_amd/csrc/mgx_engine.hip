@@ -543,7 +543,8 @@ int mgx_create(const int32_t* program, size_t program_words, const uint16_t* cla
   d.actions = e->own_act; d.vibe_actions = e->own_vact;
 
   e->verbose = getenv("MGX_VERBOSE") != nullptr;
-  e->lds_world = d.X ? mgx_world_x_lds_bytes(d.A) : mgx_world_fast_lds_bytes(d.A);
+  d.x_aoe_lds = (d.X && !(e->aoe_local && (d.NF > 0 || d.NM > 0 || d.NT > 0))) ? 1 : 0;
+  e->lds_world = d.X ? mgx_world_x_lds_bytes(d.A, d.x_aoe_lds != 0) : mgx_world_fast_lds_bytes(d.A);
   // The world kernels copy the program — everything in front of the schedule, the last and only section that grows with
   // the episode length — into LDS when it leaves room for 4 (lean) / 3 (extended) workgroups per CU (160 KB LDS).
   // (Rung 4, measured: the copy at 2 workgroups per CU is slower than the program in HBM at 3: 9.8 against 8.4 ms.)

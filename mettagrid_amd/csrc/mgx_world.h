@@ -117,10 +117,13 @@ __host__ __device__ inline int mgx_world_alds_bytes(int A) { return A * MGX_WORL
 // byte offset of the extended variant's per-lane scratch (deferred deltas | territory scores | VM words) in the LDS
 __host__ __device__ inline int mgx_world_xlds_off(int A) { return ((A * MGX_WORLD_EPG + 15) & ~15) + ((mgx_world_alds_bytes(A) + 15) & ~15); }
 // Dynamic LDS of the world kernels: order u8[A][64] | swm u32[A][64] | act i16[2][A][64] | slot, rc, prev, cls u16[A][64] |
-// [X: deferred i32[28][64] | territory i64[8][64] | VM u32[MGX_VM_WORDS][64]] | program i32[prog_words] (when it fits).
-__host__ __device__ inline int mgx_world_lds_fixed(int A, bool X) {
+// [X: VM u32[MGX_VM_WORDS][64] | (in-kernel AoE phase only:) deferred i32[28][64] | territory i64[8][64]] | program
+// i32[prog_words] (when it fits).
+// (aoe_lds: the deferred-delta and territory-score scratch of the in-kernel AoE phase; games whose AoE runs in
+// mgx_aoe_kernel do without it, which is what lets a fourth 32-env workgroup fit a CU at 64 agents per env)
+__host__ __device__ inline int mgx_world_lds_fixed(int A, bool X, bool aoe_lds = true) {
   int o = ((A * MGX_WORLD_EPG + 15) & ~15) + ((mgx_world_alds_bytes(A) + 15) & ~15);
-  if (X) o += 28 * MGX_WORLD_EPG * 4 + 8 * MGX_WORLD_EPG * 8 + MGX_VM_WORDS * MGX_WORLD_EPG * 4;
+  if (X) o += MGX_VM_WORDS * MGX_WORLD_EPG * 4 + (aoe_lds ? 28 * MGX_WORLD_EPG * 4 + 8 * MGX_WORLD_EPG * 8 : 0);
   return o;
 }
 __device__ __forceinline__ MgxALds mgx_world_alds(uint8_t* lds, int A, int lane) {
@@ -180,14 +183,14 @@ struct MgxEnvT {  // per-lane view of one env
 #ifdef MGX_WORLD_IDS
   __device__ __forceinline__ int envi() const { return (int)(blockIdx.x * MGX_WORLD_EPG) + mgx_world_lane(); }
   __device__ __forceinline__ PP prog() const {
-    if constexpr (std::is_same<PP, MgxLdsProg>::value) return (MgxLdsProg)(int32_t*)(mgx_dyn_lds + mgx_world_lds_fixed(d.A, X));
+    if constexpr (std::is_same<PP, MgxLdsProg>::value) return (MgxLdsProg)(int32_t*)(mgx_dyn_lds + mgx_world_lds_fixed(d.A, X, d.x_aoe_lds != 0));
     else return d.P;
   }
   __device__ __forceinline__ MgxALds AL() const { return mgx_world_alds(mgx_dyn_lds, d.A, mgx_world_lane()); }
   __device__ __forceinline__ MgxXLds XL() const {  // per-lane scratch of the extended variant
     MgxXLds x;
-    x.def_delta = (int*)(mgx_dyn_lds + mgx_world_xlds_off(d.A));
-    x.terr_score = (long long*)(mgx_dyn_lds + mgx_world_xlds_off(d.A) + 28 * MGX_WORLD_EPG * 4);
+    x.def_delta = (int*)(mgx_dyn_lds + mgx_world_xlds_off(d.A) + MGX_VM_WORDS * MGX_WORLD_EPG * 4);
+    x.terr_score = (long long*)(mgx_dyn_lds + mgx_world_xlds_off(d.A) + MGX_VM_WORDS * MGX_WORLD_EPG * 4 + 28 * MGX_WORLD_EPG * 4);
     x.lane = mgx_world_lane(); x.stride = MGX_WORLD_EPG;
     return x;
   }
@@ -1142,7 +1145,7 @@ struct MgxEnvT {  // per-lane view of one env
   // actor = target = the tagged object (core/grid_object.cpp:83-91).
   __device__ __forceinline__ uint32_t* vm_words() const {
 #ifdef MGX_WORLD_IDS
-    return (uint32_t*)(mgx_dyn_lds + mgx_world_xlds_off(d.A) + 28 * MGX_WORLD_EPG * 4 + 8 * MGX_WORLD_EPG * 8) + mgx_world_lane();
+    return (uint32_t*)(mgx_dyn_lds + mgx_world_xlds_off(d.A)) + mgx_world_lane();
 #else
     return nullptr;  // the handler VM only runs in the lane-per-env world kernels
 #endif
@@ -2270,10 +2273,10 @@ __device__ __forceinline__ void mgx_world_entry(const MgxDev& d, int prog_words,
   const MgxALds al = mgx_world_alds(mgx_dyn_lds, d.A, lane);
   int off = ((d.A * MGX_WORLD_EPG + 15) & ~15) + ((mgx_world_alds_bytes(d.A) + 15) & ~15);
   if (X) {
-    xl.def_delta = (int*)(mgx_dyn_lds + off);
-    off += 28 * MGX_WORLD_EPG * 4;
-    xl.terr_score = (long long*)(mgx_dyn_lds + off);
-    off += 8 * MGX_WORLD_EPG * 8 + MGX_VM_WORDS * MGX_WORLD_EPG * 4;
+    off += MGX_VM_WORDS * MGX_WORLD_EPG * 4;
+    xl.def_delta = (int*)(mgx_dyn_lds + off);   // (both only exist — and are only touched — with the in-kernel AoE phase)
+    xl.terr_score = (long long*)(mgx_dyn_lds + off + 28 * MGX_WORLD_EPG * 4);
+    if (d.x_aoe_lds) off += 28 * MGX_WORLD_EPG * 4 + 8 * MGX_WORLD_EPG * 8;
   } else {
     xl.def_delta = nullptr;
     xl.terr_score = nullptr;
@@ -2307,7 +2310,7 @@ bool mgx_world_fast_set_lds_s1(size_t lds);
 // ... and of the extended one (mgx_world_x.hip)
 void mgx_launch_world_x(bool prog_lds, size_t lds, hipStream_t stream, const MgxDev& d, const MgxDev* dev_copy, int prog_words, int phases);
 bool mgx_world_x_set_lds(size_t lds);
-size_t mgx_world_x_lds_bytes(int A);
+size_t mgx_world_x_lds_bytes(int A, bool aoe_lds);
 size_t mgx_world_x_private_bytes();
 void mgx_launch_values(hipStream_t stream, const MgxDev& d, const MgxDev* dev_copy, int phase, const uint8_t* env_mask);
 // lane-per-agent area effects (mgx_aoe.hip) and the host analysis that allows them

@@ -94,7 +94,7 @@ bool mgx_world_x_set_lds(size_t lds) {  // process-wide maximum, only ever raise
   return true;
 }
 
-size_t mgx_world_x_lds_bytes(int A) { return (size_t)mgx_world_lds_fixed(A, true); }
+size_t mgx_world_x_lds_bytes(int A, bool aoe_lds) { return (size_t)mgx_world_lds_fixed(A, true, aoe_lds); }
 
 size_t mgx_world_x_private_bytes() {  // per-lane private segment of the build (reported by MGX_VERBOSE, checked by tests)
   size_t m = 0;
