@@ -16,7 +16,7 @@
 #include "mgx_world.h"
 
 #define MGX_AOE_THREADS 256
-__global__ void __launch_bounds__(MGX_AOE_THREADS) mgx_aoe_kernel(const MgxDev* __restrict__ dp) {
+__global__ void __launch_bounds__(MGX_AOE_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) mgx_aoe_kernel(const MgxDev* __restrict__ dp) {
   const MgxDev& d = *dp;  // per-engine copy in device memory (see mgx_world_x.hip)
   extern __shared__ __align__(16) uint8_t aoe_lds[];
   const int wave = (int)threadIdx.x / MGX_WAVE, lane = (int)threadIdx.x & (MGX_WAVE - 1);

@@ -122,7 +122,7 @@ __host__ __device__ inline int mgx_obs_xmode(bool X, bool want_mask, int S, int 
 }
 __host__ __device__ inline MgxObsLds mgx_obs_lds_layout(int HW, int NOFF, int S, int A, int T, int pool_tokens,
                                                         int xmode = 0, int NOV = 0, int blk_words = 0, int GT = 6,
-                                                        bool blk_early = false) {
+                                                        bool blk_early = false, int waves = MGX_OBS_WAVES) {
   const bool X = xmode != 0;
   MgxObsLds l;
   int o = 0;
@@ -147,7 +147,7 @@ __host__ __device__ inline MgxObsLds mgx_obs_lds_layout(int HW, int NOFF, int S,
   l.rows = o;
   l.owner = 0;
   {
-    const int rows_bytes = MGX_OBS_WAVES * 4 * l.row_pitch * 4;  // one staging row per DPP row of every wavefront
+    const int rows_bytes = waves * 4 * l.row_pitch * 4;  // one staging row per DPP row of every wavefront
     int eo = o;
     l.grid = eo; eo += mgx_align16(HW * 2);
     l.offs = eo; eo += mgx_align16(NOFF * 2);
@@ -187,8 +187,9 @@ __device__ __forceinline__ uint32_t mgx_wave_sum(uint32_t x) {
 // out-of-object pointer arithmetic on an LDS address).
 // pool_prefix: the first pool_prefix pool entries are the per-class static tag tokens (a copy of MgxDev::cls_tok), which
 // is all a static object (walls ...) ever shows; only the other objects get a per-step list behind them.
-template <bool WITH_REWARDS, bool X, bool PL>
-__global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int pool_tokens, int pool_prefix, const uint8_t* env_mask,
+// NTH: threads per workgroup — 256, or 512 for envs with many agents (more wavefronts over the same per-env LDS).
+template <bool WITH_REWARDS, bool X, bool PL, int NTH = MGX_OBS_THREADS>
+__global__ void __launch_bounds__(NTH) mgx_obs_kernel(MgxDev d, int pool_tokens, int pool_prefix, const uint8_t* env_mask,
                                                                   int blk_start, int blk_words, int rewards_early) {
   MGX_KERNARG_ENTRY(d);
   extern __shared__ __align__(16) uint8_t smem[];
@@ -202,7 +203,7 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
   const int xmode = mgx_obs_xmode(X, want_mask, S, d.P[MGX_H_NUM_TAGS]);
   const bool pack_mask = (xmode & MGX_OX_PACK) != 0, owner8 = (xmode & MGX_OX_OWNER8) != 0;
   const MgxObsLds L = mgx_obs_lds_layout(HW, NOFF, S, A, T, pool_tokens, xmode, d.n_obs_values, PL ? blk_words : 0, GT,
-                                         rewards_early != 0);
+                                         rewards_early != 0, NTH / MGX_WAVE);
   const int CP = L.cp;
   uint16_t* s_grid = (uint16_t*)(smem + L.grid);
   char2* s_offs = (char2*)(smem + L.offs);
@@ -297,22 +298,22 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
     const uint4* src = (const uint4*)(d.grid + (size_t)env * HW);
     uint4* dst = (uint4*)s_grid;
     const int n16 = (HW * 2) / 16;
-    for (int i = tid; i < n16; i += MGX_OBS_THREADS) dst[i] = src[i];
-    for (int i = n16 * 8 + tid; i < HW; i += MGX_OBS_THREADS) s_grid[i] = d.grid[(size_t)env * HW + i];
+    for (int i = tid; i < n16; i += NTH) dst[i] = src[i];
+    for (int i = n16 * 8 + tid; i < HW; i += NTH) s_grid[i] = d.grid[(size_t)env * HW + i];
     if constexpr (PL) {
       const int4* bsrc = (const int4*)(d.P + blk_start);
       int4* bdst = (int4*)(smem + L.blk);
-      for (int i = tid; i < blk_words / 4; i += MGX_OBS_THREADS) bdst[i] = bsrc[i];
+      for (int i = tid; i < blk_words / 4; i += NTH) bdst[i] = bsrc[i];
     }
-    for (int i = tid; i < pool_prefix; i += MGX_OBS_THREADS) s_pool[i] = d.cls_tok[i];
+    for (int i = tid; i < pool_prefix; i += NTH) s_pool[i] = d.cls_tok[i];
     const int32_t* offs = d.P + d.sec[MGX_SEC_OBS_OFFSETS];
-    for (int i = tid; i < CP; i += MGX_OBS_THREADS) {
+    for (int i = tid; i < CP; i += NTH) {
       const int ii = min(i, NOFF - 1);
       const int orow = offs[ii * 2], ocol = offs[ii * 2 + 1];
       if (i < NOFF) s_offs[i] = make_char2((char)orow, (char)ocol);
       s_loc[i] = (uint8_t)(((orow + hr) << 4) | (ocol + wr));
     }
-    for (int i = tid; i < A; i += MGX_OBS_THREADS) {
+    for (int i = tid; i < A; i += NTH) {
       const uint32_t slot = d.ag_obj[e.ao(i)];
       const int32_t ex = d.executed[e.ao(i)];
       const uint16_t sprev = d.ag_stepprev[e.ao(i)];
@@ -334,7 +335,7 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
   __syncthreads();
   MGX_TICK(8);
   MGX_PHASE_END(1);
-  for (int s = tid; s < S; s += MGX_OBS_THREADS) {
+  for (int s = tid; s < S; s += NTH) {
     const size_t o = e.so(s);
     const bool pre = s == tid;  // first pass: loaded above
     const uint16_t cls = pre ? pre_cls : d.obj_cls[o];
@@ -360,12 +361,12 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
   // The wavefronts that get no objects ("free") take the whole window-map phase and the global tokens meanwhile, so
   // the workgroup's critical path is the longer of the two jobs, not their sum. ----
   const int ndyn = (int)s_misc[1];
-  const int nbw = min((ndyn + MGX_WAVE - 1) / MGX_WAVE, MGX_OBS_WAVES);  // wavefronts with list-building work
-  const int nfree = MGX_OBS_WAVES - nbw;
+  const int nbw = min((ndyn + MGX_WAVE - 1) / MGX_WAVE, (NTH / MGX_WAVE));  // wavefronts with list-building work
+  const int nfree = (NTH / MGX_WAVE) - nbw;
   {
     const int f_vibe = d.feat[MGX_F_VIBE], f_group = d.feat[MGX_F_GROUP], f_agent = d.feat[MGX_F_AGENT_ID], f_tag = d.feat[MGX_F_TAG];
     VP feat = vp + d.sec[MGX_SEC_INV_FEATURES];
-    for (int i = tid; i < ndyn; i += MGX_OBS_THREADS) {
+    for (int i = tid; i < ndyn; i += NTH) {
       const int s = s_dyn[i];
       const uint32_t cinfo = s_tokinfo[s];
       // every field of the slot at once: independent loads, one memory round trip
@@ -443,7 +444,7 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
   }
   // Rewards that read nothing this kernel writes (no stat operands; host flag) are evaluated here by the last
   // wavefront, which has little or no list-building work, instead of serially at the end of the workgroup.
-  if (WITH_REWARDS && rewards_early && wave == MGX_OBS_WAVES - 1) {
+  if (WITH_REWARDS && rewards_early && wave == (NTH / MGX_WAVE) - 1) {
     // One lane per (agent, reward entry): the entries of an agent are evaluated side by side (their loads in flight
     // together) and then summed in entry order by the agent's first lane, exactly like the serial loop of
     // agent_rewards (reward.hpp:56-77: total += val or val - prev, entry by entry).
@@ -492,20 +493,20 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
   if constexpr (X) {
     if (want_mask) {  // TerritoryTracker::compute_observability_at (:254-273): first territory with an owner decides.
                       // The per-type ownership maps are current here: mgx_terr_kernel runs right before this kernel.
-      for (int cellidx = tid; cellidx < HW; cellidx += MGX_OBS_THREADS) {
+      for (int cellidx = tid; cellidx < HW; cellidx += NTH) {
         uint16_t owner = 0xFFFF;
         for (int ti = 0; ti < d.NT && owner == 0xFFFF; ti++) owner = d.terr_owner[((size_t)env * d.NT + ti) * (size_t)HW + cellidx];
         if (owner8) s_owner8[cellidx] = (uint8_t)owner; else s_owner[cellidx] = owner;  // (0xFFFF -> 0xFF: tag ids stop at 254 then)
       }
       // the observers' own tag bitsets, once per env instead of one HBM round trip per masked window cell
-      for (int i = tid; i < A * MGX_TAG_WORDS; i += MGX_OBS_THREADS) {
+      for (int i = tid; i < A * MGX_TAG_WORDS; i += NTH) {
         const int slot = (int)(s_agents[i / MGX_TAG_WORDS] & 0xFFFF);
         s_agtags[i] = d.obj_tags ? d.obj_tags[e.so(slot) * MGX_TAG_WORDS + (i % MGX_TAG_WORDS)]
                                  : (uint32_t)e.cls_of(slot)[MGX_C_TAGS + (i % MGX_TAG_WORDS)];
       }
     }
     if (d.obsval)  // query-backed obs values: evaluated by mgx_values_kernel (one env per lane) right before this kernel
-      for (int i = tid; i < A * d.n_obs_values; i += MGX_OBS_THREADS) s_obsval[i] = d.obsval[(size_t)env * A * d.n_obs_values + i];
+      for (int i = tid; i < A * d.n_obs_values; i += NTH) s_obsval[i] = d.obsval[(size_t)env * A * d.n_obs_values + i];
     if (want_mask || (d.obsval && d.n_obs_values > 0)) __syncthreads();  // read by other threads below
   }
 
@@ -517,7 +518,7 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
   // a lane's window offsets of the first two passes are the same for every agent: read once, not once per agent
   const char2 offs_p0 = s_offs[min(lane, NOFF - 1)], offs_p1 = s_offs[min(lane + MGX_WAVE, NOFF - 1)];
   const int a_first = nfree > 0 ? (wave >= nbw && wave < nbw + np1 ? wave - nbw : A) : wave;
-  const int a_step = nfree > 0 ? np1 : MGX_OBS_WAVES;
+  const int a_step = nfree > 0 ? np1 : (NTH / MGX_WAVE);
   // A window of 65..96 cells (11x11: 89) leaves the second pass of an agent at most half full: two agents share it,
   // one per 32-lane half, so a pair costs three passes instead of four.
   bool pair_tail = false;
@@ -600,7 +601,7 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
     }
   }
   // global tokens (location 0xFE), mettagrid_c.cpp:700-753: one thread per agent, all agents at once
-  const int gwave = np1 < nfree ? MGX_OBS_WAVES - 1 : (nfree > 0 ? nbw : 0);  // after the early rewards when that wavefront skipped the lists
+  const int gwave = np1 < nfree ? (NTH / MGX_WAVE) - 1 : (nfree > 0 ? nbw : 0);  // after the early rewards when that wavefront skipped the lists
   for (int a = (wave == gwave) ? lane : A; a < A; a += MGX_WAVE) {
     const uint32_t ag = s_agents[a];
     const int my_slot = ag & 0xFFFF;
@@ -654,7 +655,7 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
   // ---- phase 2: encode.  One agent per 16-lane DPP row, four agents per wavefront at a time: an agent sees ~15-20
   // occupied cells, so a whole wavefront per agent left three quarters of the lanes idle.  Scans are row scans (four
   // DPP steps), row-wide values travel by ds_bpermute, long token lists are copied by the 16 lanes of their row. ----
-  for (int a0 = wave * 4; a0 < A; a0 += MGX_OBS_WAVES * 4) {
+  for (int a0 = wave * 4; a0 < A; a0 += (NTH / MGX_WAVE) * 4) {
     const int a = a0 + row;
     const bool av = a < A;          // this row has an agent
     const int ac = av ? a : A - 1;  // clamped for the unconditional reads
@@ -779,7 +780,7 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
 
   // ---- visited stamps, token statistics, rewards, termination ----
   if (step > 0)
-    for (int s = tid; s < S; s += MGX_OBS_THREADS)
+    for (int s = tid; s < S; s += NTH)
       if (s_minobs[s] != 0xFFFFFFFFu && s_visited[s] < step) d.obj_visited[e.so(s)] = step;
   if (wave == 0) {  // tokens_written / tokens_free_space (:659-661, 821-823): the reference adds agent by agent in f32
     float* gs = d.game_stats + (size_t)env * d.NG;
@@ -814,7 +815,7 @@ __global__ void __launch_bounds__(MGX_OBS_THREADS) mgx_obs_kernel(MgxDev d, int 
   if (WITH_REWARDS && !rewards_early) {
     // (reward expressions with query operands never reach this kernel: mgx_values_kernel evaluates them, one env per
     // lane, after it — the host launches this kernel without rewards then)
-    for (int a = tid; a < A; a += MGX_OBS_THREADS) agent_rewards(a);
+    for (int a = tid; a < A; a += NTH) agent_rewards(a);
   }
   MGX_TICK(14);
 }
