@@ -221,7 +221,10 @@ __global__ void __launch_bounds__(NTH) mgx_obs_kernel(MgxDev d, int pool_tokens,
   uint32_t* s_misc = (uint32_t*)(smem + L.misc);
   uint16_t* s_pool = (uint16_t*)(smem + L.pool);
   const int row = lane >> 4, rl = lane & 15;  // encode: one agent per 16-lane DPP row
-  uint32_t* s_row = (uint32_t*)(smem + L.rows) + (wave * 4 + row) * L.row_pitch;  // one u32 per token: loc | f << 8 | v << 16
+  // One u32 per token: loc | f << 8 | v << 16.  The pitch is 24 words mod 32 banks, so the rows of a wavefront start at
+  // banks 0, 24, 16, 8: DPP rows 0 and 1 (one 32-lane LDS group) take the 1st and 3rd of them, rows 2 and 3 the 2nd and 4th
+  // — the two 16-word spans of a group then never share a bank.
+  uint32_t* s_row = (uint32_t*)(smem + L.rows) + (wave * 4 + (((row & 1) << 1) | (row >> 1))) * L.row_pitch;
   const int TRASH = L.row_words + rl;  // s_row[TRASH]: target of this lane's masked-off stores
   uint16_t* s_cell = (uint16_t*)(smem + L.cell);
   uint8_t* s_vj = smem + L.vj;
