@@ -16,7 +16,12 @@
 #include "mgx_world.h"
 
 #define MGX_AOE_THREADS 256
-__global__ void __launch_bounds__(MGX_AOE_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) mgx_aoe_kernel(const MgxDev* __restrict__ dp) {
+#ifdef MGX_CPU_EMU
+#define MGX_AOE_OCCUPANCY
+#else
+#define MGX_AOE_OCCUPANCY __attribute__((amdgpu_waves_per_eu(4, 4)))  // 128 VGPRs: the kernel waits on memory 80 % of the time
+#endif
+__global__ void __launch_bounds__(MGX_AOE_THREADS) MGX_AOE_OCCUPANCY mgx_aoe_kernel(const MgxDev* __restrict__ dp) {
   const MgxDev& d = *dp;  // per-engine copy in device memory (see mgx_world_x.hip)
   extern __shared__ __align__(16) uint8_t aoe_lds[];
   const int wave = (int)threadIdx.x / MGX_WAVE, lane = (int)threadIdx.x & (MGX_WAVE - 1);
@@ -112,7 +117,10 @@ static bool mutations_are_local(const int32_t* P, int start, int count, bool& ch
   }
   return true;
 }
-bool mgx_aoe_is_target_local(const int32_t* P) {
+static bool aoe_scan(const int32_t* P, bool with_on_tick);
+bool mgx_aoe_is_target_local(const int32_t* P) { return aoe_scan(P, false); }
+bool mgx_aoe_on_tick_local(const int32_t* P) { return aoe_scan(P, true); }
+static bool aoe_scan(const int32_t* P, bool with_on_tick) {
   if (P[MGX_H_SPAWNS]) return false;  // deferred AoE registration of spawned objects stays with the serial form
   bool reads_actor_vibe = false, changes_vibe = false;
   const int na = mgx_sec_cnt(P, MGX_SEC_AOES);
@@ -134,6 +142,17 @@ bool mgx_aoe_is_target_local(const int32_t* P) {
         if (!filters_are_local(P, hd[MGX_HD_FILTER_PC], reads_actor_vibe)) return false;
         if (!mutations_are_local(P, hd[MGX_HD_MUT_START], hd[MGX_HD_MUT_COUNT], changes_vibe)) return false;
       }
+  }
+  if (with_on_tick) {  // + the per-agent on_tick handlers, run by the same lanes in front of the area effects
+    const int nc = P[MGX_H_NUM_CLASSES];
+    for (int c = 0; c < nc; c++) {
+      const int h = P[mgx_sec_off(P, MGX_SEC_CLASSES) + c * MGX_C_WORDS + MGX_C_ON_TICK];
+      if (h < 0) continue;
+      const int32_t* hd = P + mgx_sec_off(P, MGX_SEC_HANDLERS) + h * MGX_HD_WORDS;
+      if (hd[MGX_HD_KIND] != MGX_HK_LEAF) return false;
+      if (!filters_are_local(P, hd[MGX_HD_FILTER_PC], reads_actor_vibe)) return false;
+      if (!mutations_are_local(P, hd[MGX_HD_MUT_START], hd[MGX_HD_MUT_COUNT], changes_vibe)) return false;
+    }
   }
   return !(reads_actor_vibe && changes_vibe);  // a source's vibe may be another lane's target's vibe
 }

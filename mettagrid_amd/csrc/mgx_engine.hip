@@ -549,6 +549,11 @@ int mgx_create(const int32_t* program, size_t program_words, const uint16_t* cla
   d.actions = e->own_act; d.vibe_actions = e->own_vact;
 
   e->verbose = getenv("MGX_VERBOSE") != nullptr;
+  {
+    const bool split = d.X && e->aoe_local && (d.NF > 0 || d.NM > 0 || d.NT > 0);
+    d.tick_in_aoe = (split && d.any_on_tick && mgx_aoe_on_tick_local(P) && !getenv("MGX_TICK_SERIAL")) ? 1 : 0;
+    d.cov_in_aoe = (split && d.game_on_tick < 0 && !getenv("MGX_TICK_SERIAL")) ? 1 : 0;
+  }
   d.x_aoe_lds = (d.X && !(e->aoe_local && (d.NF > 0 || d.NM > 0 || d.NT > 0))) ? 1 : 0;
   e->lds_world = d.X ? mgx_world_x_lds_bytes(d.A, d.x_aoe_lds != 0) : mgx_world_fast_lds_bytes(d.A);
   // The world kernels copy the program — everything in front of the schedule, the last and only section that grows with
@@ -1062,7 +1067,7 @@ int mgx_step(mgx_engine* e) {
       mgx_launch_aoe(e->stream, e->d, dev_copy(e));
       MGX_TRACE_POINT(e, "aoe kernel");
       MGX_MARK(2);
-      mgx_launch_world_x(e->prog_in_lds, e->lds_world, e->stream, e->d, dev_copy(e), pw, MGX_PH_TAIL);
+      if (!d.cov_in_aoe) mgx_launch_world_x(e->prog_in_lds, e->lds_world, e->stream, e->d, dev_copy(e), pw, MGX_PH_TAIL);
       MGX_MARK(3);
     } else {
       mgx_launch_world_x(e->prog_in_lds, e->lds_world, e->stream, e->d, dev_copy(e), pw, MGX_PH_ALL);

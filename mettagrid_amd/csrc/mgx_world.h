@@ -1563,6 +1563,16 @@ struct MgxEnvT {  // per-lane view of one env
     const int tgt = d.ag_obj[ao(ai)];
     const uint16_t rc = d.obj_rc[so(tgt)];
     const int r = rc >> 8, c = rc & 0xFF;
+    // ---- per-agent on_tick (mettagrid_c.cpp:1019-1024) when it only touches its own agent: the step that precedes the
+    // area effects in _step runs here with one lane per agent instead of 64 agents deep in the lane-per-env kernel ----
+    if (d.tick_in_aoe) {
+      const int h = cls_of(tgt)[MGX_C_ON_TICK];
+      if (h >= 0) {
+        PP hd = prog() + d.sec[MGX_SEC_HANDLERS] + h * MGX_HD_WORDS;
+        MgxCtx tc = mgx_ctx(tgt, tgt);
+        apply_all_local(hd[MGX_HD_FILTER_PC], hd[MGX_HD_MUT_START], hd[MGX_HD_MUT_COUNT], tc);
+      }
+    }
     // ---- AOETracker::apply_fixed (core/aoe_tracker.cpp:278-362) for this agent ----
     const int nf = d.NF ? d.fx_count[envi()] : 0;
     if (nf > 0) {
@@ -1679,6 +1689,7 @@ struct MgxEnvT {  // per-lane view of one env
         }
       }
     }
+    if (d.cov_in_aoe) track_coverage(ai);  // objects/agent.cpp:49-57; nothing moves after this phase (no game on_tick)
   }
   // One packed record per registered AoE source (mgx_aoe_prep_kernel, one thread per source): see pack_covers.
   __device__ __forceinline__ void aoe_pack_source(int k) const {
@@ -2217,7 +2228,7 @@ __device__ __forceinline__ void mgx_world_body(const MgxDev& d, PP P, uint8_t* o
   if constexpr (X) {
     if (act && d.n_schedule > 0) e.process_events();  // mettagrid_c.cpp:1009-1011
   }
-  if (d.any_on_tick && act) {
+  if (d.any_on_tick && act && !d.tick_in_aoe) {
     for (int i = 0; i < A; i++) {  // per-agent on_tick (mettagrid_c.cpp:1019-1024); slot and class come from LDS
       const int li = i * MGX_WORLD_EPG + lane;
       const int h = e.cls(al.cls[li])[MGX_C_ON_TICK];
@@ -2316,6 +2327,7 @@ void mgx_launch_values(hipStream_t stream, const MgxDev& d, const MgxDev* dev_co
 // lane-per-agent area effects (mgx_aoe.hip) and the host analysis that allows them
 void mgx_launch_aoe(hipStream_t stream, const MgxDev& d, const MgxDev* dev_copy);
 bool mgx_aoe_is_target_local(const int32_t* program);
+bool mgx_aoe_on_tick_local(const int32_t* program);  // + every per-agent on_tick handler is a leaf that only touches its own agent
 
 #ifndef MGX_WORLD_FAST_TU
 // Construction: MettaGrid ctor + _init_grid (mettagrid_c.cpp:42-191, 200-269).  One lane per env scans the class

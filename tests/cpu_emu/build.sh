@@ -17,6 +17,6 @@ $CXX $FLAGS -DMGX_SLOT=1 -c $C/mgx_world_fast.hip -o $OBJ/fast1.o &
 $CXX $FLAGS -c $C/mgx_world_x.hip -o $OBJ/x.o &
 $CXX $FLAGS -c $C/mgx_aoe.hip -o $OBJ/aoe.o &
 $CXX $FLAGS -c $HERE/emu_globals.cpp -o $OBJ/globals.o &
-wait
+for job in $(jobs -p); do wait $job || { echo "compile failed"; exit 1; }; done
 $CXX $SAN -shared -o $HERE/libmgx_emu.so $OBJ/*.o
 echo "built $HERE/libmgx_emu.so"
