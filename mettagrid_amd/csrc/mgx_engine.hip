@@ -161,6 +161,10 @@ struct mgx_engine {
   MgxDev* d_dev = nullptr;     // copy of `d` in device memory for the kernels that take it by pointer (extended path)
   MgxDev d_dev_host{};         // what d_dev holds
   bool d_dev_valid = false;
+  MgxDev* d_hot = nullptr;     // the extended world kernel's copy: sec[] of the hot program range relative to its LDS copy
+  MgxDev d_hot_host{};
+  bool d_hot_valid = false;
+  int hot_lo = 0, hot_hi = 0;  // [hot_lo, hot_hi): program words of that range
   int device = 0;
   hipStream_t stream = nullptr;
   std::vector<void*> allocs;
@@ -316,6 +320,20 @@ static const MgxDev* dev_copy(mgx_engine* e) {
     e->d_dev_valid = true;
   }
   return e->d_dev;
+}
+// ... and the extended world kernel's variant of it when that kernel keeps the hot program range in LDS.
+static const MgxDev* dev_copy_world_x(mgx_engine* e) {
+  if (!e->prog_in_lds) return dev_copy(e);
+  MgxDev h = e->d;
+  h.hot_lo = e->hot_lo;
+  for (int k = 0; k < MGX_SEC_COUNT; k++)
+    if (h.sec[k] >= e->hot_lo && h.sec[k] <= e->hot_hi && k != MGX_SEC_TAG_LISTS && k != MGX_SEC_SCHEDULE && k != MGX_SEC_CLASSES) h.sec[k] -= e->hot_lo;
+  if (!e->d_hot_valid || memcmp(&e->d_hot_host, &h, sizeof(MgxDev)) != 0) {
+    (void)hipMemcpyAsync(e->d_hot, &h, sizeof(MgxDev), hipMemcpyHostToDevice, e->stream);
+    memcpy(&e->d_hot_host, &h, sizeof(MgxDev));
+    e->d_hot_valid = true;
+  }
+  return e->d_hot;
 }
 static int launch_terr(mgx_engine* e) {  // refresh the ownership maps of the envs whose territory sources changed
   if (e->d.X && e->d.NT > 0 && e->d.terr_owner) {
@@ -539,6 +557,7 @@ int mgx_create(const int32_t* program, size_t program_words, const uint16_t* cla
     A_(e->alloc(&d.qvis, E * (d.QD + 1) * d.SW));
   }
   A_(e->alloc(&e->d_dev, 1));
+  A_(e->alloc(&e->d_hot, 1));
   A_(e->alloc(&dmaps, E * HW));
   A_(e->alloc(&dseeds, E));
   A_(e->alloc(&e->dmask, E));
@@ -560,6 +579,12 @@ int mgx_create(const int32_t* program, size_t program_words, const uint16_t* cla
   // the episode length — into LDS when it leaves room for 4 (lean) / 3 (extended) workgroups per CU (160 KB LDS).
   // (Rung 4, measured: the copy at 2 workgroups per CU is slower than the program in HBM at 3: 9.8 against 8.4 ms.)
   e->prog_lds_words = (int)((d.sec[MGX_SEC_SCHEDULE] + 3) & ~3);
+  if (d.X) {  // extended kernel: only the sections the handler VM walks (LIMITS .. TERR_CONTROLS); the class table — one
+              // record per agent — and the tag-list index are read from HBM / L2 (mgx_world.h MGX_HOT_PROG)
+    e->hot_lo = d.sec[MGX_SEC_LIMITS] & ~3;
+    e->hot_hi = d.sec[MGX_SEC_TAG_LISTS];
+    e->prog_lds_words = ((e->hot_hi - e->hot_lo) + 3) & ~3;
+  }
   e->prog_in_lds = (size_t)e->prog_lds_words * 4 + e->lds_world <= (size_t)(d.X ? 53 : 40) * 1024;
   if (const char* o = getenv("MGX_PROG_LDS")) e->prog_in_lds = e->prog_in_lds && atoi(o) != 0;
 #ifdef MGX_CPU_EMU
@@ -1059,7 +1084,7 @@ int mgx_step(mgx_engine* e) {
       else mgx_launch_world_fast_s1(e->prog_in_lds, e->lds_world, e->stream, e->d, pw);
       MGX_MARK(1); MGX_MARK(2); MGX_MARK(3);
     } else if (e->aoe_local && (d.NF > 0 || d.NM > 0 || d.NT > 0)) {
-      mgx_launch_world_x(e->prog_in_lds, e->lds_world, e->stream, e->d, dev_copy(e), pw, MGX_PH_ACTIONS);
+      mgx_launch_world_x(e->prog_in_lds, e->lds_world, e->stream, e->d, dev_copy_world_x(e), pw, MGX_PH_ACTIONS);
       MGX_TRACE_POINT(e, "world kernel (actions)");
       MGX_MARK(1);
       int trc = launch_terr(e);  // the per-agent territory effects read the ownership map
@@ -1067,10 +1092,10 @@ int mgx_step(mgx_engine* e) {
       mgx_launch_aoe(e->stream, e->d, dev_copy(e));
       MGX_TRACE_POINT(e, "aoe kernel");
       MGX_MARK(2);
-      if (!d.cov_in_aoe) mgx_launch_world_x(e->prog_in_lds, e->lds_world, e->stream, e->d, dev_copy(e), pw, MGX_PH_TAIL);
+      if (!d.cov_in_aoe) mgx_launch_world_x(e->prog_in_lds, e->lds_world, e->stream, e->d, dev_copy_world_x(e), pw, MGX_PH_TAIL);
       MGX_MARK(3);
     } else {
-      mgx_launch_world_x(e->prog_in_lds, e->lds_world, e->stream, e->d, dev_copy(e), pw, MGX_PH_ALL);
+      mgx_launch_world_x(e->prog_in_lds, e->lds_world, e->stream, e->d, dev_copy_world_x(e), pw, MGX_PH_ALL);
       MGX_MARK(1); MGX_MARK(2); MGX_MARK(3);
     }
     MGX_TRACE_POINT(e, "world kernel");

@@ -113,7 +113,11 @@ __device__ __forceinline__ int mgx_world_lane() {  // index of this lane's env i
 #ifndef MGX_OUTLINE
 #define MGX_OUTLINE
 #endif
+#ifdef MGX_NO_CLS_STAGE  // extended kernel: the agents' classes are not staged (only the serial on_tick loop reads them)
+__host__ __device__ inline int mgx_world_alds_bytes(int A) { return A * MGX_WORLD_EPG * (2 + 2 + 2 + 4 + 4); }
+#else
 __host__ __device__ inline int mgx_world_alds_bytes(int A) { return A * MGX_WORLD_EPG * (2 + 2 + 2 + 2 + 4 + 4); }
+#endif
 // byte offset of the extended variant's per-lane scratch (deferred deltas | territory scores | VM words) in the LDS
 __host__ __device__ inline int mgx_world_xlds_off(int A) { return ((A * MGX_WORLD_EPG + 15) & ~15) + ((mgx_world_alds_bytes(A) + 15) & ~15); }
 // Dynamic LDS of the world kernels: order u8[A][64] | swm u32[A][64] | act i16[2][A][64] | slot, rc, prev, cls u16[A][64] |
@@ -135,7 +139,11 @@ __device__ __forceinline__ MgxALds mgx_world_alds(uint8_t* lds, int A, int lane)
   al.slot = (uint16_t*)(lds + off + A * MGX_WORLD_EPG * 8);
   al.rc = al.slot + A * MGX_WORLD_EPG;
   al.prev = al.rc + A * MGX_WORLD_EPG;
+#ifdef MGX_NO_CLS_STAGE
+  al.cls = nullptr;
+#else
   al.cls = al.prev + A * MGX_WORLD_EPG;
+#endif
   return al;
 }
 
@@ -200,13 +208,22 @@ struct MgxEnvT {  // per-lane view of one env
   __device__ __forceinline__ PP prog() const { return P_; }
   __device__ __forceinline__ const MgxALds& AL() const { return al_; }
 #endif
-  __device__ __forceinline__ PP cls(int c) const { return prog() + d.sec[MGX_SEC_CLASSES] + c * MGX_C_WORDS; }
+  // Class records: with MGX_HOT_PROG (extended world kernel) the LDS program copy holds only the sections the handler VM
+  // walks (limits .. territory controls); the class table (one record per agent: 15 KB at 64 agents) and the tag-list
+  // index stay in HBM / L2 and are read through the global pointer.
+#ifdef MGX_HOT_PROG
+  typedef MgxGlobalProg CP;
+  __device__ __forceinline__ CP cls(int c) const { return d.P + d.sec[MGX_SEC_CLASSES] + c * MGX_C_WORDS; }
+#else
+  typedef PP CP;
+  __device__ __forceinline__ CP cls(int c) const { return prog() + d.sec[MGX_SEC_CLASSES] + c * MGX_C_WORDS; }
+#endif
 
   __device__ __forceinline__ size_t so(int slot) const { return (size_t)envi() * d.S + slot; }
   __device__ __forceinline__ size_t ao(int agent) const { return (size_t)envi() * d.A + agent; }
   __device__ __forceinline__ uint16_t& inv(int slot, int item) const { return d.obj_inv[so(slot) * MGX_INV_PITCH + item]; }
   __device__ __forceinline__ int inv_of(int slot, int item) const { return slot >= 0 ? (int)inv(slot, item) : 0; }
-  __device__ __forceinline__ PP cls_of(int slot) const { return cls(d.obj_cls[so(slot)]); }
+  __device__ __forceinline__ CP cls_of(int slot) const { return cls(d.obj_cls[so(slot)]); }
   __device__ __forceinline__ int agent_of(int slot) const {
     if (slot < 0) return -1;
     int a = d.obj_agent[so(slot)];
@@ -291,7 +308,7 @@ struct MgxEnvT {  // per-lane view of one env
   }
   __device__ __forceinline__ int effective_limit(int slot, PP L) const { return effective_limit(inv_row(slot), L); }
   __device__ __forceinline__ int group_amount(int slot, PP L) const { return group_amount(inv_row(slot), L); }
-  __device__ __forceinline__ PP limit_of(PP C, int item) const {
+  __device__ __forceinline__ PP limit_of(CP C, int item) const {
     int li = C[MGX_C_RES_LIMIT + item];
     return li < 0 ? (PP) nullptr : prog() + d.sec[MGX_SEC_LIMITS] + li * MGX_L_WORDS;
   }
@@ -322,7 +339,7 @@ struct MgxEnvT {  // per-lane view of one env
     const InvRow row = inv_row(slot);
     unsigned long long ord = d.obj_order[so(slot)];
     const uint8_t ag = d.obj_agent[so(slot)];
-    PP C = cls(cls_id);
+    CP C = cls(cls_id);
     int initial = row.get(item);
     int new_amount = initial + delta;
     int mx = 65535;
@@ -358,7 +375,7 @@ struct MgxEnvT {  // per-lane view of one env
     return dl;
   }
   template <int DEPTH>
-  __device__ MGX_BIG void enforce_all_limits(int slot, PP C) const {  // inventory.cpp:141-173
+  __device__ MGX_BIG void enforce_all_limits(int slot, CP C) const {  // inventory.cpp:141-173
     for (int li = 0; li < C[MGX_C_LIMIT_COUNT]; li++) {
       PP L = prog() + d.sec[MGX_SEC_LIMITS] + (C[MGX_C_LIMIT_START] + li) * MGX_L_WORDS;
       if (L[MGX_L_DROP_COUNT] == 0) continue;
@@ -409,7 +426,11 @@ struct MgxEnvT {  // per-lane view of one env
     if constexpr (X) { if (d.obj_tags) return (d.obj_tags[so(slot) * MGX_TAG_WORDS + (t >> 5)] >> (t & 31)) & 1u; }
     return ((uint32_t)cls_of(slot)[MGX_C_TAGS + (t >> 5)] >> (t & 31)) & 1u;
   }
+#ifdef MGX_HOT_PROG
+  __device__ __forceinline__ int tag_list(int tag) const { return d.P[d.sec[MGX_SEC_TAG_LISTS] + tag]; }
+#else
   __device__ __forceinline__ int tag_list(int tag) const { return prog()[d.sec[MGX_SEC_TAG_LISTS] + tag]; }
+#endif
   __device__ __forceinline__ uint16_t* tl_items(int li) const { return d.tl_items + ((size_t)envi() * d.NL + li) * d.S; }
   __device__ __forceinline__ uint16_t& tl_count(int li) const { return d.tl_count[(size_t)envi() * d.NL + li]; }
   // GridObject::add_tag / remove_tag without the lifecycle handlers (core/grid_object.cpp:93-123): bitset + TagIndex.
@@ -437,7 +458,7 @@ struct MgxEnvT {  // per-lane view of one env
   }
   // first on_tag_add / on_tag_remove record of object o's class for `tag` at or after record j, or -1
   __device__ __forceinline__ int next_tag_handler(int o, int tag, int start_field, int j, int* handler) const {
-    PP C = cls_of(o);
+    CP C = cls_of(o);
     PP th = prog() + d.sec[MGX_SEC_TAG_HANDLERS] + C[start_field] * MGX_TH_WORDS;
     const int n = C[start_field + 1];
     for (; j < n; j++)
@@ -773,7 +794,7 @@ struct MgxEnvT {  // per-lane view of one env
   // ---- objects created / removed at run time ----
   __device__ int spawn_object(int cls_id, int r, int c) const {  // create_object_from_config + Grid::add_object + TagIndex
     if constexpr (!X) { flag(4u); return -1; } else {
-      PP C = cls(cls_id);
+      CP C = cls(cls_id);
       if (C[MGX_C_KIND] == MGX_KIND_AGENT) { flag(64u); return -1; }
       uint32_t n = d.num_objs[envi()];
       if ((int)n >= d.S) { flag(8u); return -1; }
@@ -801,7 +822,7 @@ struct MgxEnvT {  // per-lane view of one env
     }
   }
   __device__ void register_aoes(int slot) const {  // AOETracker::register_source :128-134 (flush_deferred :154-159)
-    PP C = cls_of(slot);
+    CP C = cls_of(slot);
     for (int i = 0; i < C[MGX_C_AOE_COUNT]; i++) {
       int a = C[MGX_C_AOE_START] + i;
       if (aoe(a)[MGX_AO_STATIC]) {
@@ -2141,7 +2162,8 @@ __device__ __forceinline__ void mgx_world_body(const MgxDev& d, PP P, uint8_t* o
       int i = i0 + q;
       if (i < A) {
         int li = i * MGX_WORLD_EPG + lane;
-        al.slot[li] = slot8[q]; al.rc[li] = rc8[q]; al.prev[li] = prev8[q]; al.swm[li] = swm8[q]; al.cls[li] = cls8[q];
+        al.slot[li] = slot8[q]; al.rc[li] = rc8[q]; al.prev[li] = prev8[q]; al.swm[li] = swm8[q];
+        if (al.cls) al.cls[li] = cls8[q];
         al.act[li] = mgx_sat16(a8[q]); al.act[A * MGX_WORLD_EPG + li] = mgx_sat16(v8[q]);
         if (want_stepprev && act) d.ag_stepprev[e.ao(i)] = rc8[q];  // mettagrid_c.cpp:929-931
         order[li] = (uint8_t)i;
@@ -2231,9 +2253,9 @@ __device__ __forceinline__ void mgx_world_body(const MgxDev& d, PP P, uint8_t* o
   if (d.any_on_tick && act && !d.tick_in_aoe) {
     for (int i = 0; i < A; i++) {  // per-agent on_tick (mettagrid_c.cpp:1019-1024); slot and class come from LDS
       const int li = i * MGX_WORLD_EPG + lane;
-      const int h = e.cls(al.cls[li])[MGX_C_ON_TICK];
+      const int slot = al.slot[li];
+      const int h = (al.cls ? e.cls(al.cls[li]) : e.cls_of(slot))[MGX_C_ON_TICK];
       if (h >= 0) {
-        const int slot = al.slot[li];
         MgxCtx c = mgx_ctx(slot, slot);
         e.apply_top(h, c);
       }
@@ -2294,7 +2316,7 @@ __device__ __forceinline__ void mgx_world_entry(const MgxDev& d, int prog_words,
   }
   if (PROG_LDS) {
     int32_t* lprog = (int32_t*)(mgx_dyn_lds + off);
-    const int4* src = (const int4*)d.P;
+    const int4* src = (const int4*)(d.P + d.hot_lo);  // (hot_lo: 0, or the first word of the hot range: MGX_HOT_PROG)
     int4* dst = (int4*)lprog;
     for (int i = threadIdx.x; i < prog_words / 4; i += blockDim.x) dst[i] = src[i];
     __syncthreads();

@@ -11,6 +11,8 @@
 #define MGX_WORLD_FAST_TU 1
 #define MGX_TU_NS mgx_tu_x
 #define MGX_WORLD_IDS 1
+#define MGX_HOT_PROG 1      // the LDS program copy is the hot range only; class records from HBM / L2 (mgx_world.h)
+#define MGX_NO_CLS_STAGE 1  // 14 instead of 16 bytes of LDS per agent and env
 // One 32-env wavefront per workgroup: with many agents per env the LDS staging (17 B per agent and env + 320 B per env)
 // is what limits how many envs a CU holds; small workgroups pack it better (rung 4: 45 KB per workgroup).
 #ifndef MGX_WORLD_LPW
@@ -109,3 +111,12 @@ void mgx_launch_world_x(bool prog_lds, size_t lds, hipStream_t stream, const Mgx
   if (prog_lds) hipLaunchKernelGGL((mgx_world_kernel_x<true>), grid, block, lds, stream, dp, prog_words, phases);
   else hipLaunchKernelGGL((mgx_world_kernel_x<false>), grid, block, lds, stream, dp, prog_words, phases);
 }
+
+#ifdef MGX_WORLD_TIMING  // instrumented developer build only (scripts/world_timing_x.py); not part of the ABI
+extern "C" int mgx_debug_world_x_cycles(unsigned long long* out, int reset) {
+  hipDeviceSynchronize();
+  hipMemcpyFromSymbol(out, HIP_SYMBOL(mgx_tu_x::mgx_dbg_cycles), sizeof(unsigned long long) * 16);
+  if (reset) { unsigned long long z[16] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(mgx_tu_x::mgx_dbg_cycles), z, sizeof z); }
+  return 0;
+}
+#endif
