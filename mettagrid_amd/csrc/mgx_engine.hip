@@ -663,8 +663,17 @@ int mgx_create(const int32_t* program, size_t program_words, const uint16_t* cla
         const int at = rwr[k * MGX_RW_WORDS + MGX_RW_GV_START] + i;
         if (at >= 0 && at < n_code) reward_only[at] = 1;
       }
+    // ... and then only when it reads one of the counters the deferred pass writes: the per-kind success / failed
+    // counters, action.failed and max_steps_without_motion (a game that counts zone entries in an agent stat and adds
+    // to it from a territory handler does not care when `action.move.success` is brought up to date)
+    auto booked = [&](int id) {
+      for (int k : {MGX_S_NOOP_SUCCESS, MGX_S_MOVE_SUCCESS, MGX_S_VIBE_SUCCESS})
+        if (id == d.wk[k] || id == d.wk[k + 1]) return true;
+      return id == d.wk[MGX_S_ACTION_FAILED] || id == d.wk[MGX_S_MAX_STEPS_WITHOUT_MOTION];
+    };
     for (int i = 0; i < n_code; i++)
-      if (!reward_only[i] && code[i * MGX_GV_WORDS + MGX_GV_OP] == MGX_GOP_STAT && code[i * MGX_GV_WORDS + MGX_GV_A0] != 1)
+      if (!reward_only[i] && code[i * MGX_GV_WORDS + MGX_GV_OP] == MGX_GOP_STAT && code[i * MGX_GV_WORDS + MGX_GV_A0] != 1 &&
+          booked(code[i * MGX_GV_WORDS + MGX_GV_A1]))
         reads_agent_stats = true;
     d.defer_book = reads_agent_stats ? 0 : 1;  // (flushed at the end of the launch that runs the action phase)
   }
