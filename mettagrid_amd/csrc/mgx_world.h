@@ -2414,10 +2414,11 @@ __global__ void __launch_bounds__(MGX_WAVE) mgx_init_kernel(const MgxDev* __rest
     if (d.X) {
       if (d.obj_tags)
         for (int w = 0; w < MGX_TAG_WORDS; w++) d.obj_tags[e.so(slot) * MGX_TAG_WORDS + w] = (uint32_t)C[MGX_C_TAGS + w];
-      for (int t = 0; t < 256 && d.NL > 0; t++) {  // TagIndex::register_object (core/tag_index.cpp:9-19)
-        if (!(((uint32_t)C[MGX_C_TAGS + (t >> 5)] >> (t & 31)) & 1u)) continue;
-        int li = e.tag_list(t);
-        if (li >= 0) { uint16_t n = e.tl_count(li); e.tl_items(li)[n] = (uint16_t)slot; e.tl_count(li) = n + 1; }
+      for (int w = 0; w < MGX_TAG_WORDS && d.NL > 0; w++) {  // TagIndex::register_object (core/tag_index.cpp:9-19), ascending tag id
+        for (uint32_t bits = (uint32_t)C[MGX_C_TAGS + w]; bits; bits &= bits - 1) {
+          int li = e.tag_list(w * 32 + __ffs(bits) - 1);
+          if (li >= 0) { uint16_t n = e.tl_count(li); e.tl_items(li)[n] = (uint16_t)slot; e.tl_count(li) = n + 1; }
+        }
       }
       for (int i = 0; i < C[MGX_C_AOE_COUNT]; i++) {  // AOETracker::register_source (mettagrid_c.cpp:249-252)
         int a = C[MGX_C_AOE_START] + i;
@@ -2569,10 +2570,11 @@ __global__ void __launch_bounds__(MGX_WAVE) mgx_init_wave_kernel(const MgxDev* _
       for (int slot = 0; slot < nobj; slot++) {   // registrations in object order
         const int32_t* C = mgx_cls(d, d.obj_cls[e.so(slot)]);
         const uint16_t rc = d.obj_rc[e.so(slot)];
-        for (int t = 0; t < 256 && d.NL > 0; t++) {  // TagIndex::register_object (core/tag_index.cpp:9-19)
-          if (!(((uint32_t)C[MGX_C_TAGS + (t >> 5)] >> (t & 31)) & 1u)) continue;
-          int li = e.tag_list(t);
-          if (li >= 0) { uint16_t n = e.tl_count(li); e.tl_items(li)[n] = (uint16_t)slot; e.tl_count(li) = n + 1; }
+        for (int w = 0; w < MGX_TAG_WORDS && d.NL > 0; w++) {  // TagIndex::register_object (core/tag_index.cpp:9-19)
+          for (uint32_t bits = (uint32_t)C[MGX_C_TAGS + w]; bits; bits &= bits - 1) {
+            int li = e.tag_list(w * 32 + __ffs(bits) - 1);
+            if (li >= 0) { uint16_t n = e.tl_count(li); e.tl_items(li)[n] = (uint16_t)slot; e.tl_count(li) = n + 1; }
+          }
         }
         for (int i = 0; i < C[MGX_C_AOE_COUNT]; i++) {  // AOETracker::register_source (mettagrid_c.cpp:249-252)
           int a = C[MGX_C_AOE_START] + i;
