@@ -271,15 +271,19 @@ struct mgx_engine {
 
 // Dynamic LDS of the observation kernel for the current pool capacity (mgx_create; mgx_reset_envs when new maps need
 // a larger pool).
+#ifndef MGX_OBS_EW512
+#define MGX_OBS_EW512 4  // encode wavefronts of the 512-thread observation workgroups
+#endif
 static int size_obs_lds(mgx_engine* e) {
   const MgxDev& d = e->d;
   const int xmode = mgx_obs_xmode(d.X != 0, d.X && d.aoe_mask_feat != 0 && d.NT > 0, d.S, e->num_tags);
-  // extended games with many agents per env: 512 threads (8 wavefronts share the env's LDS image; rung 4: 2 x 8 instead
-  // of 3 x 4 wavefronts per CU)
+  // extended games with many agents per env: 512 threads, of which four wavefronts encode (16 staging rows: the env's LDS
+  // image stays at 52.8 KB; rung 4: 3 x 8 wavefronts per CU instead of 3 x 4, and 2 x 8 with 32 staging rows.  Measured:
+  // 7.25 / 5.2 / 4.3 ms; 1 024 threads 8.6 ms; the lean kernel with 512 threads 1.14 instead of 0.67 ms)
   e->obs_threads = (d.X && d.A >= 48 && !getenv("MGX_OBS_256")) ? 512 : MGX_OBS_THREADS;
   e->lds_obs = (size_t)mgx_obs_lds_layout(d.H * d.W, d.NOFF, d.S, d.A, d.T, e->pool_tokens, xmode, d.n_obs_values,
                                           e->obs_blk_lds ? e->obs_blk_words : 0, mgx_obs_gt(d.n_obs_values, d.base),
-                                          e->rewards_early, e->obs_threads / MGX_WAVE).total;
+                                          e->rewards_early, e->obs_threads == 512 ? MGX_OBS_EW512 : e->obs_threads / MGX_WAVE).total;
   if (e->lds_obs > 160 * 1024)
     return fail(MGX_ERR_PROGRAM, "map/object count too large for the LDS staging of the observation kernel");
   if (e->verbose || getenv("MGX_VERBOSE"))
@@ -294,23 +298,23 @@ static int size_obs_lds(mgx_engine* e) {
     const void* fns[] = {(const void*)mgx_obs_kernel<true, false, false>, (const void*)mgx_obs_kernel<false, false, false>,
                          (const void*)mgx_obs_kernel<true, false, true>,  (const void*)mgx_obs_kernel<false, false, true>,
                          (const void*)mgx_obs_kernel<true, true, false>,  (const void*)mgx_obs_kernel<false, true, false>,
-                         (const void*)mgx_obs_kernel<true, true, false, 512>, (const void*)mgx_obs_kernel<false, true, false, 512>};
+                         (const void*)mgx_obs_kernel<true, true, false, 512, MGX_OBS_EW512>, (const void*)mgx_obs_kernel<false, true, false, 512, MGX_OBS_EW512>};
     for (const void* f : fns) HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_obs));
     cur_max = e->lds_obs;
   }
   return MGX_OK;
 }
 
-template <bool X, bool PL, int NTH = MGX_OBS_THREADS>
+template <bool X, bool PL, int NTH = MGX_OBS_THREADS, int EW = NTH / MGX_WAVE>
 static void launch_obs_t(mgx_engine* e, bool with_rewards, const uint8_t* mask) {
   dim3 grid(e->d.E), block(NTH);
   MgxDev dd = e->d;
   if (PL)  // the interpreted sections are addressed relative to their LDS copy
     for (int k = MGX_SEC_INV_FEATURES; k < MGX_SEC_WORDLIST; k++) dd.sec[k] -= e->obs_blk_start;
   if (with_rewards)
-    hipLaunchKernelGGL((mgx_obs_kernel<true, X, PL, NTH>), grid, block, e->lds_obs, e->stream, dd, e->pool_tokens, e->pool_prefix, mask, e->obs_blk_start, e->obs_blk_words, (int)e->rewards_early);
+    hipLaunchKernelGGL((mgx_obs_kernel<true, X, PL, NTH, EW>), grid, block, e->lds_obs, e->stream, dd, e->pool_tokens, e->pool_prefix, mask, e->obs_blk_start, e->obs_blk_words, (int)e->rewards_early);
   else
-    hipLaunchKernelGGL((mgx_obs_kernel<false, X, PL, NTH>), grid, block, e->lds_obs, e->stream, dd, e->pool_tokens, e->pool_prefix, mask, e->obs_blk_start, e->obs_blk_words, (int)e->rewards_early);
+    hipLaunchKernelGGL((mgx_obs_kernel<false, X, PL, NTH, EW>), grid, block, e->lds_obs, e->stream, dd, e->pool_tokens, e->pool_prefix, mask, e->obs_blk_start, e->obs_blk_words, (int)e->rewards_early);
 }
 // Device-memory copy of e->d, brought up to date (stream-ordered) whenever the host table changed.
 static const MgxDev* dev_copy(mgx_engine* e) {
@@ -353,7 +357,7 @@ static int launch_obs(mgx_engine* e, bool with_rewards, const uint8_t* mask = nu
   if (e->d.obsval) mgx_launch_values(e->stream, e->d, dev_copy(e), 0, mask);
   MGX_TRACE_POINT(e, "values kernel");
   if (e->rewards_ext) with_rewards = false;
-  if (e->d.X && e->obs_threads == 512) launch_obs_t<true, false, 512>(e, with_rewards, mask);
+  if (e->d.X && e->obs_threads == 512) launch_obs_t<true, false, 512, MGX_OBS_EW512>(e, with_rewards, mask);
   else if (e->d.X) launch_obs_t<true, false>(e, with_rewards, mask);
   else if (e->obs_blk_lds) launch_obs_t<false, true>(e, with_rewards, mask);
   else launch_obs_t<false, false>(e, with_rewards, mask);

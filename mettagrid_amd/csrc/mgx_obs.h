@@ -188,7 +188,8 @@ __device__ __forceinline__ uint32_t mgx_wave_sum(uint32_t x) {
 // pool_prefix: the first pool_prefix pool entries are the per-class static tag tokens (a copy of MgxDev::cls_tok), which
 // is all a static object (walls ...) ever shows; only the other objects get a per-step list behind them.
 // NTH: threads per workgroup — 256, or 512 for envs with many agents (more wavefronts over the same per-env LDS).
-template <bool WITH_REWARDS, bool X, bool PL, int NTH = MGX_OBS_THREADS>
+// EW: wavefronts that take part in the encode (each owns four staging rows in LDS); the others wait at the barrier behind it.
+template <bool WITH_REWARDS, bool X, bool PL, int NTH = MGX_OBS_THREADS, int EW = NTH / MGX_WAVE>
 __global__ void __launch_bounds__(NTH) mgx_obs_kernel(MgxDev d, int pool_tokens, int pool_prefix, const uint8_t* env_mask,
                                                                   int blk_start, int blk_words, int rewards_early) {
   MGX_KERNARG_ENTRY(d);
@@ -203,7 +204,7 @@ __global__ void __launch_bounds__(NTH) mgx_obs_kernel(MgxDev d, int pool_tokens,
   const int xmode = mgx_obs_xmode(X, want_mask, S, d.P[MGX_H_NUM_TAGS]);
   const bool pack_mask = (xmode & MGX_OX_PACK) != 0, owner8 = (xmode & MGX_OX_OWNER8) != 0;
   const MgxObsLds L = mgx_obs_lds_layout(HW, NOFF, S, A, T, pool_tokens, xmode, d.n_obs_values, PL ? blk_words : 0, GT,
-                                         rewards_early != 0, NTH / MGX_WAVE);
+                                         rewards_early != 0, EW);
   const int CP = L.cp;
   uint16_t* s_grid = (uint16_t*)(smem + L.grid);
   char2* s_offs = (char2*)(smem + L.offs);
@@ -658,7 +659,7 @@ __global__ void __launch_bounds__(NTH) mgx_obs_kernel(MgxDev d, int pool_tokens,
   // ---- phase 2: encode.  One agent per 16-lane DPP row, four agents per wavefront at a time: an agent sees ~15-20
   // occupied cells, so a whole wavefront per agent left three quarters of the lanes idle.  Scans are row scans (four
   // DPP steps), row-wide values travel by ds_bpermute, long token lists are copied by the 16 lanes of their row. ----
-  for (int a0 = wave * 4; a0 < A; a0 += (NTH / MGX_WAVE) * 4) {
+  for (int a0 = wave < EW ? wave * 4 : A; a0 < A; a0 += EW * 4) {
     const int a = a0 + row;
     const bool av = a < A;          // this row has an agent
     const int ac = av ? a : A - 1;  // clamped for the unconditional reads
