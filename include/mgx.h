@@ -61,6 +61,14 @@ int mgx_sync(mgx_engine* e);
 /* The engine's hipStream_t (as void*) so callers can order their own work / record events on it. */
 void* mgx_stream(mgx_engine* e);
 
+/* The action decoding of MettaGridPufferEnv.step (python/src/mettagrid/envs/mettagrid_puffer_env.py:331-381) for one joint
+ * discrete id per agent, on the device: id < num_primary is a primary action (no vibe action); otherwise
+ * off = id - num_primary, primary = off / num_vibe, vibe action = vibe_ids[off % num_vibe].  Writes the engine's bound
+ * action buffers (device buffers only), ordered on the engine's stream.  No range checks (the reference's raise
+ * ValueError on the host): ids outside [0, num_primary * (num_vibe + 1)) become invalid action indices of the step.
+ * joint: int32 [E*A] device memory; vibe_ids: int32 [num_vibe] host memory (action index of each vibe action). */
+int mgx_set_joint_actions(mgx_engine* e, const int32_t* joint, int32_t num_primary, const int32_t* vibe_ids, int32_t num_vibe);
+
 /* Two env groups on one GPU (two engines, each on its own stream): from now on every mgx_step of `e` holds its
  * world-update kernels back until the world-update kernels of `after`'s most recent mgx_step have finished; its
  * observation kernel is not held back.  Chained both ways (a after b, b after a) and stepped alternately, the latency-bound

@@ -210,6 +210,9 @@ struct mgx_engine {
   bool verbose = false;
   bool rewards_early = false;  // reward expressions have no stat operands: evaluated beside the token-cache phase
   int slot = 0;                // constant-memory slot of the lean world kernel (mgx_world_fast.hip, MGX_SLOT)
+  int32_t* d_vibe_ids = nullptr;  // mgx_set_joint_actions: action index of each vibe action
+  int32_t vibe_ids_host[256] = {};
+  int n_vibe_ids = 0;
   bool aoe_local = false;      // area effects only touch their target: one lane per agent (mgx_aoe_kernel)
   bool rewards_ext = false;    // reward expressions have query operands: evaluated by mgx_values_kernel after the obs kernel
   uint16_t* dmaps = nullptr;
@@ -1344,6 +1347,42 @@ int mgx_state_digests(mgx_engine* e, uint64_t* out) {
   hipLaunchKernelGGL(mgx_digest_kernel, dim3((unsigned)e->d.E), dim3(MGX_WAVE), 0, e->stream, dev_copy(e), e->d_digest);
   HIP_TRY(hipGetLastError());
   return d2h(e, out, e->d_digest, (size_t)e->d.E * 8);
+}
+
+// joint action id -> (primary, vibe) action indices (mettagrid_puffer_env.py:331-381), one thread per agent row
+__global__ void __launch_bounds__(256) mgx_joint_actions_kernel(const int32_t* __restrict__ joint, int32_t* __restrict__ actions,
+                                                                int32_t* __restrict__ vibe_actions, const int32_t* __restrict__ vibe_ids,
+                                                                long long rows, int num_primary, int num_vibe) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= rows) return;
+  const int a = joint[i];
+  int core = a, vibe = 0;
+  if (num_vibe > 0 && a >= num_primary) {
+    const int off = a - num_primary;
+    core = off / num_vibe;
+    vibe = vibe_ids[off % num_vibe];
+  }
+  actions[i] = core;
+  vibe_actions[i] = vibe;
+}
+
+int mgx_set_joint_actions(mgx_engine* e, const int32_t* joint, int32_t num_primary, const int32_t* vibe_ids, int32_t num_vibe) {
+  if (!e || !joint || num_primary <= 0 || num_vibe < 0 || num_vibe > 256 || (num_vibe > 0 && !vibe_ids))
+    return fail(MGX_ERR_BAD_ARG, "mgx_set_joint_actions: bad argument");
+  if (e->mem_kind != MGX_MEM_DEVICE) return fail(MGX_ERR_BAD_ARG, "mgx_set_joint_actions: needs device buffers");
+  HIP_TRY(hipSetDevice(e->device));
+  const MgxDev& d = e->d;
+  if (!e->d_vibe_ids) { int rc = e->alloc(&e->d_vibe_ids, 256); if (rc) return rc; }
+  if (num_vibe > 0 && (e->n_vibe_ids != num_vibe || memcmp(e->vibe_ids_host, vibe_ids, (size_t)num_vibe * 4) != 0)) {
+    memcpy(e->vibe_ids_host, vibe_ids, (size_t)num_vibe * 4);
+    e->n_vibe_ids = num_vibe;
+    HIP_TRY(hipMemcpyAsync(e->d_vibe_ids, e->vibe_ids_host, (size_t)num_vibe * 4, hipMemcpyHostToDevice, e->stream));
+  }
+  const long long rows = (long long)d.E * d.A;
+  hipLaunchKernelGGL(mgx_joint_actions_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, e->stream, joint, (int32_t*)d.actions, (int32_t*)d.vibe_actions,
+                     (const int32_t*)e->d_vibe_ids, rows, num_primary, num_vibe);
+  HIP_TRY(hipGetLastError());
+  return MGX_OK;
 }
 
 int mgx_decode_obs(mgx_engine* e, const uint8_t* tokens, int64_t n_rows, float* box, int32_t num_features, const float* scale) {

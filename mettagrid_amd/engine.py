@@ -59,6 +59,7 @@ def load_lib():
     L.mgx_stream.argtypes = [vp]
     L.mgx_stream.restype = vp
     L.mgx_chain_world.argtypes = [vp, vp]
+    L.mgx_set_joint_actions.argtypes = [vp, vp, i32, vp, i32]
     L.mgx_get_buffers.argtypes = [vp] + [C.POINTER(vp)] * 6 + [C.POINTER(i32)]
     L.mgx_get_episode_rewards.argtypes = [vp, vp]
     L.mgx_get_action_success.argtypes = [vp, vp]
@@ -189,6 +190,13 @@ class BatchedMettaGrid:
 
     def sync(self) -> None:
         _check(self.L.mgx_sync(self.h))
+
+    def set_joint_actions(self, joint, num_primary: int, vibe_ids) -> None:
+        """One joint discrete id per agent -> the engine's primary / vibe action buffers, decoded on the device on the
+        engine's stream (mgx.h mgx_set_joint_actions; MettaGridPufferEnv.step's decoding without its range checks).
+        ``joint``: contiguous int32 CUDA tensor [E*A]; call ``wait_for_caller()`` first if it was written on another stream."""
+        ids = np.ascontiguousarray(np.asarray(vibe_ids, dtype=np.int32))
+        _check(self.L.mgx_set_joint_actions(self.h, joint.data_ptr(), int(num_primary), ids.ctypes.data if ids.size else None, int(ids.size)))
 
     def chain_world_after(self, other: "BatchedMettaGrid | None") -> None:
         """From now on this engine's world-update kernels start only when ``other``'s most recent ones have finished

@@ -228,6 +228,7 @@ class MettaGridBatchedEnv:
             self._eng = BatchedMettaGrid(self.prog, self._maps(range(self.E)), self._seeds(), device=self._device,
                                          buffers=self._kind)
         ids = [self.prog.action_names.index(n) for n in self.vibe_action_names]
+        self._vibe_ids_host = np.asarray(ids, dtype=np.int32)
         if self._kind == "device":
             import torch
             self._vibe_ids = torch.tensor(ids, dtype=torch.int64, device=self._eng.obs.device)
@@ -262,18 +263,25 @@ class MettaGridBatchedEnv:
         if self._kind == "device":
             import torch
             a = actions if isinstance(actions, torch.Tensor) else torch.as_tensor(np.asarray(actions), device=eng.obs.device)
-            if self.validate_actions:
-                core, vibe = decode_actions(a, len(self.action_names), self._vibe_ids, xp=torch)
+            if not self.validate_actions and a.ndim == 1 and a.dtype == torch.int32 and a.is_contiguous():
+                # one kernel on the engine's stream instead of a dozen elementwise torch kernels
+                if tuple(a.shape) != tuple(eng.actions.shape):
+                    raise ValueError(f"Expected {tuple(eng.actions.shape)} actions, got {tuple(a.shape)}")
+                eng.wait_for_caller()
+                eng.set_joint_actions(a, len(self.action_names), self._vibe_ids_host)
             else:
-                core, vibe = decode_actions_unchecked(a, len(self.action_names), self._vibe_ids)
-            if tuple(core.shape) != tuple(eng.actions.shape):
-                raise ValueError(f"Expected {tuple(eng.actions.shape)} core actions, got {tuple(core.shape)}")
-            eng.actions.copy_(core.to(torch.int32))
-            if vibe is not None:
-                eng.vibe_actions.copy_(vibe.to(torch.int32))
-            else:
-                eng.vibe_actions.zero_()
-            eng.wait_for_caller()   # the engine's kernels read the actions written on the caller's stream ...
+                if self.validate_actions:
+                    core, vibe = decode_actions(a, len(self.action_names), self._vibe_ids, xp=torch)
+                else:
+                    core, vibe = decode_actions_unchecked(a, len(self.action_names), self._vibe_ids)
+                if tuple(core.shape) != tuple(eng.actions.shape):
+                    raise ValueError(f"Expected {tuple(eng.actions.shape)} core actions, got {tuple(core.shape)}")
+                eng.actions.copy_(core.to(torch.int32))
+                if vibe is not None:
+                    eng.vibe_actions.copy_(vibe.to(torch.int32))
+                else:
+                    eng.vibe_actions.zero_()
+                eng.wait_for_caller()   # the engine's kernels read the actions written on the caller's stream ...
             eng.step()
             eng.caller_waits()      # ... and whatever the caller enqueues next sees this step's results
             if self.supervisor is not None:

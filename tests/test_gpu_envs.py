@@ -273,3 +273,36 @@ def test_pettingzoo_surface_and_supervisor_hook():
     assert benv.engine.vibe_actions.tolist() == [vibe_ids[i % V] for i in range(benv.num_agents)]
     benv.disable_supervisor()
     benv.close()
+
+
+def test_joint_action_decode_on_device_matches_host_rules():
+    """mgx_set_joint_actions == decode_actions (the reference's MettaGridPufferEnv.step rules) for every joint id, and the
+    env wrapper's unchecked device path gives the same episode as the validating one."""
+    import torch
+    from mettagrid_amd import presets
+    from mettagrid_amd.compiler import compile_spec
+    from mettagrid_amd.envs import MettaGridBatchedEnv, decode_actions
+    from mettagrid_amd.mapgen import random_class_maps
+    prog = compile_spec(presets.rung3_spec(), 32, 32, max_objects=192)
+    pool = random_class_maps(prog, 32, 32, {"wall": 40, "extractor": 8, "chest": 4}, {"red": 8, "blue": 8}, range(4))
+    E = 6
+    envs = [MettaGridBatchedEnv(prog, E, map_pool=pool, validate_actions=v, seed=5) for v in (False, True)]
+    for env in envs:
+        env.reset()
+    n = envs[0].transport_action_n
+    rng = np.random.RandomState(0)
+    eng = envs[0].engine
+    joint = torch.arange(eng.actions.numel(), dtype=torch.int32, device="cuda") % n     # every joint id at least once
+    eng.set_joint_actions(joint, len(envs[0].action_names), envs[0]._vibe_ids_host)
+    eng.sync()
+    core, vibe = decode_actions(joint.cpu().numpy(), len(envs[0].action_names), np.asarray(envs[0]._vibe_ids_host, np.int64), xp=np)
+    assert np.array_equal(eng.actions.cpu().numpy(), core.astype(np.int32))
+    assert np.array_equal(eng.vibe_actions.cpu().numpy(), np.zeros_like(core, np.int32) if vibe is None else vibe.astype(np.int32))
+    for t in range(30):
+        a = torch.from_numpy(rng.randint(0, n, envs[0].num_agents).astype(np.int32)).cuda()
+        outs = [env.step(a) for env in envs]
+        torch.cuda.synchronize()
+        for x, y in zip(outs[0][:4], outs[1][:4]):
+            assert torch.equal(x, y), t
+    for env in envs:
+        env.close()
