@@ -3,10 +3,13 @@
 // (/root/reference/python/src/mettagrid/envs/grid_obs_wrapper.py:57-95): value / scale[feature] ADDED into cell
 // (feature, y, x), tokens in row order, global tokens (location 0xFE) on the centre cell, padding (0xFF) skipped.
 //
-// One wavefront per agent row, four rows per workgroup.  The row's box is assembled in LDS and streamed out with
-// 16-byte stores (the box is 26x the token bytes: the kernel is a pure HBM-write stream, 4 * C * H * W bytes per row).
-// Bit-exact sums: tokens whose cell nobody else targets (almost all) are written by their own lane; the few cells several
-// tokens share (tag tokens of one object) are accumulated by one lane in token order, like np.add.at.
+// One wavefront per agent row, four rows per workgroup.  The kernel is an HBM write stream (4 * C * H * W bytes per row,
+// 26x the token bytes), so nothing of the box is staged: the row is zero-filled with 16-byte stores straight to HBM and the
+// <= T token values are stored over it (same wavefront, program order).  LDS holds only the row's tokens and two bitmaps
+// over the cells ("seen", "hit more than once"): 1.6 KB per row instead of the 15.5 KB box, so the CU is full of
+// wavefronts that do nothing but store.
+// Bit-exact sums: a cell that a single token targets gets that token's value (0 + v == v); the few cells several tokens
+// share (tag tokens of one object) are summed by the first of their tokens, in token order, like np.add.at.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -24,13 +27,13 @@ __global__ void __launch_bounds__(MGX_DEC_WAVES* MGX_DEC_WAVE) mgx_decode_kernel
   const int wave = (int)threadIdx.x / MGX_DEC_WAVE, lane = (int)threadIdx.x & (MGX_DEC_WAVE - 1);
   const long long row = (long long)blockIdx.x * MGX_DEC_WAVES + wave;
   if (row >= rows) return;
-  const int cells = C * H * W, cells4 = (cells + 3) & ~3;
+  const int cells = C * H * W, bmw = (cells + 31) / 32;
   const int tok_words = (3 * T + 3) / 4, tok_pad = (tok_words + 3) & ~3;
-  uint8_t* mine = dec_lds + (size_t)wave * ((size_t)cells4 * 4 + (size_t)tok_pad * 4);
-  float* sbox = (float*)mine;
-  uint32_t* cnt = (uint32_t*)mine;                  // the same cells as integer token counts during the first pass
-  uint8_t* stok = mine + (size_t)cells4 * 4;
-  // ---- stage the token row, zero the box ----
+  uint8_t* mine = dec_lds + (size_t)wave * ((size_t)tok_pad * 4 + (size_t)bmw * 8);
+  uint8_t* stok = mine;
+  uint32_t* seen = (uint32_t*)(mine + (size_t)tok_pad * 4);
+  uint32_t* dup = seen + bmw;
+  // ---- stage the token row, clear the bitmaps, zero-fill the row of the box in HBM ----
   {
     const uint8_t* src = tokens + row * (long long)T * 3;
     if ((((uintptr_t)src) & 3) == 0) {
@@ -44,9 +47,15 @@ __global__ void __launch_bounds__(MGX_DEC_WAVES* MGX_DEC_WAVE) mgx_decode_kernel
     } else {
       for (int b = lane; b < 3 * T; b += MGX_DEC_WAVE) stok[b] = src[b];
     }
-    for (int i = lane; i < cells4 / 4; i += MGX_DEC_WAVE) ((uint4*)sbox)[i] = make_uint4(0u, 0u, 0u, 0u);
+    for (int i = lane; i < 2 * bmw; i += MGX_DEC_WAVE) seen[i] = 0u;
   }
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  float* dst = box + row * (long long)cells;
+  if ((cells & 3) == 0 && (((uintptr_t)dst) & 15) == 0) {
+    for (int i = lane; i < cells / 4; i += MGX_DEC_WAVE) ((uint4*)dst)[i] = make_uint4(0u, 0u, 0u, 0u);
+  } else {
+    for (int i = lane; i < cells; i += MGX_DEC_WAVE) dst[i] = 0.f;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // one wavefront per row: LDS operations complete in issue order; no need to wait for the zero-fill stores
   const int cy = H / 2, cx = W / 2;
   auto key_of = [&](int t) -> int {   // cell index of token t, or -1 (padding / outside the box)
     if (t >= T) return -1;
@@ -56,67 +65,37 @@ __global__ void __launch_bounds__(MGX_DEC_WAVES* MGX_DEC_WAVE) mgx_decode_kernel
     if (y >= H || x >= W || (int)fid >= C) return -1;
     return ((int)fid * H + y) * W + x;
   };
-  const int passes = (T + MGX_DEC_WAVE - 1) / MGX_DEC_WAVE;
-  const bool fits = passes <= 8;   // per-lane token multiplicities live in registers: up to 512 tokens per row
-  uint32_t mult[8];
-#pragma unroll
-  for (int p = 0; p < 8; p++) mult[p] = 0;
-  if (fits) {
-    // ---- pass 1: how many tokens target each cell (the box doubles as the counters) ----
-    for (int t = lane; t < T; t += MGX_DEC_WAVE) {
-      const int k = key_of(t);
-      if (k >= 0) atomicAdd(&cnt[k], 1u);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-    // ---- pass 2: every lane notes the multiplicity of its own tokens' cells, then the box is zeroed again ----
-#pragma unroll
-    for (int p = 0; p < 8; p++) {
-      const int k = key_of(p * MGX_DEC_WAVE + lane);
-      mult[p] = k >= 0 ? cnt[k] : 0u;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-    for (int i = lane; i < cells4 / 4; i += MGX_DEC_WAVE) ((uint4*)sbox)[i] = make_uint4(0u, 0u, 0u, 0u);
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-  }
-  // ---- pass 3: values.  Unshared cells by their own lane; shared cells by lane 0, tokens in row order. ----
-  if (fits) {
-#pragma unroll
-    for (int p = 0; p < 8; p++) {
-      if (p >= passes) break;
-      const int t = p * MGX_DEC_WAVE + lane;
-      const int k = key_of(t);
-      float v = 0.f;
-      if (k >= 0) v = __fdiv_rn((float)stok[3 * t + 2], scale[stok[3 * t + 1]]);
-      if (k >= 0 && mult[p] == 1u) sbox[k] = v;   // 0 + v == v
-      unsigned long long shared = __ballot(k >= 0 && mult[p] > 1u);
-      while (shared) {
-        const int src = __ffsll((long long)shared) - 1;
-        shared &= shared - 1;
-        const int sk = __shfl(k, src);
-        const float sv = __shfl(v, src);
-        if (lane == 0) sbox[sk] = __fadd_rn(sbox[sk], sv);
-      }
-    }
-  } else if (lane == 0) {
-    for (int t = 0; t < T; t++) {
-      const int k = key_of(t);
-      if (k >= 0) sbox[k] = __fadd_rn(sbox[k], __fdiv_rn((float)stok[3 * t + 2], scale[stok[3 * t + 1]]));
+  auto value_of = [&](int t) -> float { return __fdiv_rn((float)stok[3 * t + 2], scale[stok[3 * t + 1]]); };
+  // ---- pass 1: which cells are targeted, which of them more than once ----
+  for (int t = lane; t < T; t += MGX_DEC_WAVE) {
+    const int k = key_of(t);
+    if (k >= 0) {
+      const uint32_t bit = 1u << (k & 31);
+      if (atomicOr(&seen[k >> 5], bit) & bit) atomicOr(&dup[k >> 5], bit);
     }
   }
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-  // ---- stream the box out ----
-  float* dst = box + row * (long long)cells;
-  if ((cells & 3) == 0 && (((uintptr_t)dst) & 15) == 0) {
-    for (int i = lane; i < cells / 4; i += MGX_DEC_WAVE) ((uint4*)dst)[i] = ((const uint4*)sbox)[i];
-  } else {
-    for (int i = lane; i < cells; i += MGX_DEC_WAVE) dst[i] = sbox[i];
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // one wavefront per row: LDS operations complete in issue order; no need to wait for the zero-fill stores
+  // ---- pass 2: values over the zeros.  A cell with one token: that token's lane.  A shared cell: the lane of its first
+  // token adds the later ones in token order. ----
+  for (int t = lane; t < T; t += MGX_DEC_WAVE) {
+    const int k = key_of(t);
+    if (k < 0) continue;
+    float v = value_of(t);
+    if ((dup[k >> 5] >> (k & 31)) & 1u) {
+      bool first = true;
+      for (int u = 0; u < t && first; u++) first = key_of(u) != k;
+      if (!first) continue;
+      for (int u = t + 1; u < T; u++)
+        if (key_of(u) == k) v = __fadd_rn(v, value_of(u));
+    }
+    dst[k] = v;
   }
 }
 
 size_t mgx_decode_lds_bytes(int T, int C, int H, int W) {
-  const int cells4 = (C * H * W + 3) & ~3;
+  const int bmw = (C * H * W + 31) / 32;
   const int tok_pad = (((3 * T + 3) / 4) + 3) & ~3;
-  return (size_t)MGX_DEC_WAVES * ((size_t)cells4 * 4 + (size_t)tok_pad * 4);
+  return (size_t)MGX_DEC_WAVES * ((size_t)tok_pad * 4 + (size_t)bmw * 8);
 }
 
 int mgx_launch_decode(hipStream_t stream, const uint8_t* tokens, float* box, const float* scale_dev, long long rows, int T, int C, int H,
