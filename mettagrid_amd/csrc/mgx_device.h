@@ -32,6 +32,7 @@ struct MgxDev {
   int max_steps, truncates, max_priority, nact, flags, hp_res, n_obs_values, n_move_handlers, any_on_tick;
   int tick_in_aoe;        // 1: mgx_aoe_kernel runs the per-agent on_tick handlers (one lane per agent) in front of the area effects
   int cov_in_aoe;         // 1: ... and the coverage tracking behind them (no tail launch)
+  int flat_top;           // 1: top-level handlers of the action phase run on the register VM (MgxEnvT::apply_top)
   int hot_lo;             // first program word of the LDS copy (extended world kernel: sections LIMITS .. TERR_CONTROLS; their
                           // sec[] entries are relative to it in that kernel's copy of this table)
   int x_aoe_lds;          // 1: the extended world kernel runs the AoE phase itself and keeps its scratch in LDS

@@ -684,6 +684,59 @@ int mgx_create(const int32_t* program, size_t program_words, const uint16_t* cla
         reads_agent_stats = true;
     d.defer_book = reads_agent_stats ? 0 : 1;  // (flushed at the end of the launch that runs the action phase)
   }
+  if (d.X) {  // can the action phase's top-level handlers run on the register VM?  (mgx_world.h apply_top)
+    bool flat = !getenv("MGX_NO_FLAT_TOP");
+    const int n_atoms = mgx_sec_cnt(P, MGX_SEC_ATOMS);
+    std::vector<char> hseen(mgx_sec_cnt(P, MGX_SEC_HANDLERS), 0);
+    std::vector<int> todo;
+    auto push = [&](int h) { if (h >= 0 && h < (int)hseen.size() && !hseen[h]) { hseen[h] = 1; todo.push_back(h); } };
+    const int32_t* mh = P + d.sec[MGX_SEC_MOVE_HANDLERS];
+    for (int k = 0; k < d.n_move_handlers; k++) push(mh[k * MGX_MH_WORDS + MGX_MH_HANDLER]);
+    for (int c = 0; c < P[MGX_H_NUM_CLASSES]; c++) {
+      const int32_t* C = P + d.sec[MGX_SEC_CLASSES] + c * MGX_C_WORDS;
+      push(C[MGX_C_ON_USE]); push(C[MGX_C_ON_AFTER_USE]); push(C[MGX_C_ON_TICK]);
+    }
+    push(d.game_on_tick);
+    while (!todo.empty() && flat) {
+      const int32_t* hd = P + d.sec[MGX_SEC_HANDLERS] + todo.back() * MGX_HD_WORDS;
+      todo.pop_back();
+      if (hd[MGX_HD_KIND] != MGX_HK_LEAF) {
+        const int32_t* kids = P + d.sec[MGX_SEC_CHILDREN] + hd[MGX_HD_CHILD_START];
+        for (int i = 0; i < hd[MGX_HD_CHILD_COUNT]; i++) push(kids[i]);
+        continue;
+      }
+      for (int i = 0; i < hd[MGX_HD_MUT_COUNT] && flat; i++) {
+        switch (P[d.sec[MGX_SEC_MUTS] + (hd[MGX_HD_MUT_START] + i) * MGX_MU_WORDS + MGX_MU_OP]) {
+          case MGX_MOP_RESOURCE_DELTA: case MGX_MOP_RESOURCE_TRANSFER: case MGX_MOP_CLEAR_INVENTORY: case MGX_MOP_ATTACK: case MGX_MOP_STATS:
+          case MGX_MOP_CHANGE_VIBE: case MGX_MOP_RELOCATE: case MGX_MOP_SWAP: case MGX_MOP_USE_TARGET: case MGX_MOP_GAME_VALUE: break;
+          default: flat = false;   // tag mutations (lifecycle handlers), query recomputation, push / spawn / query inventory
+        }
+      }
+      std::vector<int> pcs{hd[MGX_HD_FILTER_PC]};   // filters: no atom that evaluates a query (check_filters<0>)
+      std::vector<char> aseen(n_atoms, 0);
+      while (!pcs.empty() && flat) {
+        const int pc = pcs.back();
+        pcs.pop_back();
+        if (pc < 0 || pc >= n_atoms || aseen[pc]) continue;
+        aseen[pc] = 1;
+        const int32_t* a = P + d.sec[MGX_SEC_ATOMS] + pc * MGX_AT_WORDS;
+        if (a[MGX_AT_OP] == MGX_FOP_QUERY_RESOURCE || (a[MGX_AT_OP] == MGX_FOP_MAX_DISTANCE && a[MGX_AT_A2] >= 0)) flat = false;
+        if (a[MGX_AT_OP] == MGX_FOP_GAME_VALUE)
+          for (int rec : {a[MGX_AT_A1], a[MGX_AT_A2]})
+            if (rec >= 0) {
+              const int32_t* V = P + d.sec[MGX_SEC_OBS_VALUES] + rec * MGX_OV_WORDS;
+              for (int q = 0; q < V[MGX_OV_GV_COUNT]; q++) {
+                const int op = P[d.sec[MGX_SEC_GV_CODE] + (V[MGX_OV_GV_START] + q) * MGX_GV_WORDS + MGX_GV_OP];
+                if (op == MGX_GOP_QUERY_INVENTORY || op == MGX_GOP_QUERY_COUNT) flat = false;
+              }
+            }
+        pcs.push_back(a[MGX_AT_ON_TRUE]);
+        pcs.push_back(a[MGX_AT_ON_FALSE]);
+      }
+    }
+    d.flat_top = flat ? 1 : 0;
+    if (getenv("MGX_VERBOSE")) fprintf(stderr, "[mgx] action-phase handlers on the %s VM\n", flat ? "register" : "LDS");
+  }
   {  // reward code made only of inventory / constant arithmetic reads nothing the observation kernel writes
     bool pure = !d.X;
     const int32_t* rw = P + d.sec[MGX_SEC_REWARDS];

@@ -1361,9 +1361,16 @@ struct MgxEnvT {  // per-lane view of one env
     return rv;
   }
   // apply a top-level handler: register VM in the lean variant, LDS VM in the extended one
+  // (extended variant: programs whose move / on_use / on_after_use / on_tick / game on_tick handlers contain no tag
+  // mutation, no query recomputation and no query filter — flat_top, decided by the host — never need the LDS VM for
+  // them: the register VM of the lean variant runs them, frames and contexts in registers)
   __device__ __forceinline__ bool apply_top(int h, MgxCtx& c) const {
-    if constexpr (X) return vm_run(h, 0, 0, 0, c);
-    else return run_handler(h, c);
+    if constexpr (X) {
+      if (d.flat_top) return run_handler(h, c);
+      return vm_run(h, 0, 0, 0, c);
+    } else {
+      return run_handler(h, c);
+    }
   }
 
   // Filters + every mutation, no stop on mutation_failed (events, AoE sources, territory handlers).
