@@ -38,7 +38,7 @@ def workload(rung: int):
         spec, H, W, S = presets.rung4_spec(), 64, 64, presets.RUNG4_MAX_OBJECTS
         objs, agents, mapf = dict(presets.RUNG4_OBJECTS), dict(presets.RUNG4_AGENTS), presets.rung4_map
         desc = ("rung4: 65536 envs/GPU x 64x64 random map x 64 agents (4 teams), rung-3 rules + 16 static AoE + mobile "
-                "AoE per agent + territory (8 sources) + aoe_mask obs + 3 events + materialized closure query, T=200")
+                "AoE per agent + territory (8 sources) + aoe_mask obs + 3 events + materialized closure query, T=256")
         A, T = 64, spec.obs.num_tokens
         R, n_rw, n_dyn = len(spec.resource_names), 3, sum(v for k, v in objs.items() if k != "wall")
         s_agent = 4 + 1 + 32 + 2 * R + R + 16 + 4 * n_rw             # SURVEY.md §8d S_agent

@@ -181,7 +181,7 @@ struct mgx_engine {
   int32_t *h_act = nullptr, *h_vact = nullptr;
   bool external = false;
   size_t lds_world = 0, lds_obs = 0;
-  int obs_threads = MGX_OBS_THREADS;
+  int obs_threads = MGX_OBS_THREADS, obs_ew = MGX_OBS_THREADS / MGX_WAVE;
   int pool_tokens = 0;   // capacity of the LDS token pool (entries), including the class-tag prefix
   int pool_prefix = 0;   // entries of the per-class static tag table at the head of the pool
   bool prog_in_lds = false;
@@ -274,19 +274,27 @@ struct mgx_engine {
 
 // Dynamic LDS of the observation kernel for the current pool capacity (mgx_create; mgx_reset_envs when new maps need
 // a larger pool).
-#ifndef MGX_OBS_EW512
-#define MGX_OBS_EW512 4  // encode wavefronts of the 512-thread observation workgroups
-#endif
 static int size_obs_lds(mgx_engine* e) {
   const MgxDev& d = e->d;
   const int xmode = mgx_obs_xmode(d.X != 0, d.X && d.aoe_mask_feat != 0 && d.NT > 0, d.S, e->num_tags);
-  // extended games with many agents per env: 512 threads, of which four wavefronts encode (16 staging rows: the env's LDS
-  // image stays at 52.8 KB; rung 4: 3 x 8 wavefronts per CU instead of 3 x 4, and 2 x 8 with 32 staging rows.  Measured:
-  // 7.25 / 5.2 / 4.3 ms; 1 024 threads 8.6 ms; the lean kernel with 512 threads 1.14 instead of 0.67 ms)
+  // extended games with many agents per env: 512 threads, of which EW wavefronts encode (4 staging rows each).  Fewer
+  // encode wavefronts = fewer rows in LDS: the largest EW of 4, 3, 2 that lets three workgroups share a CU's 160 KB is
+  // taken (rung 4, T = 200: EW 4, 52.8 KB, 4.3 ms; all eight wavefronts encoding: 66.6 KB, two workgroups, 5.2 ms;
+  // T = 256: EW 3, 52.6 KB, 4.8 ms against 6.1 ms for EW 4 at two workgroups; 1 024 threads 8.6 ms; 256 threads 7.25 ms;
+  // the lean kernel with 512 threads 1.14 instead of 0.67 ms)
   e->obs_threads = (d.X && d.A >= 48 && !getenv("MGX_OBS_256")) ? 512 : MGX_OBS_THREADS;
-  e->lds_obs = (size_t)mgx_obs_lds_layout(d.H * d.W, d.NOFF, d.S, d.A, d.T, e->pool_tokens, xmode, d.n_obs_values,
-                                          e->obs_blk_lds ? e->obs_blk_words : 0, mgx_obs_gt(d.n_obs_values, d.base),
-                                          e->rewards_early, e->obs_threads == 512 ? MGX_OBS_EW512 : e->obs_threads / MGX_WAVE).total;
+  e->obs_ew = e->obs_threads / MGX_WAVE;
+  auto lds_for = [&](int ew) {
+    return (size_t)mgx_obs_lds_layout(d.H * d.W, d.NOFF, d.S, d.A, d.T, e->pool_tokens, xmode, d.n_obs_values,
+                                      e->obs_blk_lds ? e->obs_blk_words : 0, mgx_obs_gt(d.n_obs_values, d.base),
+                                      e->rewards_early, ew).total;
+  };
+  if (e->obs_threads == 512) {
+    e->obs_ew = 4;
+    for (int ew : {4, 3, 2})
+      if (lds_for(ew) <= 53760) { e->obs_ew = ew; break; }
+  }
+  e->lds_obs = lds_for(e->obs_ew);
   if (e->lds_obs > 160 * 1024)
     return fail(MGX_ERR_PROGRAM, "map/object count too large for the LDS staging of the observation kernel");
   if (e->verbose || getenv("MGX_VERBOSE"))
@@ -301,7 +309,9 @@ static int size_obs_lds(mgx_engine* e) {
     const void* fns[] = {(const void*)mgx_obs_kernel<true, false, false>, (const void*)mgx_obs_kernel<false, false, false>,
                          (const void*)mgx_obs_kernel<true, false, true>,  (const void*)mgx_obs_kernel<false, false, true>,
                          (const void*)mgx_obs_kernel<true, true, false>,  (const void*)mgx_obs_kernel<false, true, false>,
-                         (const void*)mgx_obs_kernel<true, true, false, 512, MGX_OBS_EW512>, (const void*)mgx_obs_kernel<false, true, false, 512, MGX_OBS_EW512>};
+                         (const void*)mgx_obs_kernel<true, true, false, 512, 4>, (const void*)mgx_obs_kernel<false, true, false, 512, 4>,
+                         (const void*)mgx_obs_kernel<true, true, false, 512, 3>, (const void*)mgx_obs_kernel<false, true, false, 512, 3>,
+                         (const void*)mgx_obs_kernel<true, true, false, 512, 2>, (const void*)mgx_obs_kernel<false, true, false, 512, 2>};
     for (const void* f : fns) HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_obs));
     cur_max = e->lds_obs;
   }
@@ -360,7 +370,9 @@ static int launch_obs(mgx_engine* e, bool with_rewards, const uint8_t* mask = nu
   if (e->d.obsval) mgx_launch_values(e->stream, e->d, dev_copy(e), 0, mask);
   MGX_TRACE_POINT(e, "values kernel");
   if (e->rewards_ext) with_rewards = false;
-  if (e->d.X && e->obs_threads == 512) launch_obs_t<true, false, 512, MGX_OBS_EW512>(e, with_rewards, mask);
+  if (e->d.X && e->obs_threads == 512 && e->obs_ew == 4) launch_obs_t<true, false, 512, 4>(e, with_rewards, mask);
+  else if (e->d.X && e->obs_threads == 512 && e->obs_ew == 3) launch_obs_t<true, false, 512, 3>(e, with_rewards, mask);
+  else if (e->d.X && e->obs_threads == 512) launch_obs_t<true, false, 512, 2>(e, with_rewards, mask);
   else if (e->d.X) launch_obs_t<true, false>(e, with_rewards, mask);
   else if (e->obs_blk_lds) launch_obs_t<false, true>(e, with_rewards, mask);
   else launch_obs_t<false, false>(e, with_rewards, mask);

@@ -128,7 +128,7 @@ RUNG4_AGENTS = {t: 16 for t in RUNG4_TEAMS}
 RUNG4_MAX_OBJECTS = 576   # 252 border walls + 246 placed objects + 64 agents = 562, rounded up
 
 
-def rung4_spec(obs_tokens: int = 200, max_steps: int = 0) -> S.GameSpec:
+def rung4_spec(obs_tokens: int = 256, max_steps: int = 0) -> S.GameSpec:
     """Rung 4 = BASELINE.json configs[3]: the rung-3 rules on 64x64 maps with 64 agents in 4 teams,
     plus 16 static AoE sources (r=3, same-team filter, hp +2, presence shield +1), a mobile AoE on every agent
     (r=1, enemies lose 1 hp), one territory type over the team tags with 8 sources (strength 5, decay 1; presence
