@@ -136,6 +136,10 @@ __global__ void __launch_bounds__(MGX_WAVE) mgx_digest_kernel(const MgxDev* __re
     float tot = 0.f;
     for (int k = 0; k < nrw; k++) tot = __fadd_rn(tot, d.ag_rprev[e.ao(a) * d.NRW + k]);
     h = mgx_fnv(h, __float_as_uint(tot));
+    for (int q = 0; q < MGX_INVALID_EXTRA; q++) {   // "action.invalid_index.<k>" keys beyond the stat columns (mgx.h)
+      const float nq = d.ag_invn[e.ao(a) * MGX_INVALID_EXTRA + q];
+      if (nq != 0.f) { h = mgx_fnv(h, (uint32_t)d.ag_invk[e.ao(a) * MGX_INVALID_EXTRA + q]); h = mgx_fnv(h, __float_as_uint(nq)); }
+    }
   }
   out[env] = h;
 }

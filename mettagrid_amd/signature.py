@@ -91,7 +91,8 @@ def _fnv(h: int, w: int) -> int:
     return ((h ^ (int(w) & 0xFFFFFFFF)) * _FNV_PRIME) & _M64
 
 
-def state_digest(raw_objects: np.ndarray, raw_stats, episode_rewards, action_success, current_stat_reward, step: int) -> int:
+def state_digest(raw_objects: np.ndarray, raw_stats, episode_rewards, action_success, current_stat_reward, step: int,
+                 invalid_extra=None) -> int:
     """The digest mgx_state_digests computes for one env, from the raw dumps every engine offers (the HIP engine through
     mgx_get_objects / mgx_get_stats / ..., the CPU oracle through its mgxo_* twins)."""
     gv, gt, av, at = raw_stats
@@ -110,4 +111,6 @@ def state_digest(raw_objects: np.ndarray, raw_stats, episode_rewards, action_suc
         h = _fnv(h, bits(episode_rewards[a]))
         h = _fnv(h, int(bool(action_success[a])))
         h = _fnv(h, bits(current_stat_reward[a]))
+        for k, n in (invalid_extra[a] if invalid_extra else {}).items():   # invalid_index_extra(): first-seen order
+            h = _fnv(_fnv(h, int(k) & 0xFFFFFFFF), bits(n))
     return h

@@ -49,3 +49,28 @@ def test_digest_equals_host_digest_of_oracle_state(name):
                                snap["action_success"][i * A:(i + 1) * A], eng.current_stat_reward(i), int(eng.current_steps()[i]))
         assert int(dig[i]) == mine
     assert len(set(int(x) for x in dig)) == E   # different maps / seeds -> different states
+
+
+def test_digest_covers_far_invalid_action_indices():
+    """The (k, count) pairs behind "action.invalid_index.<k>" for indices far outside the action table are part of the state."""
+    spec_f, map_f, _, _ = hp.SCENARIOS["rung1"]
+    spec, cells = spec_f(), map_f(0)
+    prog = hp.compile_scenario("rung1", spec, *cells.shape)
+    cm = prog.class_map(cells)[None]
+    eng = BatchedMettaGrid(prog, cm, [3], buffers="host")
+    ora = op.OracleSim(prog, cm[0], 3)
+    ora.reinit_buffers()
+    A = prog.num_agents
+    before = int(eng.state_digests()[0])
+    for a, v in ((1000, 0), (-500, 0), (1000, 2 ** 31 - 1)):
+        eng.actions[:] = a
+        eng.vibe_actions[:] = v
+        eng.step()
+        ora.step(np.full(A, a, np.int32), np.full(A, v, np.int32))
+    s = ora.snapshot()
+    want = sg.state_digest(ora.raw_objects(), ora.raw_stats(), s["episode_rewards"], s["action_success"], ora.current_stat_reward(),
+                           ora.current_step, invalid_extra=ora.invalid_index_extra())
+    plain = sg.state_digest(ora.raw_objects(), ora.raw_stats(), s["episode_rewards"], s["action_success"], ora.current_stat_reward(),
+                            ora.current_step)
+    got = int(eng.state_digests()[0])
+    assert got == want and got != plain and got != before
