@@ -19,7 +19,7 @@ from mettagrid_amd.mapgen import random_class_maps
 pytestmark = pytest.mark.gpu
 
 
-def _run_and_check(E, sample, steps, seed0=0, rung=3, actions=None):
+def _run_and_check(E, sample, steps, seed0=0, rung=3, actions=None, obs_tokens=None):
     import torch
     if rung == 3:
         spec = presets.rung3_spec()
@@ -27,7 +27,7 @@ def _run_and_check(E, sample, steps, seed0=0, rung=3, actions=None):
         cms = random_class_maps(prog, 32, 32, {"wall": 40, "extractor": 8, "chest": 4}, {"red": 8, "blue": 8},
                                 range(seed0, seed0 + E))
     else:
-        spec = presets.rung4_spec()
+        spec = presets.rung4_spec() if obs_tokens is None else presets.rung4_spec(obs_tokens=obs_tokens)
         prog = compile_spec(spec, 64, 64, max_objects=presets.RUNG4_MAX_OBJECTS)
         cms = random_class_maps(prog, 64, 64, presets.RUNG4_OBJECTS, presets.RUNG4_AGENTS, range(seed0, seed0 + E))
     A, T = prog.num_agents, prog.num_tokens
@@ -134,3 +134,10 @@ def test_large_rectangular_map():
         for i, o in enumerate(oracles):
             o.step(a[i * A:(i + 1) * A], v[i * A:(i + 1) * A])
     assert eng.poll_errors()[0] == 0
+
+
+@pytest.mark.parametrize("obs_tokens", [200, 400])
+def test_rung4_other_token_budgets(obs_tokens):
+    """The 512-thread observation kernel picks its number of encode wavefronts by what fits in LDS (4 at T = 200, 3 at the
+    preset's 256, 2 at 400): every instantiation against the oracle."""
+    _run_and_check(40, [0, 1, 31, 32, 39], 12, seed0=300, rung=4, obs_tokens=obs_tokens)
