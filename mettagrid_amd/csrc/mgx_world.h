@@ -2179,9 +2179,6 @@ __device__ __forceinline__ void mgx_world_body(const MgxDev& d, PP P, uint8_t* o
   }
   e.al_ = al;
   MGX_TICK(0);
-#if defined(MGX_DBG_STOP) && MGX_DBG_STOP == 1
-  return;
-#endif
   // std::shuffle (bits/stl_algo.h:3729-3795): one draw for an even n, then paired draws.  The generator outputs
   // are produced eight at a time (rng_block): one round trip for the state words of the whole shuffle instead of
   // three dependent ones per draw.  A Lemire rejection (probability < 1e-7) simply consumes one more output.
@@ -2223,9 +2220,6 @@ __device__ __forceinline__ void mgx_world_body(const MgxDev& d, PP P, uint8_t* o
   PP acts = P + d.sec[MGX_SEC_ACTIONS];
   const int repeats = d.max_priority + 1;
   MGX_TICK(1);
-#if defined(MGX_DBG_STOP) && MGX_DBG_STOP == 2
-  return;
-#endif
   for (int stream = 0; stream < (act ? 2 : 0); stream++) {
     for (int k = 0; k < A; k++) {
       int ai = order[k * MGX_WORLD_EPG + lane];
@@ -2250,9 +2244,6 @@ __device__ __forceinline__ void mgx_world_body(const MgxDev& d, PP P, uint8_t* o
       }
     }
     MGX_TICK(2 + stream);
-#if defined(MGX_DBG_STOP) && (MGX_DBG_STOP == 3 || MGX_DBG_STOP == 4)
-    if (stream == MGX_DBG_STOP - 3) return;
-#endif
   }
   if constexpr (X) {
     if (act && d.n_schedule > 0) e.process_events();  // mettagrid_c.cpp:1009-1011
@@ -2288,13 +2279,7 @@ __device__ __forceinline__ void mgx_world_body(const MgxDev& d, PP P, uint8_t* o
     }
   }
   MGX_TICK(4);
-#if defined(MGX_DBG_STOP) && MGX_DBG_STOP == 5
-  return;
-#endif
   if (d.defer_book && act) e.bookkeeping_flush();
-#if defined(MGX_DBG_STOP) && MGX_DBG_STOP == 6
-  return;
-#endif
   if (phases & MGX_PH_TAIL) e.track_coverage_all();
   MGX_TICK(5);
 }
