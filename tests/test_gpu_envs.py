@@ -124,21 +124,27 @@ def test_reset_with_denser_maps_grows_the_token_pool():
     assert eng.poll_errors()[0] == 0 and fresh.poll_errors()[0] == 0
 
 
-def _pool_env_against_oracle(buffers: str, steps: int = 45, check=None):
+def _pool_env_against_oracle(buffers: str, steps: int = 45, check=None, E: int = 5, workload: str = "rung2", max_steps: int = 11):
     """MettaGridBatchedEnv with a device-resident map pool, device-side lazy auto-reset and the EarlyResetHandler desync,
     against per-env oracles that are rebuilt on the host exactly when the reference wrapper would build a new Simulation
     (mettagrid_puffer_env.py:299-302)."""
     import oracle_py as op
-    spec = presets.rung2_spec()
-    spec.max_steps = 11
-    spec.episode_truncates = True
-    E, M, stride = 5, 7, 3
-    prog = compile_spec(spec, 32, 32, max_objects=192)
-    pool = np.stack([prog.class_map(presets.rung2_map(50 + m)) for m in range(M)])
+    M, stride = 7, 3
+    if workload == "rung4":
+        spec = presets.rung4_spec(max_steps=max_steps)
+        prog = compile_spec(spec, 64, 64, max_objects=presets.RUNG4_MAX_OBJECTS)
+        pool = np.stack([prog.class_map(presets.rung4_map(50 + m)) for m in range(M)])
+    else:
+        spec = presets.rung3_spec() if workload == "rung3" else presets.rung2_spec()
+        spec.max_steps = max_steps
+        spec.episode_truncates = True
+        prog = compile_spec(spec, 32, 32, max_objects=192)
+        mapf = presets.rung3_map if workload == "rung3" else presets.rung2_map
+        pool = np.stack([prog.class_map(mapf(50 + m)) for m in range(M)])
     env = MettaGridBatchedEnv(prog, E, map_pool=pool, pool_stride=stride, desync=True, seed=7, buffers=buffers)
     env.reset()
     early = env.early_end_steps()
-    assert (early >= 1).all() and (early <= 11).all() and len(set(early.tolist())) > 1
+    assert (early >= 1).all() and (early <= max_steps).all() and len(set(early.tolist())) > 1
     A = prog.num_agents
     seeds = [(7 + e) & 0xFFFFFFFF for e in range(E)]
     episode = [0] * E
@@ -306,3 +312,28 @@ def test_joint_action_decode_on_device_matches_host_rules():
             assert torch.equal(x, y), t
     for env in envs:
         env.close()
+
+
+def _check_all(env, oracles, episode, early, t, obs, rew, term, trunc):
+    A = env.prog.num_agents
+    obs_h, rew_h, term_h, trunc_h = obs.cpu().numpy(), rew.cpu().numpy(), term.cpu().numpy(), trunc.cpu().numpy()
+    for e, o in enumerate(oracles):
+        s = o.snapshot()
+        sl = slice(e * A, (e + 1) * A)
+        where = f"env {e} episode {episode[e]} step {t}"
+        assert np.array_equal(s["obs"], obs_h[sl]), where
+        assert np.array_equal(s["rewards"], rew_h[sl]), where
+        assert np.array_equal(s["terminals"], term_h[sl]), where
+        assert np.array_equal(s["truncations"] | (episode[e] == 0 and o.current_step >= early[e]), trunc_h[sl]), where
+
+
+def test_auto_reset_many_envs_across_wavefronts():
+    """96 envs of the rung-3 rules with 9-step episodes: a dozen restarts in every step, spread over many workgroups of the
+    wavefront-per-env construction kernel, each compared with a freshly built oracle."""
+    _pool_env_against_oracle("device", steps=40, check=_check_all, E=96, workload="rung3", max_steps=9)
+
+
+def test_auto_reset_extended_game():
+    """The rung-4 preset (64 agents, tag index, AoE / territory sources and a materialized query to register at every
+    construction) with 7-step episodes."""
+    _pool_env_against_oracle("device", steps=24, check=_check_all, E=10, workload="rung4", max_steps=7)
