@@ -7,7 +7,15 @@ One "step" = one tick of all envs (world-update kernel + observation/reward kern
 in HBM before the timed region.  N>1: one process per GPU (torch.distributed / RCCL), envs sharded by index, every
 rank steps its own 65 536 envs (weak scaling); the path has no exchange step so no data-path collective is issued
 unless --gather is given.
-Prints ONE JSON line on rank 0.
+
+Protocol (python/src/mettagrid/perf/harness.py:100-209 of the reference): pre-generated actions, warm-up, then the K timed
+steps as R rounds of K/R steps; the whole region is ONE bracket (barrier + synchronize on both sides, `value` comes
+from it) and the round boundaries are HIP events on the engine's stream, so the per-round mean / sigma / CV cost no host
+synchronisation; CV > 20 % is flagged like benchmarks/perf/perf_benchmark.py:216-218.
+
+The default N=1 run also measures, after the headline and outside its bracket: BASELINE.json configs[3] (rung 4) as the
+object "rung4" (same fields, short run) and the throughput a trainer sees through the PufferEnv-shaped wrapper
+("env_wrapper").  Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
 
@@ -49,6 +57,31 @@ def workload(rung: int):
     return spec, H, W, S, objs, agents, mapf, desc, per
 
 
+# ---- host-side map construction (before the GPU is touched: the workers are forked) ---------------------------------
+def _maps_chunk(job):
+    rung, lo, hi = job
+    from mettagrid_amd.compiler import compile_spec
+    from mettagrid_amd.mapgen import random_class_maps
+    spec, H, W, S, objs, agents, _, _, _ = workload(rung)
+    prog = compile_spec(spec, H, W, max_objects=S)
+    return random_class_maps(prog, H, W, objs, agents, range(lo, hi))
+
+
+def build_maps(rung: int, envs: range, workers: int) -> np.ndarray:
+    """uint16 [E][H][W] class maps of the global envs ``envs`` (map seed = global env index), built by ``workers`` forked
+    processes: the reference's RandomMapBuilder shuffle is one numpy generator per map (64 s on one core for rung 4)."""
+    n = len(envs)
+    workers = max(1, min(workers, n // 256 or 1))
+    if workers == 1:
+        return _maps_chunk((rung, envs.start, envs.stop))
+    import multiprocessing as mp
+    step = (n + workers * 4 - 1) // (workers * 4)
+    jobs = [(rung, lo, min(lo + step, envs.stop)) for lo in range(envs.start, envs.stop, step)]
+    with mp.get_context("fork").Pool(workers) as pool:
+        return np.concatenate(pool.map(_maps_chunk, jobs))
+
+
+# ---- CPU baseline (the reference engine on the host cores; never the measured product) -------------------------------
 def cpu_baseline(spec, prog, steps: int, cells) -> dict:
     """Reference C++ engine (oracle/_ref, kind "reference") or the CPU restatement (kind "port") on ONE env of the same
     workload on one host core — a reported baseline, never the measured product."""
@@ -158,69 +191,35 @@ def _cpu_sim(spec, prog, cells, seed, acts, vibes):
         return "port", step
 
 
-def main() -> None:
-    if len(sys.argv) > 1 and sys.argv[1] == "--cpu-worker":
-        cpu_worker(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), float(sys.argv[5]))
-        return
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--envs", type=int, default=65536, help="envs per GPU")
-    ap.add_argument("--rung", type=int, default=3, help="3 = BASELINE.json configs[2] (the headline metric), 4 = configs[3]")
-    ap.add_argument("--gather", choices=["none", "scalars", "obs"], default="none",
-                    help="optional per-step gather of rewards/terminals/truncations (+obs) to rank 0: grouped RCCL "
-                         "send/recv over xGMI on a side stream, overlapped with the next step (mettagrid_amd/dist.py)")
-    ap.add_argument("--groups", type=int, default=1,
-                    help="env groups per GPU (mettagrid_amd/groups.py): 2 = the world update of one half of the envs runs "
-                         "beside the observation kernel of the other half (measured slower on MI355X: DESIGN.md); "
-                         "1 = one engine, kernels back to back")
-    ap.add_argument("--cpu-steps", type=int, default=0, help="CPU baseline sample (default: about 10 s of one host core)")
-    ap.add_argument("--no-cpu", action="store_true")
-    args = ap.parse_args()
-
-    import torch
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    cpu = None
-    if not args.no_cpu and world == 1:
-        # CPU baseline first: its worker processes are started before this process initialises the GPU.  One core:
-        # about 10 s; then every host core at once, one env per process, about 5 s of stepping each.
-        from mettagrid_amd.compiler import compile_spec as _cs
-        spec_c, H_c, W_c, S_c, _, _, mapf_c, _, _ = workload(args.rung)
-        prog_c = _cs(spec_c, H_c, W_c, max_objects=S_c)
-        cpu_steps = args.cpu_steps or (300000 if args.rung == 3 else 25000)
-        one = cpu_baseline(spec_c, prog_c, cpu_steps, mapf_c(0))
-        host = cpu_baseline_host(args.rung, max(1000, cpu_steps // 2))
-        if host.get("value"):
-            cpu = {"value": host["value"], "unit": "agent-steps/s", "cores": host["cores"], "kind": host["kind"],
-                   "sample": f"{host['cores']} processes (one per host core), 1 env each (map seed = process index) of the "
-                             f"same workload, {max(1000, cpu_steps // 2)} steps each, random actions, started together",
-                   "one_core": one}
-        else:
-            cpu = one
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the step engine has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-
+def cpu_leg(rung: int, cpu_steps: int) -> dict:
+    """One core (about cpu_steps steps), then every host core at once, for one rung."""
     from mettagrid_amd.compiler import compile_spec
-    from mettagrid_amd.dist import GatherToRoot, env_shard, shard_seeds
-    from mettagrid_amd.groups import EnvGroups
-    from mettagrid_amd.mapgen import random_class_maps
-
-    spec, H, W, S, objs, agents, mapf, desc, per = workload(args.rung)
+    spec, H, W, S, _, _, mapf, _, _ = workload(rung)
     prog = compile_spec(spec, H, W, max_objects=S)
-    E, A, T = args.envs, prog.num_agents, prog.num_tokens
-    cms = random_class_maps(prog, H, W, objs, agents, env_shard(rank, world, E))   # map seed = global env index
+    one = cpu_baseline(spec, prog, cpu_steps, mapf(0))
+    host = cpu_baseline_host(rung, max(1000, cpu_steps // 2))
+    if host.get("value"):
+        return {"value": host["value"], "unit": "agent-steps/s", "cores": host["cores"], "kind": host["kind"],
+                "sample": f"{host['cores']} processes (one per host core), 1 env each (map seed = process index) of the "
+                          f"same workload, {max(1000, cpu_steps // 2)} steps each, random actions, started together",
+                "one_core": one}
+    return one
+
+
+# ---- the GPU measurement of one rung ---------------------------------------------------------------------------------
+def measure(rung: int, cms: np.ndarray, *, envs: int, steps: int, warmup: int, rounds: int, groups: int, gather_kind: str,
+            rank: int, local_rank: int, world: int, dist) -> dict:
+    import torch
+    from mettagrid_amd.compiler import compile_spec
+    from mettagrid_amd.dist import GatherToRoot, shard_seeds
+    from mettagrid_amd.groups import EnvGroups
+
+    spec, H, W, S, objs, agents, mapf, desc, per = workload(rung)
+    prog = compile_spec(spec, H, W, max_objects=S)
+    E, A, T = envs, prog.num_agents, prog.num_tokens
     seeds = shard_seeds(rank, world, E)
-    grp = EnvGroups(prog, cms, seeds, device=local_rank, groups=args.groups)
-    del cms
-    G = args.groups
+    grp = EnvGroups(prog, cms, seeds, device=local_rank, groups=groups)
+    G = groups
 
     # pre-generated actions resident in HBM (protocol of python/src/mettagrid/perf/harness.py:32-34)
     n_actions = len(prog.action_names)
@@ -233,8 +232,11 @@ def main() -> None:
     torch.cuda.synchronize()
 
     gather = None
-    if world > 1 and args.gather != "none":
-        gather = GatherToRoot(dist, root=0, device=torch.device("cuda", local_rank), producer_stream=ext)
+    if world > 1 and gather_kind != "none":
+        # the step that next writes the gathered buffers is ordered behind the staging copy: only its observation kernel
+        # waits (mgx_wait_before_outputs), the world update runs beside the copy
+        gather = GatherToRoot(dist, root=0, device=torch.device("cuda", local_rank), producer_stream=ext,
+                              output_fence=grp.wait_before_outputs)
 
     def one_step(t: int, only=None) -> None:
         for g, eng in enumerate(grp.engines):
@@ -252,28 +254,36 @@ def main() -> None:
                     ev.record(exts[g])
                     ext.wait_event(ev)
             out = {"rewards": grp.rewards, "terminals": grp.terminals, "truncations": grp.truncations}
-            if args.gather == "obs":
+            if gather_kind == "obs":
                 out["observations"] = grp.obs
             gather.submit(out)
 
-    for t in range(args.warmup):
+    for t in range(warmup):
         one_step(t)
     grp.sync()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    # round boundaries: events on the stream that finishes a step last (no host synchronisation inside the bracket)
+    rounds = max(1, min(rounds, steps))
+    bounds = [round(i * steps / rounds) for i in range(rounds + 1)]
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(rounds + 1)]
+    ev0 = torch.cuda.Event(enable_timing=True)
     ev0.record(exts[0])      # (all streams are idle here; the first group starts a step first ...)
+    marks[0].record(ext)
     t0 = time.perf_counter()
-    for t in range(args.steps):
-        one_step(args.warmup + t)
-    ev1.record(ext)          # (... and the last group ends it)
+    r = 1
+    for t in range(steps):
+        one_step(warmup + t)
+        if t + 1 == bounds[r]:
+            marks[r].record(ext)   # (... and the last group ends it)
+            r += 1
     grp.sync()
     if gather is not None:
         gather.finish()
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
-    dev_ms = ev0.elapsed_time(ev1)
+    dev_ms = ev0.elapsed_time(marks[rounds])
     if dist is not None:
         dist.barrier()
         tmax = torch.tensor([wall], dtype=torch.float64, device="cuda")
@@ -282,12 +292,20 @@ def main() -> None:
     bits, first = grp.poll_errors()
     if bits:
         raise SystemExit(f"engine reported env error bits {bits} (first env {first})")
+    per_round = []
+    for i in range(rounds):
+        n_i = bounds[i + 1] - bounds[i]
+        if n_i > 0:
+            per_round.append(E * A * n_i / (marks[i].elapsed_time(marks[i + 1]) * 1e-3))
+    mean = float(np.mean(per_round))
+    std = float(np.std(per_round))
+    cv = std / mean if mean else 0.0
 
     # per-kernel durations for the roofline line: HIP events between the two kernels on the engine stream
     # (one group at a time, so that a duration is the kernel's own and not its share of an overlapped pair; a launch
     # covers E / G envs)
     grp.set_profiling(True)
-    nprof = min(50, max(5, args.steps))
+    nprof = min(50, max(5, steps))
     seg = {}
     for t in range(nprof):
         for g, eng in enumerate(grp.engines):
@@ -295,43 +313,164 @@ def main() -> None:
             for k, v in eng.step_timing_segments_ms().items():   # waits for the step
                 seg[k] = seg.get(k, 0.0) + v / (nprof * G)
     grp.set_profiling(False)
+    grp.close()
+    del grp, pre_a, pre_v
+    torch.cuda.empty_cache()
+
+    # Roofline of the dominant kernel (DESIGN.md "Roofline accounting").  Algorithmic bytes per agent-step: the
+    # observation kernel owns obs out 3T + reward 4 + terminal 1 + truncation 1 + one read of the env state
+    # S_env/A; the world-update kernel owns the two action streams (8) + one pass over S_env/A.
+    names = {"obs": "mgx_obs_kernel", "actions": "mgx_world_kernel_x" if rung == 4 else "mgx_world_kernel_fast"}
+    dom = "obs" if seg["obs"] >= seg["actions"] else "actions"
+    bytes_per_agent_step = per["obs"] if dom == "obs" else per["world"]
+    achieved = (E // G) * A * bytes_per_agent_step / (seg[dom] * 1e-3) / 1e9
+    traffic, source = None, None
+    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc):
+        try:
+            pj = json.load(open(pmc))
+            traffic = pj.get(f"rung{rung}", {}).get(names[dom] + "_bytes_per_launch")
+            source = f"profiles/pmc_traffic.json@{pj.get('build', '?')} (PMC FETCH_SIZE x2 + WRITE_SIZE of a profiled run, not this run)"
+        except Exception:
+            traffic = None
+    return {
+        "value": world * E * A * steps / wall, "ms_per_step": wall * 1e3 / steps, "device_ms_per_step": dev_ms / steps,
+        "steps": steps, "warmup": warmup,
+        "rounds": {"n": len(per_round), "steps_per_round": steps // rounds, "mean": mean * world, "std": std * world, "cv": cv,
+                   "unstable": bool(cv > 0.20), "per_gpu": world > 1},
+        "kernels_ms": {"world_actions": seg["actions"], "aoe": seg["aoe"], "world_tail": seg["tail"],
+                       "mgx_obs_kernel": seg["obs"], "rewards_ext": seg["rewards"]},
+        "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                     "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": source,
+                     "bytes_per_agent_step": bytes_per_agent_step, "tick_bytes_per_agent_step": per["tick"],
+                     "kernel_ms": seg[dom]},
+        "config": {"workload": desc, "baseline_config": f"configs[{rung - 1}]", "envs_per_gpu": E, "agents_per_env": A,
+                   "obs_tokens": T, "gather": gather_kind, "parallelism": f"env-shard x{world}",
+                   "env_groups_per_gpu": G, "envs_per_launch": E // G},
+    }
+
+
+def env_wrapper_throughput(envs: int, steps: int, local_rank: int) -> dict:
+    """Agent-steps/s a trainer sees through the PufferEnv-shaped wrapper (mettagrid_amd/envs.py): rung-3 rules, max_steps =
+    1000, device map pool of 256 maps with on-device auto-reset and desynchronised first episodes, joint action ids decoded on
+    the device — what MettaGridPufferEnv.step does around MettaGrid::step (mettagrid_puffer_env.py:296-408)."""
+    import torch
+    from mettagrid_amd import presets
+    from mettagrid_amd.compiler import compile_spec
+    from mettagrid_amd.envs import MettaGridBatchedEnv
+    from mettagrid_amd.mapgen import random_class_maps
+    spec = presets.rung3_spec()
+    spec.max_steps = 1000
+    prog = compile_spec(spec, 32, 32, max_objects=192)
+    pool = random_class_maps(prog, 32, 32, {"wall": 40, "extractor": 8, "chest": 4}, {"red": 8, "blue": 8}, range(256))
+    out = {}
+    for validate in (False, True):
+        env = MettaGridBatchedEnv(prog, envs, map_pool=pool, pool_stride=7, desync=True, validate_actions=validate, seed=1,
+                                  device=local_rank)
+        env.reset()
+        gen = torch.Generator(device="cuda").manual_seed(3)
+        acts = torch.randint(0, int(env.transport_action_n), (8, env.num_agents), dtype=torch.int32, device="cuda", generator=gen)
+        for t in range(20):
+            env.step(acts[t % 8])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for t in range(steps):
+            env.step(acts[t % 8])
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        ep, _ = env.engine.episodes()
+        bits, _ = env.engine.poll_errors()
+        out["validate_actions" if validate else "unchecked_actions"] = {
+            "value": env.num_agents * steps / dt, "ms_per_step": dt * 1e3 / steps, "episodes_finished": int(ep.sum()),
+            "env_error_bits": int(bits)}
+        env.close()
+    out["unit"] = "agent-steps/s"
+    out["sample"] = (f"rung-3 rules through MettaGridBatchedEnv, {envs} envs x 16 agents, max_steps=1000, pool of 256 maps, "
+                     f"desync, {steps} timed steps")
+    return out
+
+
+def main() -> None:
+    if len(sys.argv) > 1 and sys.argv[1] == "--cpu-worker":
+        cpu_worker(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), float(sys.argv[5]))
+        return
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--rounds", type=int, default=10, help="the timed steps are reported as this many rounds (mean / std / CV)")
+    ap.add_argument("--envs", type=int, default=65536, help="envs per GPU")
+    ap.add_argument("--rung", type=int, default=3, help="3 = BASELINE.json configs[2] (the headline metric), 4 = configs[3]")
+    ap.add_argument("--gather", choices=["none", "scalars", "obs"], default="none",
+                    help="optional per-step gather of rewards/terminals/truncations (+obs) to rank 0: grouped RCCL "
+                         "send/recv over xGMI on a side stream, overlapped with the next step (mettagrid_amd/dist.py)")
+    ap.add_argument("--groups", type=int, default=1,
+                    help="env groups per GPU (mettagrid_amd/groups.py): 2 = the world update of one half of the envs runs "
+                         "beside the observation kernel of the other half (measured slower on MI355X: DESIGN.md); "
+                         "1 = one engine, kernels back to back")
+    ap.add_argument("--cpu-steps", type=int, default=0, help="CPU baseline sample (default: about 10 s of one host core)")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="headline only: skip the rung-4 object and the env-wrapper throughput")
+    ap.add_argument("--rung4-steps", type=int, default=30)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    extras = world == 1 and args.rung == 3 and not args.no_extras
+    from mettagrid_amd.dist import env_shard
+
+    # Everything that forks or spawns comes first: this process has not touched the GPU yet.
+    workers = host_cores() if world == 1 else max(1, min(4, host_cores() // max(1, world)))
+    cms = build_maps(args.rung, env_shard(rank, world, args.envs), workers)   # map seed = global env index
+    cms4 = build_maps(4, env_shard(0, 1, args.envs), workers) if extras else None
+    cpu = cpu4 = None
+    if not args.no_cpu and world == 1:
+        # about 10 s on one core, then every host core at once (one env per process, about 5 s of stepping each)
+        cpu = cpu_leg(args.rung, args.cpu_steps or (300000 if args.rung == 3 else 25000))
+        if extras:
+            cpu4 = cpu_leg(4, 12000)
+
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the step engine has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    common = dict(envs=args.envs, groups=args.groups, gather_kind=args.gather, rank=rank, local_rank=local_rank, world=world, dist=dist)
+    head = measure(args.rung, cms, steps=args.steps, warmup=args.warmup, rounds=args.rounds, **common)
+    del cms
+    r4 = wrap = None
+    if extras:
+        r4 = measure(4, cms4, steps=args.rung4_steps, warmup=5, rounds=min(5, args.rung4_steps), **common)
+        del cms4
+        wrap = env_wrapper_throughput(args.envs, 100, local_rank)
 
     if rank == 0:
-        agent_steps = world * E * A * args.steps
-        value = agent_steps / wall
-        # Roofline of the dominant kernel (DESIGN.md "Roofline accounting").  Algorithmic bytes per agent-step: the
-        # observation kernel owns obs out 3T + reward 4 + terminal 1 + truncation 1 + one read of the env state
-        # S_env/A; the world-update kernel owns the two action streams (8) + one pass over S_env/A.
-        names = {"obs": "mgx_obs_kernel", "actions": "mgx_world_kernel_x" if args.rung == 4 else "mgx_world_kernel_fast"}
-        dom = "obs" if seg["obs"] >= seg["actions"] else "actions"
-        bytes_per_agent_step = per["obs"] if dom == "obs" else per["world"]
-        achieved = (E // G) * A * bytes_per_agent_step / (seg[dom] * 1e-3) / 1e9
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
-            try:
-                traffic = json.load(open(pmc)).get(f"rung{args.rung}", {}).get(names[dom] + "_bytes_per_launch")
-            except Exception:
-                traffic = None
         out = {
             "metric": "agent-steps/sec (whole node) at 65 536 envs, 32x32x16-agent; HBM GB/s vs peak",
-            "value": value, "unit": "agent-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": wall * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "value": head["value"], "unit": "agent-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
-            "config": {"workload": desc, "baseline_config": f"configs[{args.rung - 1}]",
-                       "envs_per_gpu": E, "agents_per_env": A, "obs_tokens": T, "gather": args.gather,
-                       "parallelism": f"env-shard x{world}",
-                       "env_groups_per_gpu": G, "envs_per_launch": E // G},
-            "device_ms_per_step": dev_ms / args.steps,
-            "kernels_ms": {"world_actions": seg["actions"], "aoe": seg["aoe"], "world_tail": seg["tail"],
-                           "mgx_obs_kernel": seg["obs"], "rewards_ext": seg["rewards"]},
-            "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": 8000.0,
-                         "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
-                         "bytes_per_agent_step": bytes_per_agent_step,
-                         "tick_bytes_per_agent_step": per["tick"]},
+            "config": head["config"],
+            "device_ms_per_step": head["device_ms_per_step"],
+            "rounds": head["rounds"],
+            "kernels_ms": head["kernels_ms"],
+            "roofline": head["roofline"],
         }
         if cpu is not None:
             out["cpu_baseline"] = cpu
+        if r4 is not None:
+            r4 = dict(r4, metric="agent-steps/sec at 65 536 envs, 64x64x64-agent (BASELINE.json configs[3])", unit="agent-steps/s",
+                      dtype="u8", data="synthetic")
+            if cpu4 is not None:
+                r4["cpu_baseline"] = cpu4
+            out["rung4"] = r4
+        if wrap is not None:
+            out["env_wrapper"] = wrap
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

@@ -77,6 +77,14 @@ int mgx_set_joint_actions(mgx_engine* e, const int32_t* joint, int32_t num_prima
  * counterpart: the reference steps one env per process and overlaps processes. */
 int mgx_chain_world(mgx_engine* e, mgx_engine* after);
 
+/* One-shot ordering for consumers that read the bound output buffers asynchronously (the per-step gather of SURVEY.md §8e,
+ * mettagrid_amd/dist.py): the NEXT engine work that writes observations / rewards / terminals / truncations — the
+ * observation kernel of the next mgx_step, or an episode restart — first waits for `hip_event` (a hipEvent_t recorded by
+ * the caller on any stream of the engine's device).  The world-update kernels of that step are not held back: they do not
+ * touch those buffers.  The event must stay alive until that work has been enqueued.  NULL clears a pending wait.  No
+ * reference counterpart: the reference's caller and engine share one thread. */
+int mgx_wait_before_outputs(mgx_engine* e, void* hip_event);
+
 /* Episode restart for a subset of envs, on the device.  The reference restarts an episode by
  * constructing a new MettaGrid (MettaGridPufferEnv._new_sim, python/src/mettagrid/envs/mettagrid_puffer_env.py:225-228,
  * 299-302); here the selected envs are rebuilt in place by the same construction kernel mgx_create uses, their rows of

@@ -681,6 +681,18 @@ class _Compiler:
         cw = self.sections[K.SEC_CLASSES]
         n = self.counts[K.SEC_CLASSES]
 
+        def has_raycast(q) -> bool:
+            if isinstance(q, S.RaycastQuery):
+                return True
+            if isinstance(q, S.MaterializedQuery):
+                return has_raycast(q.query)
+            return any(has_raycast(getattr(q, attr)) for attr in ("source", "candidates") if getattr(q, attr, None) is not None
+                       and not isinstance(getattr(q, attr), str))
+        # A raycast returns whatever lies on its rays (blockers included), not a subset of its source objects
+        # (query_config.hpp "collect objects on unblocked rays"): any class can then receive the tag.
+        if any(has_raycast(mq.query) for mq in self.spec.materialize_queries):
+            return set(range(n))
+
         def has(c, t):
             return (cw[c * K.C_WORDS + K.C_TAGS + (t >> 5)] >> (t & 31)) & 1
 

@@ -74,7 +74,10 @@ __global__ void __launch_bounds__(MGX_DEC_WAVES* MGX_DEC_WAVE) mgx_decode_kernel
       if (atomicOr(&seen[k >> 5], bit) & bit) atomicOr(&dup[k >> 5], bit);
     }
   }
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // one wavefront per row: LDS operations complete in issue order; no need to wait for the zero-fill stores
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // one wavefront per row: LDS operations complete in issue order
+  // The value stores below go to addresses OTHER lanes of this wavefront have just zero-filled: wait until every fill
+  // store of the wavefront has been acknowledged, so that no value can be overtaken by a zero (pass 1 ran meanwhile).
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   // ---- pass 2: values over the zeros.  A cell with one token: that token's lane.  A shared cell: the lane of its first
   // token adds the later ones in token order. ----
   for (int t = lane; t < T; t += MGX_DEC_WAVE) {
@@ -102,10 +105,12 @@ int mgx_launch_decode(hipStream_t stream, const uint8_t* tokens, float* box, con
                       int W) {
   const size_t lds = mgx_decode_lds_bytes(T, C, H, W);
   if (lds > 160 * 1024) return -1;
-  static size_t cur_max = 0;
-  if (lds > cur_max) {
+  static size_t cur_max[64] = {};   // the attribute is per device
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -2;
+  if (lds > cur_max[dev]) {
     if (hipFuncSetAttribute((const void*)mgx_decode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -2;
-    cur_max = lds;
+    cur_max[dev] = lds;
   }
   const long long blocks = (rows + MGX_DEC_WAVES - 1) / MGX_DEC_WAVES;
   hipLaunchKernelGGL(mgx_decode_kernel, dim3((unsigned)blocks), dim3(MGX_DEC_WAVES * MGX_DEC_WAVE), lds, stream, tokens, box, scale_dev, rows, T, C,

@@ -248,6 +248,7 @@ struct mgx_engine {
   size_t stage_bytes = 0;
   bool profiling = false;
   bool timing_valid = false;   // a step has been recorded since profiling was switched on
+  hipEvent_t out_fence = nullptr;    // mgx_wait_before_outputs: pending, consumed by the next writer of the output buffers
   hipEvent_t world_done = nullptr;   // recorded after the world-update kernels of every step (mgx_chain_world)
   mgx_engine* world_after = nullptr;
   bool world_chained = false;
@@ -307,7 +308,9 @@ static int size_obs_lds(mgx_engine* e) {
   // The attribute is per kernel and process-wide: keep one maximum and only ever raise it, so that a second engine
   // with a smaller requirement cannot lower the limit under a live one.
   static std::mutex mu;
-  static size_t cur_max = 0;
+  static size_t cur_max_dev[64] = {};   // (function attributes are per device)
+  if (e->device < 0 || e->device >= 64) return fail(MGX_ERR_BAD_ARG, "device ordinal out of range");
+  size_t& cur_max = cur_max_dev[e->device];
   std::lock_guard<std::mutex> lock(mu);
   if (e->lds_obs > cur_max) {
     const void* fns[] = {(const void*)mgx_obs_kernel<true, false, false>, (const void*)mgx_obs_kernel<false, false, false>,
@@ -356,6 +359,15 @@ static const MgxDev* dev_copy_world_x(mgx_engine* e) {
   }
   return e->d_hot;
 }
+// mgx_wait_before_outputs: whatever writes the bound output buffers next goes behind the caller's event.
+static int consume_out_fence(mgx_engine* e) {
+  if (e->out_fence) {
+    hipEvent_t ev = e->out_fence;
+    e->out_fence = nullptr;
+    HIP_TRY(hipStreamWaitEvent(e->stream, ev, 0));
+  }
+  return MGX_OK;
+}
 static int launch_terr(mgx_engine* e) {  // refresh the ownership maps of the envs whose territory sources changed
   if (e->d.X && e->d.NT > 0 && e->d.terr_owner) {
     hipLaunchKernelGGL(mgx_terr_kernel, dim3(e->d.E), dim3(256), 8 * 256 * 8, e->stream, e->d);
@@ -368,7 +380,9 @@ static int launch_obs(mgx_engine* e, bool with_rewards, const uint8_t* mask = nu
   (void)with_rewards; (void)mask;
   return launch_terr(e);  // sanitizer build: the wavefront-cooperative observation kernel is not emulated
 #endif
-  int trc = launch_terr(e);
+  int trc = consume_out_fence(e);
+  if (trc) return trc;
+  trc = launch_terr(e);
   if (trc) return trc;
   MGX_TRACE_POINT(e, "terr kernel");
   if (e->d.obsval) mgx_launch_values(e->stream, e->d, dev_copy(e), 0, mask);
@@ -388,6 +402,7 @@ static int launch_obs(mgx_engine* e, bool with_rewards, const uint8_t* mask = nu
 static int init_buffers(mgx_engine* e) {
   const MgxDev& d = e->d;
   size_t rows = (size_t)d.E * d.A;
+  { int frc = consume_out_fence(e); if (frc) return frc; }
   HIP_TRY(hipMemsetAsync(d.terminals, 0, rows, e->stream));
   HIP_TRY(hipMemsetAsync(d.truncations, 0, rows, e->stream));
   HIP_TRY(hipMemsetAsync(d.rewards, 0, rows * 4, e->stream));
@@ -698,7 +713,20 @@ int mgx_create(const int32_t* program, size_t program_words, const uint16_t* cla
       if (!reward_only[i] && code[i * MGX_GV_WORDS + MGX_GV_OP] == MGX_GOP_STAT && code[i * MGX_GV_WORDS + MGX_GV_A0] != 1 &&
           booked(code[i * MGX_GV_WORDS + MGX_GV_A1]))
         reads_agent_stats = true;
-    d.defer_book = reads_agent_stats ? 0 : 1;  // (flushed at the end of the launch that runs the action phase)
+    // ... or a handler WRITES one of them mid-tick (SetStat / a game-value mutation on a StatValue): set-then-deferred-add
+    // would end on a different value than the reference's add-then-set
+    bool writes_booked = false;
+    const int n_mut = mgx_sec_cnt(P, MGX_SEC_MUTS);
+    for (int i = 0; i < n_mut; i++) {
+      const int32_t* m = P + d.sec[MGX_SEC_MUTS] + i * MGX_MU_WORDS;
+      if (m[MGX_MU_OP] == MGX_MOP_STATS && m[MGX_MU_A0] != 0 && booked(m[MGX_MU_A2])) writes_booked = true;
+      if (m[MGX_MU_OP] == MGX_MOP_GAME_VALUE && m[MGX_MU_A1] >= 0) {
+        const int32_t* V = P + d.sec[MGX_SEC_OBS_VALUES] + m[MGX_MU_A1] * MGX_OV_WORDS;
+        const int32_t* c0 = P + d.sec[MGX_SEC_GV_CODE] + V[MGX_OV_GV_START] * MGX_GV_WORDS;
+        if (V[MGX_OV_GV_COUNT] > 0 && c0[MGX_GV_OP] == MGX_GOP_STAT && c0[MGX_GV_A0] != 1 && booked(c0[MGX_GV_A1])) writes_booked = true;
+      }
+    }
+    d.defer_book = (reads_agent_stats || writes_booked) ? 0 : 1;  // (flushed at the end of the launch that runs the action phase)
   }
   if (d.X) {  // can the action phase's top-level handlers run on the register VM?  (mgx_world.h apply_top)
     bool flat = !getenv("MGX_NO_FLAT_TOP");
@@ -916,7 +944,9 @@ static int stage(mgx_engine* e, size_t bytes) {
 // from_pool: maps come from the pool through d_map_index; bump: auto-reset bookkeeping (episode counter, next pool map).
 static int restart_masked(mgx_engine* e, const uint8_t* dmask, bool from_pool, bool bump) {
   const MgxDev& d = e->d;
-  int rc = upload_rows(e);
+  int rc = consume_out_fence(e);   // the cleared rows include terminals / truncations / rewards
+  if (rc) return rc;
+  rc = upload_rows(e);
   if (rc) return rc;
   hipLaunchKernelGGL(mgx_clear_rows_kernel, dim3((unsigned)d.E), dim3(256), 0, e->stream, (const MgxRow*)e->d_rows, e->n_rows, dmask, d.E,
                      bump ? e->d_episodes : (uint32_t*)nullptr, bump ? e->d_map_index : (int32_t*)nullptr, e->n_pool, e->pool_stride);
@@ -1231,6 +1261,12 @@ int mgx_chain_world(mgx_engine* e, mgx_engine* after) {
   if (after && after->device != e->device) return fail(MGX_ERR_BAD_ARG, "mgx_chain_world: engines live on different devices");
   e->world_after = after;
   if (after) after->world_chained = true;
+  return MGX_OK;
+}
+
+int mgx_wait_before_outputs(mgx_engine* e, void* hip_event) {
+  if (!e) return fail(MGX_ERR_BAD_ARG, "mgx_wait_before_outputs: null engine");
+  e->out_fence = (hipEvent_t)hip_event;
   return MGX_OK;
 }
 

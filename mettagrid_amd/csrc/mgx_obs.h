@@ -144,6 +144,12 @@ __host__ __device__ inline MgxObsLds mgx_obs_lds_layout(int HW, int NOFF, int S,
   l.pool = o; o += mgx_align16((pool_tokens + 8) * 2);
   l.row_words = (T + 3) & ~3;
   l.row_pitch = l.row_words + 16;  // + one trash word per lane of a 16-lane row: masked-off stores land there
+#ifndef MGX_OBS_PITCH_OLD
+  // ... + padding to 8 words mod 16: the two DPP rows of a 32-lane LDS group write to staging rows two pitches apart
+  // (row permutation in the kernel), and 2 * pitch = 16 mod 32 keeps their 16-word spans on disjoint banks for every T
+  // (T = 200: 216, no padding; T = 256: 272 -> 280, where both rows of a half started on the same bank).
+  l.row_pitch += (8 - (l.row_pitch & 15)) & 15;
+#endif
   l.rows = o;
   l.owner = 0;
   {
@@ -222,9 +228,9 @@ __global__ void __launch_bounds__(NTH) mgx_obs_kernel(MgxDev d, int pool_tokens,
   uint32_t* s_misc = (uint32_t*)(smem + L.misc);
   uint16_t* s_pool = (uint16_t*)(smem + L.pool);
   const int row = lane >> 4, rl = lane & 15;  // encode: one agent per 16-lane DPP row
-  // One u32 per token: loc | f << 8 | v << 16.  The pitch is 24 words mod 32 banks, so the rows of a wavefront start at
-  // banks 0, 24, 16, 8: DPP rows 0 and 1 (one 32-lane LDS group) take the 1st and 3rd of them, rows 2 and 3 the 2nd and 4th
-  // — the two 16-word spans of a group then never share a bank.
+  // One u32 per token: loc | f << 8 | v << 16.  The pitch is 8 words mod 16 (layout), so the rows of a wavefront start at
+  // banks 0, 8 | 24, 16, 24 | 8: DPP rows 0 and 1 (one 32-lane LDS group) take the 1st and 3rd of them, rows 2 and 3 the 2nd
+  // and 4th — the two 16-word spans of a group then never share a bank.
   uint32_t* s_row = (uint32_t*)(smem + L.rows) + (wave * 4 + (((row & 1) << 1) | (row >> 1))) * L.row_pitch;
   const int TRASH = L.row_words + rl;  // s_row[TRASH]: target of this lane's masked-off stores
   uint16_t* s_cell = (uint16_t*)(smem + L.cell);

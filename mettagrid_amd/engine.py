@@ -59,6 +59,7 @@ def load_lib():
     L.mgx_stream.argtypes = [vp]
     L.mgx_stream.restype = vp
     L.mgx_chain_world.argtypes = [vp, vp]
+    L.mgx_wait_before_outputs.argtypes = [vp, vp]
     L.mgx_set_joint_actions.argtypes = [vp, vp, i32, vp, i32]
     L.mgx_get_buffers.argtypes = [vp] + [C.POINTER(vp)] * 6 + [C.POINTER(i32)]
     L.mgx_get_episode_rewards.argtypes = [vp, vp]
@@ -202,6 +203,13 @@ class BatchedMettaGrid:
         """From now on this engine's world-update kernels start only when ``other``'s most recent ones have finished
         (include/mgx.h mgx_chain_world): the building block of ``EnvGroups``."""
         _check(self.L.mgx_chain_world(self.h, other.h if other is not None else None))
+
+    def wait_before_outputs(self, event) -> None:
+        """The next engine work that writes observations / rewards / terminals / truncations waits for ``event`` (a recorded
+        ``torch.cuda.Event``, kept alive here until then); the next step's world update does not (include/mgx.h
+        mgx_wait_before_outputs).  Used by ``dist.GatherToRoot`` to order a step behind the staging copy of the previous one."""
+        self._out_fence = event
+        _check(self.L.mgx_wait_before_outputs(self.h, C.c_void_p(event.cuda_event)))
 
     def reset_envs(self, env_mask, class_maps=None, seeds=None) -> None:
         """Restart the selected envs in place on the device (new episode): optional new maps / seeds for them.

@@ -148,6 +148,7 @@ class MettaGridBatchedEnv:
         self.pool_stride = pool_stride
         self.desync = desync
         self.validate_actions = validate_actions
+        self._default_seed_fn = seed_fn is None
         self.seed_fn = seed_fn or (lambda base, env, episode: (base + env) & 0xFFFFFFFF)
         self._seed = seed
         self._device = device
@@ -203,6 +204,8 @@ class MettaGridBatchedEnv:
         return out
 
     def _seeds(self) -> np.ndarray:
+        if self._default_seed_fn:   # (base + env) mod 2^32 for every env at once
+            return ((np.int64(self._seed) + np.arange(self.E, dtype=np.int64)) & 0xFFFFFFFF).astype(np.uint32)
         return np.array([self.seed_fn(self._seed, e, int(self.episode[e])) for e in range(self.E)], dtype=np.uint32)
 
     def early_end_steps(self) -> np.ndarray:
@@ -210,7 +213,8 @@ class MettaGridBatchedEnv:
         ms = int(self.prog.words[11])   # MGX_H_MAX_STEPS
         if ms <= 0:
             return np.zeros(self.E, np.uint32)
-        return np.array([int(np.random.default_rng(int(s)).integers(1, ms + 1)) for s in self._seeds()], dtype=np.uint32)
+        from .early_reset import first_integers
+        return first_integers(self._seeds(), ms)
 
     def reset(self, seed: Optional[int] = None):
         if seed is not None:
@@ -263,7 +267,7 @@ class MettaGridBatchedEnv:
         if self._kind == "device":
             import torch
             a = actions if isinstance(actions, torch.Tensor) else torch.as_tensor(np.asarray(actions), device=eng.obs.device)
-            if not self.validate_actions and a.ndim == 1 and a.dtype == torch.int32 and a.is_contiguous():
+            if self.supervisor is None and not self.validate_actions and a.ndim == 1 and a.dtype == torch.int32 and a.is_contiguous():
                 # one kernel on the engine's stream instead of a dozen elementwise torch kernels
                 if tuple(a.shape) != tuple(eng.actions.shape):
                     raise ValueError(f"Expected {tuple(eng.actions.shape)} actions, got {tuple(a.shape)}")
@@ -274,13 +278,17 @@ class MettaGridBatchedEnv:
                     core, vibe = decode_actions(a, len(self.action_names), self._vibe_ids, xp=torch)
                 else:
                     core, vibe = decode_actions_unchecked(a, len(self.action_names), self._vibe_ids)
+                    if self.supervisor is not None and vibe is not None and a.ndim == 1:
+                        # the reference only overwrites the vibe stream when some action of the batch carries a vibe
+                        # (:361-381); decided on the device, no host read
+                        vibe = torch.where((a >= len(self.action_names)).any(), vibe, eng.vibe_actions.to(vibe.dtype))
                 if tuple(core.shape) != tuple(eng.actions.shape):
                     raise ValueError(f"Expected {tuple(eng.actions.shape)} core actions, got {tuple(core.shape)}")
                 eng.actions.copy_(core.to(torch.int32))
                 if vibe is not None:
                     eng.vibe_actions.copy_(vibe.to(torch.int32))
-                else:
-                    eng.vibe_actions.zero_()
+                elif self.supervisor is None:   # with a supervisor the teacher's vibe labels of the last step stay
+                    eng.vibe_actions.zero_()    # (mettagrid_puffer_env.py:389-391)
                 eng.wait_for_caller()   # the engine's kernels read the actions written on the caller's stream ...
             eng.step()
             eng.caller_waits()      # ... and whatever the caller enqueues next sees this step's results
@@ -294,7 +302,7 @@ class MettaGridBatchedEnv:
             np.copyto(eng.actions, core.astype(np.int32))
             if vibe is not None:
                 np.copyto(eng.vibe_actions, vibe.astype(np.int32))
-            else:
+            elif self.supervisor is None:       # mettagrid_puffer_env.py:389-391
                 eng.vibe_actions.fill(0)
             eng.step()
             if self.supervisor is not None:

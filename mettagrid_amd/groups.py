@@ -74,6 +74,10 @@ class EnvGroups:
         for eng in self.engines:
             eng.caller_waits()
 
+    def wait_before_outputs(self, event) -> None:
+        for eng in self.engines:
+            eng.wait_before_outputs(event)
+
     def poll_errors(self):
         bits, first = 0, -1
         for g, eng in enumerate(self.engines):

@@ -114,3 +114,52 @@ def state_digest(raw_objects: np.ndarray, raw_stats, episode_rewards, action_suc
         for k, n in (invalid_extra[a] if invalid_extra else {}).items():   # invalid_index_extra(): first-seen order
             h = _fnv(_fnv(h, int(k) & 0xFFFFFFFF), bits(n))
     return h
+
+
+def state_digest_many(dumps: list) -> np.ndarray:
+    """``state_digest`` of many envs at once (uint64 [N]): the FNV chains run side by side in numpy, one array step per
+    hashed word.  ``dumps``: per env ``(raw_objects, raw_stats, episode_rewards, action_success, current_stat_reward, step)``
+    with an optional seventh entry ``invalid_extra``; envs that have such extras take the scalar function."""
+    N = len(dumps)
+    out = np.zeros(N, np.uint64)
+    plain = [i for i, d in enumerate(dumps) if not (len(d) > 6 and d[6] and any(d[6]))]
+    for i in set(range(N)) - set(plain):
+        out[i] = state_digest(*dumps[i])
+    if not plain:
+        return out
+    D = [dumps[i] for i in plain]
+    n = len(D)
+    prime, m32 = np.uint64(_FNV_PRIME), np.uint64(0xFFFFFFFF)
+
+    def fnv(h, w):
+        return (h ^ (w.astype(np.uint64) & m32)) * prime
+
+    with np.errstate(over="ignore"):
+        nobj = np.array([len(d[0]) for d in D], np.int64)
+        words = D[0][0].shape[1] if nobj.max() > 0 else 0
+        recs = np.zeros((n, int(nobj.max()), words), np.int64)
+        for i, d in enumerate(D):
+            recs[i, :nobj[i]] = d[0]
+        hs = np.full(recs.shape[:2], _FNV_BASIS, np.uint64)
+        for w in range(words):
+            hs = fnv(hs, recs[:, :, w].astype(np.uint64))
+        h = fnv(fnv(np.full(n, _FNV_BASIS, np.uint64), np.array([d[5] for d in D], np.uint64)), nobj.astype(np.uint64))
+        for k in range(recs.shape[1]):
+            live = k < nobj
+            h = np.where(live, fnv(fnv(h, hs[:, k] & m32), hs[:, k] >> np.uint64(32)), h)
+        f32bits = lambda x: np.ascontiguousarray(x, dtype=np.float32).view(np.uint32)  # noqa: E731
+        gv = np.stack([f32bits(d[1][0]) for d in D])
+        gt = np.stack([(np.asarray(d[1][1]) != 0) | (np.asarray(d[1][0]) != 0) for d in D])
+        for i in range(gv.shape[1]):
+            h = fnv(fnv(h, gv[:, i]), gt[:, i])
+        av = np.stack([f32bits(d[1][2]) for d in D])
+        at = np.stack([(np.asarray(d[1][3]) != 0) | (np.asarray(d[1][2]) != 0) for d in D])
+        ep = np.stack([f32bits(d[2]) for d in D])
+        ok = np.stack([np.asarray(d[3]).astype(bool) for d in D])
+        cur = np.stack([f32bits(d[4]) for d in D])
+        for a in range(av.shape[1]):
+            for i in range(av.shape[2]):
+                h = fnv(fnv(h, av[:, a, i]), at[:, a, i])
+            h = fnv(fnv(fnv(h, ep[:, a]), ok[:, a]), cur[:, a])
+    out[plain] = h
+    return out

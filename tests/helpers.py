@@ -422,3 +422,34 @@ def thirteen_spec() -> S.GameSpec:
 
 
 SCENARIOS["thirteen"] = (thirteen_spec, torture_map, 45, False)
+
+
+def lit_spec() -> S.GameSpec:
+    """A materialized RAYCAST tag with no tag mutation anywhere in the program: the rays of every lamp put the tag "lit" on
+    whatever they cross — walls, boxes, agents — so classes that never carry a leaf tag of the query (plain walls) must
+    still show it in observations (query_config.hpp: a raycast collects the objects on its rays, blockers included).
+    Agents block rays, so the event that recomputes the query moves the lit set as they walk."""
+    T = S.TARGET
+    rays = S.RaycastQuery(S.TagQuery("type:lamp"), max_range=4, blocker=[S.TagPrefixFilter(T, "type:agent")],
+                          include_blocker=True)
+    events = {"relight": S.EventSpec(S.TagQuery("type:lamp"), list(range(4, 200, 5)), [], [S.RecomputeMaterializedQuery("lit")])}
+    return S.GameSpec(
+        resource_names=["hp", "ore"],
+        agents=[S.AgentSpec(team_id=0, inventory=S.Inventory(initial={"hp": 9}, default_limit=50),
+                            rewards=[S.RewardSpec(S.QueryCountValue(S.TagQuery("lit")), per_tick=True)]) for _ in range(5)],
+        objects={"wall": S.ObjectSpec("wall", kind="wall"), "lamp": S.ObjectSpec("lamp"),
+                 "box": S.ObjectSpec("box", inventory=S.Inventory(initial={"ore": 3}))},
+        tags=["lit"],
+        vibe_names=["default", "a"], change_vibe_enabled=True,
+        move_directions=["north", "south", "west", "east"],
+        obs=S.ObsSpec(width=9, height=9, num_tokens=150),
+        events=events,
+        materialize_queries=[S.MaterializedQuery("lit", rays)],
+        max_steps=0)
+
+
+def lit_map(seed: int) -> np.ndarray:
+    return random_map(12, 13, {"wall": 14, "lamp": 3, "box": 5}, 5, seed)
+
+
+SCENARIOS["lit"] = (lit_spec, lit_map, 40, False)

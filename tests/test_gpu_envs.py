@@ -266,19 +266,52 @@ def test_pettingzoo_surface_and_supervisor_hook():
 
         def step_batch(self, raw_obs, teacher_actions):
             i = np.arange(teacher_actions.shape[0])
-            teacher_actions[:] = (i % self.P) if self.t % 2 == 0 else self.P + (i % self.V)
+            lab = ((i % self.P) if self.t % 2 == 0 else self.P + (i % self.V)).astype(np.int32)
+            if isinstance(teacher_actions, np.ndarray):
+                teacher_actions[:] = lab
+            else:
+                import torch
+                teacher_actions.copy_(torch.as_tensor(lab, device=teacher_actions.device))
             self.t += 1
-    benv = MettaGridBatchedEnv(prog, 2, map_fn=lambda e, ep: prog.class_map(presets.rung2_map(e)), seed=1, buffers="host")
-    benv.reset()
-    P, V = len(benv.action_names), len(benv.vibe_action_names)
-    benv.set_supervisor(Teacher(P, V))
-    benv.step(np.zeros(benv.num_agents, np.int64))
-    assert benv.engine.vibe_actions.tolist() == [0] * benv.num_agents and benv.teacher_actions.max() < P
-    benv.step(np.zeros(benv.num_agents, np.int64))
-    vibe_ids = [prog.action_names.index(nm) for nm in benv.vibe_action_names]
-    assert benv.engine.vibe_actions.tolist() == [vibe_ids[i % V] for i in range(benv.num_agents)]
-    benv.disable_supervisor()
-    benv.close()
+    for kind, validate in (("host", True), ("device", True), ("device", False)):
+        benv = MettaGridBatchedEnv(prog, 2, map_fn=lambda e, ep: prog.class_map(presets.rung2_map(e)), seed=1, buffers=kind,
+                                   validate_actions=validate)
+        benv.reset()
+        P, V = len(benv.action_names), len(benv.vibe_action_names)
+        benv.set_supervisor(Teacher(P, V))
+        zeros = np.zeros(benv.num_agents, np.int32)
+        if kind == "device":
+            import torch
+            zeros = torch.zeros(benv.num_agents, dtype=torch.int32, device="cuda")
+        host = (lambda x: x.cpu().numpy()) if kind == "device" else (lambda x: x)
+        benv.step(zeros)
+        assert host(benv.engine.vibe_actions).tolist() == [0] * benv.num_agents and int(benv.teacher_actions.max()) < P
+        benv.step(zeros)
+        vibe_ids = [prog.action_names.index(nm) for nm in benv.vibe_action_names]
+        want = [vibe_ids[i % V] for i in range(benv.num_agents)]
+        assert host(benv.engine.vibe_actions).tolist() == want
+        # the NEXT tick is stepped WITH the teacher's vibes: the reference leaves the vibe stream alone when a supervisor is
+        # configured and the learner sent no vibe (mettagrid_puffer_env.py:389-391)
+        benv.step(zeros)
+        benv.engine.sync()
+        A = prog.num_agents
+        for e in range(2):
+            o2 = op.OracleSim(prog, prog.class_map(presets.rung2_map(e)), 1 + e)
+            o2.reinit_buffers()
+            z = np.zeros(A, np.int32)
+            o2.step(z, z)
+            o2.step(z, z)
+            o2.step(z, np.asarray(want[e * A:(e + 1) * A], np.int32))
+            assert np.array_equal(o2.snapshot()["obs"], host(benv.engine.obs)[e * A:(e + 1) * A]), (kind, validate, e)
+            plain = op.OracleSim(prog, prog.class_map(presets.rung2_map(e)), 1 + e)
+            plain.reinit_buffers()
+            for _ in range(3):
+                plain.step(z, z)
+            assert not np.array_equal(plain.snapshot()["obs"], o2.snapshot()["obs"])   # the vibes are visible in the obs
+        benv.disable_supervisor()
+        benv.step(zeros)   # without a supervisor the stream is cleared again
+        assert host(benv.engine.vibe_actions).tolist() == [0] * benv.num_agents
+        benv.close()
 
 
 def test_joint_action_decode_on_device_matches_host_rules():

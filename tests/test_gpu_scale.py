@@ -29,7 +29,10 @@ def _run_and_check(E, sample, steps, seed0=0, rung=3, actions=None, obs_tokens=N
     else:
         spec = presets.rung4_spec() if obs_tokens is None else presets.rung4_spec(obs_tokens=obs_tokens)
         prog = compile_spec(spec, 64, 64, max_objects=presets.RUNG4_MAX_OBJECTS)
-        cms = random_class_maps(prog, 64, 64, presets.RUNG4_OBJECTS, presets.RUNG4_AGENTS, range(seed0, seed0 + E))
+        distinct = min(E, 4096)   # one numpy generator per map on the host: a minute for 65 536 maps; seeds stay per env
+        cms = random_class_maps(prog, 64, 64, presets.RUNG4_OBJECTS, presets.RUNG4_AGENTS, range(seed0, seed0 + distinct))
+        if distinct < E:
+            cms = cms[np.arange(E) % distinct]
     A, T = prog.num_agents, prog.num_tokens
     seeds = np.arange(seed0, seed0 + E, dtype=np.uint32)
     eng = BatchedMettaGrid(prog, cms, seeds, buffers="device")

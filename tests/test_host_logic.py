@@ -133,3 +133,52 @@ def test_split_supervisor_actions_inplace_known_answers():
     with pytest.raises(ValueError):
         split_supervisor_actions_inplace(np.array([-1], np.int32), np.zeros(1, np.int32), num_primary_actions=5,
                                          vibe_action_ids_by_index=ids)
+
+
+def test_early_reset_draws_equal_numpy_generators():
+    """mettagrid_amd/early_reset.py restates default_rng(seed).integers(1, max_steps + 1) (EarlyResetHandler,
+    python/src/mettagrid/envs/early_reset_handler.py:6-22) for arrays of seeds: SeedSequence, PCG64, 32-bit Lemire."""
+    from mettagrid_amd.early_reset import first_integers
+    for high in (1, 2, 7, 1000, 12345, 2 ** 20):
+        for seeds in (np.arange(3000), np.random.RandomState(high).randint(0, 2 ** 32, 3000, dtype=np.uint64)):
+            want = [int(np.random.default_rng(int(s)).integers(1, high + 1)) for s in seeds]
+            assert first_integers(seeds, high).tolist() == want
+
+
+def test_batched_env_seeds_and_early_steps_are_vectorised_equivalents():
+    from mettagrid_amd import presets
+    from mettagrid_amd.compiler import compile_spec
+    from mettagrid_amd.envs import MettaGridBatchedEnv
+    spec = presets.rung2_spec()
+    spec.max_steps = 77
+    prog = compile_spec(spec, 32, 32)
+    env = MettaGridBatchedEnv(prog, 500, map_fn=lambda e, ep: None, seed=2 ** 32 - 3)
+    seeds = env._seeds()
+    assert seeds.dtype == np.uint32 and seeds.tolist() == [(2 ** 32 - 3 + e) & 0xFFFFFFFF for e in range(500)]
+    assert env.early_end_steps().tolist() == [int(np.random.default_rng(int(s)).integers(1, 78)) for s in seeds]
+    custom = MettaGridBatchedEnv(prog, 5, map_fn=lambda e, ep: None, seed=10, seed_fn=lambda b, e, ep: b * 100 + e)
+    assert custom._seeds().tolist() == [1000, 1001, 1002, 1003, 1004]
+
+
+def test_state_digest_many_equals_scalar_digest():
+    """signature.state_digest_many (what the long-horizon GPU test checks mgx_state_digests against) == state_digest per env,
+    including envs with far-invalid action indices."""
+    import helpers as hp
+    import oracle_py as op
+    from mettagrid_amd import signature as sg
+    for name in ("rung3", "rung4", "rung1_invalid"):
+        spec_f, map_f, steps, invalid = hp.SCENARIOS[name]
+        dumps = []
+        for seed in range(4):
+            cells = map_f(seed)
+            prog = hp.compile_scenario(name, spec_f(), *cells.shape)
+            o = op.OracleSim(prog, prog.class_map(cells), seed)
+            o.reinit_buffers()
+            acts, vibes = hp.make_actions(prog, seed, 12 + seed, invalid)
+            for t in range(12 + seed):
+                o.step(acts[t] + (1000 if name == "rung1_invalid" and seed == 2 else 0), vibes[t])
+            s = o.snapshot()
+            dumps.append((o.raw_objects(), o.raw_stats(), s["episode_rewards"], s["action_success"], o.current_stat_reward(),
+                          o.current_step, o.invalid_index_extra()))
+        got = sg.state_digest_many(dumps)
+        assert [int(g) for g in got] == [sg.state_digest(*d) for d in dumps]
