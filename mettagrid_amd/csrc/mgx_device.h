@@ -17,6 +17,7 @@
 #define MGX_WAVE 64
 #define MGX_NO_AGENT 0xFF
 #define MGX_DEAD_CLASS 0xFFFF
+#define MGX_AOE_MAX_STATS 32
 #define MGX_INV_PITCH 16  // u16 entries per inventory row: a row is two aligned 16-byte loads (R <= 13 resources)
 
 struct MgxDev {
@@ -79,7 +80,12 @@ struct MgxDev {
   int X;                  // 1: extended kernels are in use
   int NL;                 // indexed tags (TagIndex lists)
   int NF, NM, NTS, NT;    // capacities: fixed AoE sources, mobile AoE sources, territory sources; territory types
-  int AW;                 // words of a per-source agent bitmap
+  int AW;                 // words of a bitmap over the env's agents
+  int FW, MW;             // words of one agent's bitmap over the fixed / mobile AoE sources (fx_inside / mb_inside)
+  // lane-per-agent area-effect kernel (mgx_aoe_local.h): the agent stats its records can touch, staged per lane
+  int aoe_nstat;                 // number of such stat ids (<= MGX_AOE_MAX_STATS)
+  const int16_t* aoe_stat_ids;   // [aoe_nstat] stat id of local index k
+  const uint8_t* aoe_stat_map;   // [256] stat id -> local index, 0xFF = not staged (read / written in HBM directly)
   int QB, QD;             // query workspace buffers per env, max query nesting
   int SW;                 // words of a per-env object bitmap
   int game_on_tick, n_events, n_schedule, n_matq, aoe_mask_feat;
@@ -89,12 +95,12 @@ struct MgxDev {
   uint16_t* fx_obj;       // [E][NF] fixed AoE sources in registration order
   uint16_t* fx_aoe;       // [E][NF]
   uint16_t* fx_rc;        // [E][NF] location at registration
-  uint32_t* fx_inside;    // [E][NF][AW]
+  uint32_t* fx_inside;    // [E][A][FW]  bit f of agent ai: ai is inside fixed source f
   uint32_t* fx_pack;      // [E][NF] rc | radius << 16 | live << 24, rebuilt every step for the lane-per-agent AoE kernel
   uint16_t* fx_count;     // [E]
   uint16_t* mb_obj;       // [E][NM] mobile AoE sources
   uint16_t* mb_aoe;       // [E][NM]
-  uint32_t* mb_inside;    // [E][NM][AW]
+  uint32_t* mb_inside;    // [E][A][MW]
   uint32_t* mb_pack;      // [E][NM] like fx_pack, with the source's CURRENT location
   uint16_t* mb_count;     // [E]
   uint16_t* ts_obj;       // [E][NTS] territory sources in registration order

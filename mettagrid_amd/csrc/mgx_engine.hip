@@ -14,6 +14,7 @@
 #include "mgx_device.h"
 #include "mgx_obs.h"
 #include "mgx_world.h"
+#include "mgx_aoe_local.h"
 
 
 // Territory ownership map (TerritoryTracker::compute_cell_ownership, core/territory_tracker.cpp:215-252) of every cell,
@@ -218,6 +219,8 @@ struct mgx_engine {
   int32_t vibe_ids_host[256] = {};
   int n_vibe_ids = 0;
   bool aoe_local = false;      // area effects only touch their target: one lane per agent (mgx_aoe_kernel)
+  bool aoe_prog_lds = false;   // ... with the hot program range copied into its LDS
+  int hot_words = 0;           // words of the hot program range, rounded up to 4
   bool rewards_ext = false;    // reward expressions have query operands: evaluated by mgx_values_kernel after the obs kernel
   uint16_t* dmaps = nullptr;
   uint32_t* dseeds = nullptr;
@@ -346,8 +349,9 @@ static const MgxDev* dev_copy(mgx_engine* e) {
   return e->d_dev;
 }
 // ... and the extended world kernel's variant of it when that kernel keeps the hot program range in LDS.
-static const MgxDev* dev_copy_world_x(mgx_engine* e) {
-  if (!e->prog_in_lds) return dev_copy(e);
+static const MgxDev* dev_copy_hot(mgx_engine* e);
+static const MgxDev* dev_copy_world_x(mgx_engine* e) { return e->prog_in_lds ? dev_copy_hot(e) : dev_copy(e); }
+static const MgxDev* dev_copy_hot(mgx_engine* e) {
   MgxDev h = e->d;
   h.hot_lo = e->hot_lo;
   for (int k = 0; k < MGX_SEC_COUNT; k++)
@@ -526,6 +530,7 @@ int mgx_create(const int32_t* program, size_t program_words, const uint16_t* cla
       nm += per_m ? std::min<int>(d.S * per_m, 4096) : 0;
     }
     d.NF = nf; d.NM = nm; d.NTS = nts;
+    d.FW = std::max(1, (nf + 31) / 32); d.MW = std::max(1, (nm + 31) / 32);
     e->aoe_local = mgx_aoe_is_target_local(P) && !getenv("MGX_AOE_SERIAL");
     d.X = (any_aoe || d.NT > 0 || d.n_schedule > 0 || d.n_matq > 0 || d.game_on_tick >= 0 || P[MGX_H_DYNAMIC_TAGS] ||
            mgx_sec_cnt(P, MGX_SEC_QUERIES) > 0) ? 1 : 0;
@@ -579,10 +584,10 @@ int mgx_create(const int32_t* program, size_t program_words, const uint16_t* cla
     if (P[MGX_H_DYNAMIC_TAGS]) A_(e->alloc_env(&d.obj_tags, S * MGX_TAG_WORDS));
     if (d.NL) { A_(e->alloc_env(&d.tl_items, d.NL * S)); A_(e->alloc_env(&d.tl_count, (size_t)d.NL)); }
     if (d.NF) { A_(e->alloc_env(&d.fx_obj, (size_t)d.NF)); A_(e->alloc_env(&d.fx_aoe, (size_t)d.NF)); A_(e->alloc_env(&d.fx_rc, (size_t)d.NF));
-                A_(e->alloc_env(&d.fx_inside, (size_t)d.NF * d.AW)); A_(e->alloc_env(&d.fx_count, 1));
+                A_(e->alloc_env(&d.fx_inside, A * (size_t)d.FW)); A_(e->alloc_env(&d.fx_count, 1));
                 if (e->aoe_local) A_(e->alloc(&d.fx_pack, E * (size_t)d.NF)); }
     if (d.NM) { A_(e->alloc_env(&d.mb_obj, (size_t)d.NM)); A_(e->alloc_env(&d.mb_aoe, (size_t)d.NM));
-                A_(e->alloc_env(&d.mb_inside, (size_t)d.NM * d.AW)); A_(e->alloc_env(&d.mb_count, 1));
+                A_(e->alloc_env(&d.mb_inside, A * (size_t)d.MW)); A_(e->alloc_env(&d.mb_count, 1));
                 if (e->aoe_local) A_(e->alloc(&d.mb_pack, E * (size_t)d.NM)); }
     if (d.NTS) { A_(e->alloc_env(&d.ts_obj, (size_t)d.NTS)); A_(e->alloc_env(&d.ts_ctrl, (size_t)d.NTS)); A_(e->alloc_env(&d.ts_rc, (size_t)d.NTS));
                  A_(e->alloc_env(&d.ts_count, 1)); }
@@ -612,6 +617,35 @@ int mgx_create(const int32_t* program, size_t program_words, const uint16_t* cla
     d.cov_in_aoe = (split && d.game_on_tick < 0 && !getenv("MGX_TICK_SERIAL")) ? 1 : 0;
   }
   d.x_aoe_lds = (d.X && !(e->aoe_local && (d.NF > 0 || d.NM > 0 || d.NT > 0))) ? 1 : 0;
+  if (d.X && e->aoe_local && (d.NF > 0 || d.NM > 0 || d.NT > 0)) {
+    // the agent stats the lane-per-agent area-effect kernel keeps in LDS (mgx_aoe_local.h)
+    std::vector<int16_t> ids;
+    mgx_aoe_collect_stats(P, d.tick_in_aoe != 0, d.cov_in_aoe != 0, ids);
+    if (getenv("MGX_AOE_NO_STAT_CELLS")) ids.clear();   // (debug: every stat access of the kernel goes to HBM)
+    std::vector<uint8_t> map(256, 0xFF);
+    for (size_t k = 0; k < ids.size(); k++) map[(size_t)ids[k]] = (uint8_t)k;
+    int16_t* dids = nullptr;
+    uint8_t* dmap = nullptr;
+    int arc = e->alloc(&dids, std::max<size_t>(1, ids.size()));
+    if (arc == MGX_OK) arc = e->alloc(&dmap, 256);
+    if (arc != MGX_OK) { mgx_destroy(e); return arc; }
+    hipError_t ce = hipSuccess;
+    if (!ids.empty()) ce = hipMemcpyAsync(dids, ids.data(), ids.size() * 2, hipMemcpyHostToDevice, e->stream);
+    if (ce == hipSuccess) ce = hipMemcpyAsync(dmap, map.data(), 256, hipMemcpyHostToDevice, e->stream);
+    if (ce == hipSuccess) ce = hipStreamSynchronize(e->stream);   // `ids` / `map` are locals
+    if (ce != hipSuccess) { mgx_destroy(e); return fail(MGX_ERR_HIP, std::string("aoe stat table upload: ") + hipGetErrorString(ce)); }
+    d.aoe_nstat = (int)ids.size();
+    d.aoe_stat_ids = dids;
+    d.aoe_stat_map = dmap;
+    // hot program range in the kernel's LDS when it leaves room for three workgroups per CU
+    e->hot_words = ((d.sec[MGX_SEC_TAG_LISTS] - (d.sec[MGX_SEC_LIMITS] & ~3)) + 3) & ~3;
+    e->aoe_prog_lds = (size_t)mgx_aoe_lds_bytes(d.aoe_nstat) + (size_t)e->hot_words * 4 <= 52 * 1024 && !getenv("MGX_AOE_PROG_HBM");
+#ifdef MGX_CPU_EMU
+    e->aoe_prog_lds = false;  // the LDS copy needs a workgroup barrier; the sanitizer build runs work-items one by one
+#endif
+    if (!mgx_aoe_set_lds(d.aoe_nstat, e->aoe_prog_lds ? e->hot_words : 0)) { mgx_destroy(e); return fail(MGX_ERR_HIP, "mgx_create: cannot raise the area-effect kernel's dynamic LDS limit"); }
+    if (getenv("MGX_VERBOSE")) fprintf(stderr, "[mgx] aoe kernel: %d agent stats staged per lane, %d B of LDS per workgroup\n", d.aoe_nstat, mgx_aoe_lds_bytes(d.aoe_nstat));
+  }
   e->lds_world = d.X ? mgx_world_x_lds_bytes(d.A, d.x_aoe_lds != 0) : mgx_world_fast_lds_bytes(d.A);
   // The world kernels copy the program — everything in front of the schedule, the last and only section that grows with
   // the episode length — into LDS when it leaves room for 4 (lean) / 3 (extended) workgroups per CU (160 KB LDS).
@@ -1204,7 +1238,7 @@ int mgx_step(mgx_engine* e) {
       MGX_MARK(1);
       int trc = launch_terr(e);  // the per-agent territory effects read the ownership map
       if (trc) return trc;
-      mgx_launch_aoe(e->stream, e->d, dev_copy(e));
+      mgx_launch_aoe(e->stream, e->d, dev_copy(e), e->aoe_prog_lds ? dev_copy_hot(e) : nullptr, e->aoe_prog_lds ? e->hot_words : 0);
       MGX_TRACE_POINT(e, "aoe kernel");
       MGX_MARK(2);
       if (!d.cov_in_aoe) mgx_launch_world_x(e->prog_in_lds, e->lds_world, e->stream, e->d, dev_copy_world_x(e), pw, MGX_PH_TAIL);

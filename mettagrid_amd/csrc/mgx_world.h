@@ -165,6 +165,7 @@ struct MgxValueStack {
 
 template <class PP, bool X>
 struct MgxEnvT {  // per-lane view of one env
+  typedef PP ProgPtr;
 #ifdef MGX_CONST_DEV
   static constexpr const MgxDev& d = g_mgx_dev;
 #else
@@ -278,6 +279,13 @@ struct MgxEnvT {  // per-lane view of one env
     }
     __device__ __forceinline__ int get(int item) const { uint32_t v = pair(item >> 1); return (int)((item & 1) ? v >> 16 : v & 0xFFFFu); }
     template <int K> __device__ __forceinline__ int at() const { return (int)((K & 1) ? w[K >> 1] >> 16 : w[K >> 1] & 0xFFFFu); }
+    __device__ __forceinline__ void set(int item, int v) {  // run-time item, again without indexing the array
+      const int i = item >> 1;
+      const uint32_t old = pair(i);
+      const uint32_t nw = (item & 1) ? ((old & 0xFFFFu) | ((uint32_t)v << 16)) : ((old & 0xFFFF0000u) | ((uint32_t)v & 0xFFFFu));
+#pragma unroll
+      for (int q = 0; q < MGX_INV_PITCH / 2; q++) w[q] = (i == q) ? nw : w[q];
+    }
   };
   __device__ __forceinline__ InvRow inv_row(int slot) const {
     const uint4* p = (const uint4*)(d.obj_inv + so(slot) * MGX_INV_PITCH);
@@ -830,14 +838,14 @@ struct MgxEnvT {  // per-lane view of one env
         if (n >= d.NF) { flag(8u); continue; }
         size_t q = (size_t)envi() * d.NF + n;
         d.fx_obj[q] = (uint16_t)slot; d.fx_aoe[q] = (uint16_t)a; d.fx_rc[q] = d.obj_rc[so(slot)];
-        for (int w = 0; w < d.AW; w++) d.fx_inside[q * d.AW + w] = 0;
+        for (int ai = 0; ai < d.A; ai++) fx_in(n, ai) &= ~(1u << (n & 31));
         d.fx_count[envi()] = n + 1;
       } else {
         uint16_t n = d.mb_count[envi()];
         if (n >= d.NM) { flag(8u); continue; }
         size_t q = (size_t)envi() * d.NM + n;
         d.mb_obj[q] = (uint16_t)slot; d.mb_aoe[q] = (uint16_t)a;
-        for (int w = 0; w < d.AW; w++) d.mb_inside[q * d.AW + w] = 0;
+        for (int ai = 0; ai < d.A; ai++) mb_in(n, ai) &= ~(1u << (n & 31));
         d.mb_count[envi()] = n + 1;
       }
     }
@@ -850,8 +858,8 @@ struct MgxEnvT {  // per-lane view of one env
         if (d.fx_obj[fb + f] != (uint16_t)slot) continue;
         PP a = aoe(d.fx_aoe[fb + f]);
         for (int ai = 0; ai < d.A; ai++) {
-          uint32_t& w = d.fx_inside[(fb + f) * d.AW + (ai >> 5)];
-          if ((w >> (ai & 31)) & 1u) { w &= ~(1u << (ai & 31)); presence(a, d.ag_obj[ao(ai)], -1); }
+          uint32_t& w = fx_in(f, ai);
+          if ((w >> (f & 31)) & 1u) { w &= ~(1u << (f & 31)); presence(a, d.ag_obj[ao(ai)], -1); }
         }
         d.fx_obj[fb + f] = 0xFFFF;  // unregistered
       }
@@ -862,8 +870,8 @@ struct MgxEnvT {  // per-lane view of one env
         if (d.mb_obj[mb + f] != (uint16_t)slot) continue;
         PP a = aoe(d.mb_aoe[mb + f]);
         for (int ai = 0; ai < d.A; ai++) {
-          uint32_t& w = d.mb_inside[(mb + f) * d.AW + (ai >> 5)];
-          if ((w >> (ai & 31)) & 1u) { w &= ~(1u << (ai & 31)); presence(a, d.ag_obj[ao(ai)], -1); }
+          uint32_t& w = mb_in(f, ai);
+          if ((w >> (f & 31)) & 1u) { w &= ~(1u << (f & 31)); presence(a, d.ag_obj[ao(ai)], -1); }
         }
         d.mb_obj[mb + f] = 0xFFFF;
       }
@@ -1425,6 +1433,11 @@ struct MgxEnvT {  // per-lane view of one env
   }
 
   // ---- AoE (core/aoe_tracker.cpp) ----
+  // "agent ai is inside source f": one bit per (agent, source), stored AGENT-major — [E][A][FW] / [E][A][MW] words — so that
+  // the lane-per-agent kernel owns its words (plain loads and stores, one word covers 32 sources of the agent) and the
+  // serial form below walks the same bits.
+  __device__ __forceinline__ uint32_t& fx_in(int f, int ai) const { return d.fx_inside[ao(ai) * d.FW + (f >> 5)]; }
+  __device__ __forceinline__ uint32_t& mb_in(int m, int ai) const { return d.mb_inside[ao(ai) * d.MW + (m >> 5)]; }
   __device__ __forceinline__ PP aoe(int a) const { return prog() + d.sec[MGX_SEC_AOES] + a * MGX_AO_WORDS; }
   __device__ bool fixed_covers(PP a, uint16_t src_rc, int r, int c) const {  // register_fixed :166-200
     long long range = a[MGX_AO_RADIUS], dr = r - (int)(src_rc >> 8), dc = c - (int)(src_rc & 0xFF);
@@ -1451,10 +1464,10 @@ struct MgxEnvT {  // per-lane view of one env
     // exits first.  The reference walks an unordered_set<AOESource*> here (address order); registration order is used.
     for (int f = 0; f < nf; f++) {
       if (d.fx_obj[fb + f] == 0xFFFF) continue;
-      uint32_t& w = d.fx_inside[(fb + f) * d.AW + (ai >> 5)];
-      if (!((w >> (ai & 31)) & 1u)) continue;
+      uint32_t& w = fx_in(f, ai);
+      if (!((w >> (f & 31)) & 1u)) continue;
       PP a = aoe(d.fx_aoe[fb + f]);
-      if (!fixed_covers(a, d.fx_rc[fb + f], r, c)) { w &= ~(1u << (ai & 31)); presence(a, tgt, -1); }
+      if (!fixed_covers(a, d.fx_rc[fb + f], r, c)) { w &= ~(1u << (f & 31)); presence(a, tgt, -1); }
     }
     for (int f = 0; f < nf; f++) {
       if (d.fx_obj[fb + f] == 0xFFFF) continue;
@@ -1466,10 +1479,10 @@ struct MgxEnvT {  // per-lane view of one env
       MgxCtx fc = mgx_ctx(src, tgt);
       fc.deferred = true;
       bool passes = !skip_self && check_filters<TOPQ>(a[MGX_AO_FILTER_PC], fc, 0);
-      uint32_t& w = d.fx_inside[(fb + f) * d.AW + (ai >> 5)];
-      bool was = (w >> (ai & 31)) & 1u;
-      if (passes && !was) { w |= 1u << (ai & 31); presence(a, tgt, +1); }
-      else if (!passes && was) { w &= ~(1u << (ai & 31)); presence(a, tgt, -1); }
+      uint32_t& w = fx_in(f, ai);
+      bool was = (w >> (f & 31)) & 1u;
+      if (passes && !was) { w |= 1u << (f & 31); presence(a, tgt, +1); }
+      else if (!passes && was) { w &= ~(1u << (f & 31)); presence(a, tgt, -1); }
       if (passes && a[MGX_AO_MUT_COUNT] > 0) {
         MgxCtx ac = mgx_ctx(src, tgt);
         ac.deferred = true;
@@ -1494,249 +1507,28 @@ struct MgxEnvT {  // per-lane view of one env
       for (int ai = 0; ai < d.A; ai++) {
         const int tgt = d.ag_obj[ao(ai)];
         if (!a[MGX_AO_EFFECT_SELF] && src == tgt) continue;
-        uint32_t& w = d.mb_inside[(mb + m) * d.AW + (ai >> 5)];
-        bool was = (w >> (ai & 31)) & 1u;
+        uint32_t& w = mb_in(m, ai);
+        bool was = (w >> (m & 31)) & 1u;
         uint16_t s = d.obj_rc[so(src)], t = d.obj_rc[so(tgt)];
         long long dr = (int)(s >> 8) - (int)(t >> 8), dc = (int)(s & 0xFF) - (int)(t & 0xFF);
         if (dr * dr + dc * dc > range * range) {
-          if (was) { w &= ~(1u << (ai & 31)); presence(a, tgt, -1); }
+          if (was) { w &= ~(1u << (m & 31)); presence(a, tgt, -1); }
           continue;
         }
         MgxCtx c = mgx_ctx(src, tgt);
         if (check_filters<TOPQ>(a[MGX_AO_FILTER_PC], c, 0)) {
-          if (!was) { w |= 1u << (ai & 31); presence(a, tgt, +1); }
+          if (!was) { w |= 1u << (m & 31); presence(a, tgt, +1); }
           if (a[MGX_AO_MUT_COUNT] > 0) { MgxCtx ac = mgx_ctx(src, tgt); apply_all(a[MGX_AO_FILTER_PC], a[MGX_AO_MUT_START], a[MGX_AO_MUT_COUNT], ac); }
         } else if (was) {
-          w &= ~(1u << (ai & 31));
+          w &= ~(1u << (m & 31));
           presence(a, tgt, -1);
         }
       }
     }
   }
 
-  // ---- area effects, one lane per AGENT (mgx_aoe_kernel) ----
-  // When every AoE / territory handler of the program only reads and writes its TARGET (an agent) — plus things
-  // nothing changes during the phase: positions, tags, the sources' registration lists — the agents of an env are
-  // independent here and each is handled by its own lane, in the reference's per-agent order: fixed AoEs, territory
-  // (mettagrid_c.cpp:1032-1035), then the mobile sources in registration order (:1038).  The host decides
-  // (mgx_aoe_is_target_local) from the filter atoms and mutations the records can reach; everything else takes the
-  // serial form above through the handler VM.
-  __device__ __forceinline__ void mutate_local(PP m, MgxCtx& c) const {
-    const int a0 = m[MGX_MU_A0], a1 = m[MGX_MU_A1], a2 = m[MGX_MU_A2], a3 = m[MGX_MU_A3];
-    switch (m[MGX_MU_OP]) {
-      case MGX_MOP_RESOURCE_DELTA: {  // resource_mutation.hpp:25-47 (target only)
-        if (c.deferred && c.target >= 0 && !(cls_of(c.target)[MGX_C_MODIFIER_MASK] & (1 << a1))) {
-          int* dd = XL().def_delta + a1 * XL().stride + XL().lane;
-          int* meta = XL().def_delta + 13 * XL().stride + XL().lane;
-          int* cnt = XL().def_delta + 14 * XL().stride + XL().lane;
-          if (!((*meta >> a1) & 1)) { *meta |= 1 << a1; XL().def_delta[(15 + *cnt) * XL().stride + XL().lane] = a1; *cnt += 1; *dd = 0; }
-          *dd += a2;
-        } else if (c.target >= 0) {
-          inv_update<1>(c.target, a1, a2);
-        }
-        break;
-      }
-      case MGX_MOP_CLEAR_INVENTORY: {
-        const int e = c.target;
-        if (e < 0) break;
-        if (a2 == 0) {
-          unsigned long long ord = d.obj_order[so(e)];
-          for (int k = 0; k < 16; k++) {
-            int item = (int)((ord >> (4 * k)) & 0xF);
-            if (item == 0xF) break;
-            inv_update<1>(e, item, -(int)inv(e, item));
-          }
-        } else {
-          PP ids = prog() + d.sec[MGX_SEC_WORDLIST] + a1;
-          for (int i = 0; i < a2; i++) inv_update<1>(e, ids[i], -(int)inv(e, ids[i]));
-        }
-        break;
-      }
-      case MGX_MOP_CHANGE_VIBE: if (c.target >= 0) d.obj_vibe[so(c.target)] = (uint8_t)a1; break;
-      case MGX_MOP_STATS: {  // agent scope on the target
-        float v = eval_value<0>(a3, c.target, c, 0);
-        int a = agent_of(c.target);
-        if (a >= 0) astat_set(a, a2, v);
-        break;
-      }
-      case MGX_MOP_GAME_VALUE: {
-        const int e = c.target;
-        float delta = eval_value<0>(a2, e, c, 0);
-        PP V = prog() + d.sec[MGX_SEC_OBS_VALUES] + a1 * MGX_OV_WORDS;
-        PP code = prog() + d.sec[MGX_SEC_GV_CODE] + V[MGX_OV_GV_START] * MGX_GV_WORDS;
-        if (code[MGX_GV_OP] == MGX_GOP_INVENTORY) { if (e >= 0) inv_update<1>(e, code[MGX_GV_A0], (int)delta); }
-        else if (code[MGX_GV_OP] == MGX_GOP_STAT) { int a = agent_of(e); if (a >= 0) astat_add_touch(a, code[MGX_GV_A1], delta); }
-        break;
-      }
-      default: flag(4u); break;  // not reachable: the host only selects this path for the operations above
-    }
-  }
-  __device__ __forceinline__ bool apply_all_local(int filter_pc, int mut_start, int mut_count, MgxCtx& c) const {
-    if (!check_filters<0>(filter_pc, c, 0)) return false;
-    PP m = prog() + d.sec[MGX_SEC_MUTS] + mut_start * MGX_MU_WORDS;
-    for (int i = 0; i < mut_count; i++, m += MGX_MU_WORDS) mutate_local(m, c);
-    return true;
-  }
-  // the `inside` bit of agent ai for one source: lanes of a wavefront share the word, so changes are atomic
-  static __device__ __forceinline__ void inside_set(uint32_t* w, int ai, bool on) {
-    if (on) atomicOr(w, 1u << (ai & 31)); else atomicAnd(w, ~(1u << (ai & 31)));
-  }
-  // Packed source record written by mgx_aoe_prep_kernel every step: rc (16) | radius (8) << 16 | live << 24 — live = the
-  // source is registered and has an effect (territory-style AoEs without mutations and presence deltas never do).
-  static __device__ __forceinline__ bool pack_covers(uint32_t p, int r, int c) {
-    const int dr = r - (int)((p >> 8) & 0xFF), dc = c - (int)(p & 0xFF), rad = (int)((p >> 16) & 0xFF);
-    return ((p >> 24) & 1u) && dr * dr + dc * dc <= rad * rad;
-  }
-  __device__ __forceinline__ void aoe_local_agent(int ai) const {
-    const int tgt = d.ag_obj[ao(ai)];
-    const uint16_t rc = d.obj_rc[so(tgt)];
-    const int r = rc >> 8, c = rc & 0xFF;
-    // ---- per-agent on_tick (mettagrid_c.cpp:1019-1024) when it only touches its own agent: the step that precedes the
-    // area effects in _step runs here with one lane per agent instead of 64 agents deep in the lane-per-env kernel ----
-    if (d.tick_in_aoe) {
-      const int h = cls_of(tgt)[MGX_C_ON_TICK];
-      if (h >= 0) {
-        PP hd = prog() + d.sec[MGX_SEC_HANDLERS] + h * MGX_HD_WORDS;
-        MgxCtx tc = mgx_ctx(tgt, tgt);
-        apply_all_local(hd[MGX_HD_FILTER_PC], hd[MGX_HD_MUT_START], hd[MGX_HD_MUT_COUNT], tc);
-      }
-    }
-    // ---- AOETracker::apply_fixed (core/aoe_tracker.cpp:278-362) for this agent ----
-    const int nf = d.NF ? d.fx_count[envi()] : 0;
-    if (nf > 0) {
-      const size_t fb = (size_t)envi() * d.NF;
-      XL().def_delta[13 * XL().stride + XL().lane] = 0;
-      XL().def_delta[14 * XL().stride + XL().lane] = 0;
-      // Scan first, act second: a light pass over the sources leaves each lane with the bit sets of ITS sources that need
-      // work (a handful out of nf); the costly paths then run once per set bit, every lane on its own source, instead of
-      // once per source for the whole wavefront whenever any lane is in that source's range.
-      for (int f0 = 0; f0 < nf; f0 += 32) {   // every exit of this agent first (registration order)
-        uint32_t exits = 0;
-        for (int q = 0; q < 32 && f0 + q < nf; q++) {
-          const uint32_t p = d.fx_pack[fb + f0 + q];
-          const bool was = (d.fx_inside[(fb + f0 + q) * d.AW + (ai >> 5)] >> (ai & 31)) & 1u;
-          if (((p >> 24) & 1u) && was && !pack_covers(p, r, c)) exits |= 1u << q;
-        }
-        while (exits) {
-          const int f = f0 + __ffs(exits) - 1;
-          exits &= exits - 1;
-          inside_set(&d.fx_inside[(fb + f) * d.AW + (ai >> 5)], ai, false);
-          presence(aoe(d.fx_aoe[fb + f]), tgt, -1);
-        }
-      }
-      for (int f0 = 0; f0 < nf; f0 += 32) {
-        uint32_t covered = 0;
-        for (int q = 0; q < 32 && f0 + q < nf; q++)
-          if (pack_covers(d.fx_pack[fb + f0 + q], r, c)) covered |= 1u << q;
-        while (covered) {
-          const int f = f0 + __ffs(covered) - 1;
-          covered &= covered - 1;
-          PP a = aoe(d.fx_aoe[fb + f]);
-          const int src = d.fx_obj[fb + f];
-          const bool skip_self = !a[MGX_AO_EFFECT_SELF] && src == tgt;
-          MgxCtx fc = mgx_ctx(src, tgt);
-          fc.deferred = true;
-          const bool passes = !skip_self && check_filters<0>(a[MGX_AO_FILTER_PC], fc, 0);
-          uint32_t* w = &d.fx_inside[(fb + f) * d.AW + (ai >> 5)];
-          const bool was = (*w >> (ai & 31)) & 1u;
-          if (passes && !was) { inside_set(w, ai, true); presence(a, tgt, +1); }
-          else if (!passes && was) { inside_set(w, ai, false); presence(a, tgt, -1); }
-          if (passes && a[MGX_AO_MUT_COUNT] > 0) {
-            MgxCtx ac = mgx_ctx(src, tgt);
-            ac.deferred = true;
-            apply_all_local(a[MGX_AO_FILTER_PC], a[MGX_AO_MUT_START], a[MGX_AO_MUT_COUNT], ac);
-          }
-        }
-      }
-      const int cnt = XL().def_delta[14 * XL().stride + XL().lane];
-      for (int k = 0; k < cnt; k++) {
-        int res = XL().def_delta[(15 + k) * XL().stride + XL().lane];
-        int dl = XL().def_delta[res * XL().stride + XL().lane];
-        if (dl != 0) inv_update<1>(tgt, res, dl);
-      }
-    }
-    // ---- TerritoryTracker::apply_effects (core/territory_tracker.cpp:275-346); ownership from the current map ----
-    for (int ti = 0; ti < d.NT; ti++) {
-      PP TE = prog() + d.sec[MGX_SEC_TERRITORIES] + ti * MGX_TE_WORDS;
-      const uint16_t ov = d.terr_owner[((size_t)envi() * d.NT + ti) * (size_t)(d.H * d.W) + r * d.W + c];
-      const int cur = ov == 0xFFFF ? -1 : (int)ov;
-      int16_t& pv = d.terr_prev[ao(ai) * d.NT + ti];
-      const int prev = pv;
-      for (int pass = 0; pass < 3; pass++) {
-        const int tag = pass == 0 ? prev : cur;
-        const bool run = pass == 0 ? (prev != cur && prev >= 0) : pass == 1 ? (prev != cur && cur >= 0) : cur >= 0;
-        if (pass == 2) pv = (int16_t)cur;
-        if (!run) continue;
-        const int start = TE[pass == 0 ? MGX_TE_EXIT_START : pass == 1 ? MGX_TE_ENTER_START : MGX_TE_PRES_START];
-        const int count = TE[pass == 0 ? MGX_TE_EXIT_COUNT : pass == 1 ? MGX_TE_ENTER_COUNT : MGX_TE_PRES_COUNT];
-        for (int i = 0; i < count; i++) {
-          PP hd = prog() + d.sec[MGX_SEC_HANDLERS] + (start + i) * MGX_HD_WORDS;
-          MgxCtx tc = mgx_ctx(MGX_SLOT_PROXY, tgt);
-          tc.proxy_tag = tag;
-          tc.target_r = r; tc.target_c = c;
-          apply_all_local(hd[MGX_HD_FILTER_PC], hd[MGX_HD_MUT_START], hd[MGX_HD_MUT_COUNT], tc);
-        }
-      }
-    }
-    // ---- AOETracker::apply_mobile (core/aoe_tracker.cpp:364-415): this agent against every mobile source, in
-    // registration order.  Eight sources per trip: their packed records are one 32-byte load, the range tests and the
-    // `inside` words are independent, and only sources in range (or left since the last tick) take the full path. ----
-    const int nm = d.NM ? d.mb_count[envi()] : 0;
-    const size_t mb = (size_t)envi() * d.NM;
-    for (int m0 = 0; m0 < nm; m0 += 32) {   // scan 32 sources (independent loads), then visit this agent's own few
-      uint32_t todo = 0, inr = 0;
-#pragma unroll 8
-      for (int q = 0; q < 32; q++) {
-        const int m = m0 + q;
-        if (m < nm) {
-          const uint32_t p = d.mb_pack[mb + m];
-          const bool was = (d.mb_inside[(mb + m) * d.AW + (ai >> 5)] >> (ai & 31)) & 1u;
-          const bool in_range = pack_covers(p, r, c);
-          if (((p >> 24) & 1u) && (in_range || was)) todo |= 1u << q;
-          if (in_range) inr |= 1u << q;
-        }
-      }
-      while (todo) {
-        const int q = __ffs(todo) - 1;
-        todo &= todo - 1;
-        const int m = m0 + q;
-        const bool in_range = (inr >> q) & 1u;
-        const int src = d.mb_obj[mb + m];
-        PP a = aoe(d.mb_aoe[mb + m]);
-        if (!a[MGX_AO_EFFECT_SELF] && src == tgt) continue;
-        uint32_t* w = &d.mb_inside[(mb + m) * d.AW + (ai >> 5)];
-        const bool was = (*w >> (ai & 31)) & 1u;
-        if (!in_range) { if (was) { inside_set(w, ai, false); presence(a, tgt, -1); } continue; }
-        MgxCtx mc = mgx_ctx(src, tgt);
-        if (check_filters<0>(a[MGX_AO_FILTER_PC], mc, 0)) {
-          if (!was) { inside_set(w, ai, true); presence(a, tgt, +1); }
-          if (a[MGX_AO_MUT_COUNT] > 0) { MgxCtx ac = mgx_ctx(src, tgt); apply_all_local(a[MGX_AO_FILTER_PC], a[MGX_AO_MUT_START], a[MGX_AO_MUT_COUNT], ac); }
-        } else if (was) {
-          inside_set(w, ai, false);
-          presence(a, tgt, -1);
-        }
-      }
-    }
-    if (d.cov_in_aoe) track_coverage(ai);  // objects/agent.cpp:49-57; nothing moves after this phase (no game on_tick)
-  }
-  // One packed record per registered AoE source (mgx_aoe_prep_kernel, one thread per source): see pack_covers.
-  __device__ __forceinline__ void aoe_pack_source(int k) const {
-    const bool fixed = k < d.NF;
-    const int i = fixed ? k : k - d.NF;
-    const size_t q = (size_t)envi() * (fixed ? d.NF : d.NM) + i;
-    const int n = fixed ? (d.NF ? d.fx_count[envi()] : 0) : (d.NM ? d.mb_count[envi()] : 0);
-    uint32_t p = 0;
-    if (i < n) {
-      const int obj = fixed ? d.fx_obj[q] : d.mb_obj[q];
-      if (obj != 0xFFFF) {
-        PP a = aoe(fixed ? d.fx_aoe[q] : d.mb_aoe[q]);
-        const uint16_t rc = fixed ? d.fx_rc[q] : d.obj_rc[so(obj)];  // fixed: location at registration (:166-200)
-        const bool effect = !fixed || a[MGX_AO_MUT_COUNT] > 0 || a[MGX_AO_PRES_COUNT] > 0;
-        p = (uint32_t)rc | ((uint32_t)(a[MGX_AO_RADIUS] & 0xFF) << 16) | (effect ? 1u << 24 : 0u);
-      }
-    }
-    if (fixed) d.fx_pack[q] = p; else d.mb_pack[q] = p;
-  }
+  // (area effects with one lane per AGENT — mgx_aoe_kernel — live in mgx_aoe_local.h: a register / LDS resident copy of
+  // the agent the lane owns, on which the same filter / mutation records are interpreted)
 
   // ---- territory (core/territory_tracker.cpp) ----
   __device__ int cell_owner(int r, int c, int ti) const {  // compute_cell_ownership :215-252 -> winning tag or -1
@@ -2339,9 +2131,16 @@ size_t mgx_world_x_lds_bytes(int A, bool aoe_lds);
 size_t mgx_world_x_private_bytes();
 void mgx_launch_values(hipStream_t stream, const MgxDev& d, const MgxDev* dev_copy, int phase, const uint8_t* env_mask);
 // lane-per-agent area effects (mgx_aoe.hip) and the host analysis that allows them
-void mgx_launch_aoe(hipStream_t stream, const MgxDev& d, const MgxDev* dev_copy);
+// (dev_copy: absolute section offsets, for the source-record kernel; hot_copy + prog_words: the copy whose hot sections are
+// relative to the kernel's LDS program copy, or nullptr / 0 when the program stays in HBM / L2)
+void mgx_launch_aoe(hipStream_t stream, const MgxDev& d, const MgxDev* dev_copy, const MgxDev* hot_copy, int prog_words);
 bool mgx_aoe_is_target_local(const int32_t* program);
 bool mgx_aoe_on_tick_local(const int32_t* program);  // + every per-agent on_tick handler is a leaf that only touches its own agent
+bool mgx_aoe_set_lds(int nstat, int prog_words);
+#ifdef __cplusplus
+#include <vector>
+void mgx_aoe_collect_stats(const int32_t* program, bool with_on_tick, bool with_coverage, std::vector<int16_t>& out);
+#endif
 
 #ifndef MGX_WORLD_FAST_TU
 // Construction: MettaGrid ctor + _init_grid (mettagrid_c.cpp:42-191, 200-269).  One lane per env scans the class

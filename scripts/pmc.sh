@@ -8,13 +8,13 @@ OUT="$ROOT/gpurun_out/${1:-pmc}"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 echo "[pmc] kernel trace"
-timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o run -- python3 "$ROOT/bench.py" --steps 30 --warmup 5 --no-cpu $BENCH_ARGS > "$OUT/trace.log" 2>&1 || { echo "[pmc] kernel trace failed"; tail -5 "$OUT/trace.log"; exit 1; }
+timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o run -- python3 "$ROOT/bench.py" --steps 30 --warmup 5 --no-cpu --no-extras $BENCH_ARGS > "$OUT/trace.log" 2>&1 || { echo "[pmc] kernel trace failed"; tail -5 "$OUT/trace.log"; exit 1; }
 grep -o '"value": [0-9.]*' "$OUT/trace.log" | head -1
 i=0
 while read -r group; do
   [ -z "$group" ] && continue
   i=$((i+1))
-  if timeout -k 10 180 rocprofv3 --kernel-trace --pmc $group --output-format csv -d "$OUT/g$i" -o run -- python3 "$ROOT/bench.py" --steps 6 --warmup 2 --no-cpu $BENCH_ARGS > "$OUT/g$i.log" 2>&1; then
+  if timeout -k 10 180 rocprofv3 --kernel-trace --pmc $group --output-format csv -d "$OUT/g$i" -o run -- python3 "$ROOT/bench.py" --steps 6 --warmup 2 --no-cpu --no-extras $BENCH_ARGS > "$OUT/g$i.log" 2>&1; then
     echo "[pmc] group $i ok: $group"
   else
     echo "[pmc] group $i FAILED: $group"; grep -m3 -i "error\|fail" "$OUT/g$i.log"

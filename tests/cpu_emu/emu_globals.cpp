@@ -3,6 +3,6 @@
 thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
 alignas(16) uint8_t mgx_dyn_lds[160 * 1024];  // dynamic LDS of the world kernels
 alignas(16) uint8_t smem[160 * 1024];         // dynamic LDS of the (not emulated) observation kernel
-alignas(16) uint8_t aoe_lds[64 * 1024];     // dynamic LDS of mgx_aoe_kernel
+alignas(16) uint8_t aoe_lds[160 * 1024];     // dynamic LDS of mgx_aoe_kernel
 // the token-decode kernel is wavefront-cooperative (ballot / shuffles): not part of the sanitizer build
 int mgx_launch_decode(hipStream_t, const uint8_t*, float*, const float*, long long, int, int, int, int) { return -2; }

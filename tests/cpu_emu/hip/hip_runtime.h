@@ -100,6 +100,7 @@ static inline float __int_as_float(int u) { float f; memcpy(&f, &u, 4); return f
 static inline int __popc(uint32_t x) { return __builtin_popcount(x); }
 static inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 static inline int __ffs(uint32_t x) { return __builtin_ffs((int)x); }
+static inline int __ffsll(unsigned long long x) { return __builtin_ffsll((long long)x); }
 static inline int __mul24(int a, int b) { return a * b; }
 static inline unsigned long long clock64() { return 0; }
 template <class T> static inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
