@@ -21,7 +21,10 @@
 #ifdef MGX_CPU_EMU
 #define MGX_AOE_OCCUPANCY
 #else
-#define MGX_AOE_OCCUPANCY __attribute__((amdgpu_waves_per_eu(3, 4)))
+#ifndef MGX_AOE_WPE
+#define MGX_AOE_WPE 3, 4
+#endif
+#define MGX_AOE_OCCUPANCY __attribute__((amdgpu_waves_per_eu(MGX_AOE_WPE)))
 #endif
 // One wavefront per env, lane = agent (MgxLocalAgent, mgx_aoe_local.h).  Between the pieces of the phase the lanes of the
 // wavefront stage the env's source records in LDS, 64 at a time: s_pack (location | radius | live), s_info (object | AoE
@@ -55,6 +58,7 @@ __global__ void __launch_bounds__(MGX_AOE_THREADS) MGX_AOE_OCCUPANCY mgx_aoe_ker
   __syncthreads();
 #endif
   if (env >= d.E) return;
+  MGX_TICK0();
   typedef typename std::conditional<PROG_LDS, MgxLdsProg, MgxGlobalProg>::type PP;
   typedef MgxEnvT<PP, true> Env;
   PP prog;
@@ -88,8 +92,10 @@ __global__ void __launch_bounds__(MGX_AOE_THREADS) MGX_AOE_OCCUPANCY mgx_aoe_ker
     MgxLocalAgent<Env> ag(e);
     if (valid) {
       ag.load(ai, s_val, s_map, s_ids, s_def);
+      MGX_TICK(0);
       if (d.tick_in_aoe) ag.on_tick();
     }
+    MGX_TICK(1);
     if (nf > 0) {
       for (int pass = 0; pass < 2; pass++)
         for (int f0 = 0; f0 < nf; f0 += MGX_WAVE) {
@@ -98,15 +104,20 @@ __global__ void __launch_bounds__(MGX_AOE_THREADS) MGX_AOE_OCCUPANCY mgx_aoe_ker
         }
       if (valid) ag.fixed_finish();
     }
+    MGX_TICK(2);
     if (valid && d.NT > 0) ag.territory();
+    MGX_TICK(3);
     for (int m0 = 0; m0 < nm; m0 += MGX_WAVE) {
       stage(d.mb_pack, d.mb_obj, d.mb_aoe, mb, m0, nm);
       if (valid) ag.mobile_chunk(m0, min(MGX_WAVE, nm - m0), s_pack, s_info);
     }
+    MGX_TICK(4);
     if (valid) {
       if (d.cov_in_aoe) ag.coverage();
+      MGX_TICK(5);
       ag.store();
     }
+    MGX_TICK(6);
   }
 }
 
@@ -357,3 +368,12 @@ void mgx_aoe_collect_stats(const int32_t* P, bool with_on_tick, bool with_covera
   out.clear();
   for (int id : all) if ((int)out.size() < MGX_AOE_MAX_STATS) out.push_back((int16_t)id);
 }
+
+#ifdef MGX_WORLD_TIMING  // instrumented developer build only (scripts/aoe_timing.py); not part of the ABI
+extern "C" int mgx_debug_aoe_cycles(unsigned long long* out, int reset) {
+  hipDeviceSynchronize();
+  hipMemcpyFromSymbol(out, HIP_SYMBOL(mgx_tu_aoe::mgx_dbg_cycles), sizeof(unsigned long long) * 16);
+  if (reset) { unsigned long long z[16] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(mgx_tu_aoe::mgx_dbg_cycles), z, sizeof z); }
+  return 0;
+}
+#endif
