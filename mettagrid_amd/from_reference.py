@@ -45,9 +45,8 @@ class _Lowering:
         if n == "InventoryValueConfig":
             return S.InventoryValue(self.res[v.id])
         if n == "StatValueConfig":
-            if getattr(v, "delta", False):
-                raise UnsupportedFeature("StatValue(delta=True) is not supported")
-            return S.StatValue(v.stat_name, "agent" if v.scope == C.GameValueScope.AGENT else "game")
+            return S.StatValue(v.stat_name, "agent" if v.scope == C.GameValueScope.AGENT else "game",
+                               delta=bool(getattr(v, "delta", False)))   # (no effect in the reference engine: spec.StatValue)
         if n == "ConstValueConfig":
             return S.ConstValue(float(v.value))
         if n == "SumValueConfig":
@@ -258,8 +257,10 @@ class _Lowering:
                                     self.mutations(ev.mutations), None if int(ev.max_targets) < 0 else int(ev.max_targets),
                                     ev.fallback or None)
                   for name, ev in cfg.events.items()}
-        territories = {terr_names[i]: S.TerritorySpec("", [self.leaf(h) for h in t.on_enter], [self.leaf(h) for h in t.on_exit],
-                                                      [self.leaf(h) for h in t.presence], tags=self.tag_names(t.tag_prefix_ids))
+        territories = {terr_names[i]: S.TerritorySpec("", tags=self.tag_names(t.tag_prefix_ids),
+                                                      on_enter=[self.leaf(h) for h in t.on_enter],
+                                                      on_exit=[self.leaf(h) for h in t.on_exit],
+                                                      presence=[self.leaf(h) for h in t.presence])
                        for i, t in enumerate(cfg.territories)}
         all_tag_names = [self.tags[i] for i in sorted(self.tags)]
         return S.GameSpec(

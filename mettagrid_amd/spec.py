@@ -30,6 +30,12 @@ class InventoryValue:
 class StatValue:
     name: str
     scope: str = "agent"  # "agent" | "game"
+    # StatValueConfig.delta (core/game_value_config.hpp:27).  Carried for the config boundary; the engine ignores it because
+    # the reference does: every consumer resolves the value afresh (handler_context.cpp:8-14, reward.hpp:49 with a const
+    # read(), mettagrid_c.cpp:1219) into a ResolvedGameValue whose baseline prev_value starts at 0 and is only moved by
+    # read_delta() / reset_delta() (core/resolved_game_value.hpp:28-42), which nothing calls — read() of a delta value is
+    # current - 0.  tests/golden/delta_s*.npz pins that against the reference engine.
+    delta: bool = False
 
 
 @dataclass

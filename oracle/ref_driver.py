@@ -67,6 +67,7 @@ class _Lower:
             c = m.StatValueConfig()
             c.scope = m.GameValueScope.AGENT if v.scope == "agent" else m.GameValueScope.GAME
             c.stat_name = v.name
+            c.delta = bool(getattr(v, "delta", False))
             return c
         if isinstance(v, S.ConstValue):
             c = m.ConstValueConfig()

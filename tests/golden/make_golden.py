@@ -24,7 +24,7 @@ from mettagrid_amd import signature as sg  # noqa: E402
 from mettagrid_amd.compiler import compile_spec  # noqa: E402
 
 SEEDS = {"rung1": [42], "rung1_invalid": [43], "rung2": [0, 1], "rung3": [0, 1], "rung3_flat_damage": [10],
-         "torture": [0, 1], "torture_terminal": [2], "rung4": [0, 1], "rung4_truncating": [2], "rung4_full": [0], "dynamic": [0, 1], "wide": [0], "crowd": [0], "torture_base10": [3], "keyhole": [1], "letterbox": [1], "minmax": [0, 4], "thirteen": [0, 2], "lit": [0, 1]}
+         "torture": [0, 1], "torture_terminal": [2], "rung4": [0, 1], "rung4_truncating": [2], "rung4_full": [0], "dynamic": [0, 1], "wide": [0], "crowd": [0], "torture_base10": [3], "keyhole": [1], "letterbox": [1], "minmax": [0, 4], "thirteen": [0, 2], "lit": [0, 1], "delta": [0, 1]}
 
 
 def main() -> None:

@@ -453,3 +453,30 @@ def lit_map(seed: int) -> np.ndarray:
 
 
 SCENARIOS["lit"] = (lit_spec, lit_map, 40, False)
+
+
+def delta_spec() -> S.GameSpec:
+    """StatValue(delta=True) everywhere a game value can stand — a top-level reward entry (tests/test_reward_config.py:85 of the
+    reference), a per-tick entry nested in a sum, an observation value, a filter threshold, the source of a SetStat.  The
+    reference engine resolves every value afresh, so the delta baseline is never consumed and the flag changes nothing
+    (mettagrid_amd/spec.py StatValue); the goldens of this scenario come from the real engine."""
+    import dataclasses
+    base = torture_spec(40, True)
+    forged = S.StatValue("forged", "agent", delta=True)
+    agents = []
+    for a in base.agents:
+        rewards = [S.RewardSpec(forged),
+                   S.RewardSpec(S.SumValue([S.StatValue("ore.gained", "agent", delta=True), S.InventoryValue("hp")], [0.2, 0.01]), per_tick=True),
+                   S.RewardSpec(S.StatValue("ticks", "game", delta=True))]
+        agents.append(dataclasses.replace(a, rewards=rewards))
+    A = S.ACTOR
+    gate = S.Handler([S.GameValueFilter(A, S.InventoryValue("hp"), S.StatValue("forged", "agent", delta=True))],
+                     [S.ResourceDelta(A, "energy", 2), S.SetStat("forged.seen", S.StatValue("forged", "agent", delta=True), scope="agent", entity=A)], "gate")
+    objects = dict(base.objects)
+    objects["shrine"] = dataclasses.replace(objects["shrine"], on_use=gate)
+    obs = dataclasses.replace(base.obs, values={"d_forged": forged, "d_gain": S.StatValue("ore.gained", "agent", delta=True)})
+    return dataclasses.replace(base, agents=agents, objects=objects, obs=obs,
+                               on_tick=S.Handler([], [S.SetStat("ticks", S.SumValue([S.StatValue("ticks", "game"), S.ConstValue(1.0)]))]))
+
+
+SCENARIOS["delta"] = (delta_spec, torture_map, 45, False)
