@@ -411,7 +411,7 @@ def main() -> None:
     ap.add_argument("--cpu-steps", type=int, default=0, help="CPU baseline sample (default: about 10 s of one host core)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="headline only: skip the rung-4 object and the env-wrapper throughput")
-    ap.add_argument("--rung4-steps", type=int, default=30)
+    ap.add_argument("--rung4-steps", type=int, default=100)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -445,7 +445,7 @@ def main() -> None:
     del cms
     r4 = wrap = None
     if extras:
-        r4 = measure(4, cms4, steps=args.rung4_steps, warmup=5, rounds=min(5, args.rung4_steps), **common)
+        r4 = measure(4, cms4, steps=args.rung4_steps, warmup=20, rounds=min(5, args.rung4_steps), **common)
         del cms4
         wrap = env_wrapper_throughput(args.envs, 100, local_rank)
 

@@ -140,6 +140,11 @@ int mgx_get_stats(mgx_engine* e, int32_t env, float* game_values, uint8_t* game_
  * memory; pairs with n == 0 are unused. */
 int mgx_get_invalid_index_extra(mgx_engine* e, int32_t env, int32_t* k_out, float* n_out);
 int mgx_get_objects(mgx_engine* e, int32_t env, int32_t* out, int32_t* n_objects);
+/* The same records for a LIST of envs with one kernel and one copy — what a replay writer or a signature sweep wants
+ * (python/src/mettagrid/simulator/replay_log_writer.py calls grid_objects() every step): envs int32 [n_envs] host memory
+ * (any order, repeats allowed), out int32 [n_envs][MAX_OBJECTS][MGX_OBJ_RECORD_WORDS] host memory (records past an env's
+ * count are not written), n_objects int32 [n_envs]. */
+int mgx_get_objects_batch(mgx_engine* e, const int32_t* envs, int32_t n_envs, int32_t* out, int32_t* n_objects);
 /* current_stat_reward per agent of env `env` (RewardHelper::current_reward, systems/reward.hpp:36-42). f32 [A]. */
 int mgx_get_reward_state(mgx_engine* e, int32_t env, float* out);
 
@@ -187,6 +192,9 @@ int mgx_set_profiling(mgx_engine* e, int32_t enabled);
 int mgx_get_step_timing(mgx_engine* e, float* ms_out /* [MGX_T_COUNT] */);
 
 /* Shape queries. */
+/* Which instance of the observation kernel the engine launches: 0 = the generic one (shape read at run time), 3 = the
+ * instance compiled for the shape of BASELINE.json configs[2] (mettagrid_amd/gen_presets.py). Diagnostic. */
+int32_t mgx_obs_variant(const mgx_engine* e);
 int32_t mgx_num_envs(const mgx_engine* e);
 int32_t mgx_num_agents(const mgx_engine* e);   /* per env */
 int32_t mgx_num_tokens(const mgx_engine* e);

@@ -13,6 +13,7 @@
 #include "mgx.h"
 #include "mgx_device.h"
 #include "mgx_obs.h"
+#include "mgx_presets_gen.h"   // MgxObsShapeR3 / R4: the benchmark presets' shapes (mettagrid_amd/gen_presets.py, written at build())
 #include "mgx_world.h"
 #include "mgx_aoe_local.h"
 
@@ -145,6 +146,42 @@ __global__ void __launch_bounds__(MGX_WAVE) mgx_digest_kernel(const MgxDev* __re
   out[env] = h;
 }
 
+// ---- batched object export (the replay-writer shape of grid_objects(), cpp/bindings/mettagrid_py.cpp:28-139) ----
+// One workgroup per LISTED env, one thread per object slot: the slot's mgx_get_objects record (MGX_OBJ_RECORD_WORDS int32,
+// layout in include/mgx.h) goes to a packed device buffer [n_envs][S][words] that the host fetches with one copy.
+__global__ void __launch_bounds__(256) mgx_objects_kernel(const MgxDev* __restrict__ dp, const int32_t* __restrict__ envs, int32_t* __restrict__ out,
+                                                          int32_t* __restrict__ counts) {
+  const MgxDev& d = *dp;
+  const int env = envs[blockIdx.x];
+  MgxEnvX e(d, d.P, env);
+  const int n = (int)d.num_objs[env];
+  if (threadIdx.x == 0) counts[blockIdx.x] = n;
+  for (int s = (int)threadIdx.x; s < n; s += (int)blockDim.x) {
+    int32_t* w = out + ((size_t)blockIdx.x * d.S + s) * MGX_OBJ_RECORD_WORDS;
+    const size_t o = e.so(s);
+    const uint16_t cls = d.obj_cls[o], rc = d.obj_rc[o];
+    const uint8_t oflags = d.obj_flags ? d.obj_flags[o] : 0;
+    const uint8_t ag = d.obj_agent[o];
+    const unsigned long long ord = d.obj_order[o];
+    w[0] = s + 1; w[1] = cls; w[2] = rc >> 8; w[3] = rc & 0xFF; w[4] = d.obj_vibe[o];
+    w[5] = (cls != MGX_DEAD_CLASS && !(oflags & 1)) ? 1 : 0;
+    w[6] = ag == MGX_NO_AGENT ? -1 : (int)ag;
+    int cnt = 0;
+    bool ended = false;
+    for (int k = 0; k < MGX_MAX_RESOURCES; k++) {
+      const int item = (int)((ord >> (4 * k)) & 0xF);
+      ended = ended || item == 0xF;
+      w[8 + k] = ended ? -1 : item;
+      cnt += ended ? 0 : 1;
+    }
+    w[7] = cnt;
+    for (int k = 0; k < MGX_MAX_RESOURCES; k++) w[8 + MGX_MAX_RESOURCES + k] = k < d.R ? (int)d.obj_inv[o * MGX_INV_PITCH + k] : 0;
+    for (int k = 0; k < MGX_TAG_WORDS; k++)
+      w[8 + 2 * MGX_MAX_RESOURCES + k] = d.obj_tags ? (int32_t)d.obj_tags[o * MGX_TAG_WORDS + k]
+                                                    : (cls != MGX_DEAD_CLASS ? mgx_cls(d, cls)[MGX_C_TAGS + k] : 0);
+  }
+}
+
 // token decode kernel (mgx_decode.hip)
 int mgx_launch_decode(hipStream_t stream, const uint8_t* tokens, float* box, const float* scale_dev, long long rows, int T, int C, int H, int W);
 
@@ -187,6 +224,7 @@ struct mgx_engine {
   bool external = false;
   size_t lds_world = 0, lds_obs = 0;
   int obs_threads = MGX_OBS_THREADS, obs_ew = MGX_OBS_THREADS / MGX_WAVE;
+  int obs_variant = 0;   // 0: generic observation kernel; 3: the instance specialised for the shape of BASELINE.json configs[2]
   int pool_tokens = 0;   // capacity of the LDS token pool (entries), including the class-tag prefix
   int pool_prefix = 0;   // entries of the per-class static tag table at the head of the pool
   bool prog_in_lds = false;
@@ -244,6 +282,8 @@ struct mgx_engine {
   int pool_stride = 1;
   uint32_t step_seq = 0;
   unsigned long long* d_digest = nullptr;   // [E] mgx_state_digests
+  int32_t* d_objs = nullptr;        // mgx_get_objects_batch: env list | counts | packed records
+  size_t objs_cap = 0;              // envs the buffer holds
   float* d_scale = nullptr;         // per-feature scale of the token decode (mgx_decode_obs)
   float scale_host[256] = {};
   bool scale_valid = false;
@@ -303,6 +343,12 @@ static int size_obs_lds(mgx_engine* e) {
       if (lds_for(ew) <= 53760) { e->obs_ew = ew; break; }
   }
   e->lds_obs = lds_for(e->obs_ew);
+  e->obs_variant = 0;
+  if (!getenv("MGX_OBS_GENERIC")) {
+    if (!d.X && e->obs_blk_lds && mgx_obs_shape_matches<MgxObsShapeR3>(d, e->obs_blk_words, (int)e->rewards_early)) e->obs_variant = 3;
+    // (an instance for the shape of configs[3], MgxObsShapeR4, was measured too: 5.07 ms against the generic kernel's 5.01 —
+    // the extended kernel's time is barrier and LDS latency, not scalar arithmetic; it is not built)
+  }
   if (e->lds_obs > 160 * 1024)
     return fail(MGX_ERR_PROGRAM, "map/object count too large for the LDS staging of the observation kernel");
   if (e->verbose || getenv("MGX_VERBOSE"))
@@ -316,7 +362,9 @@ static int size_obs_lds(mgx_engine* e) {
   size_t& cur_max = cur_max_dev[e->device];
   std::lock_guard<std::mutex> lock(mu);
   if (e->lds_obs > cur_max) {
-    const void* fns[] = {(const void*)mgx_obs_kernel<true, false, false>, (const void*)mgx_obs_kernel<false, false, false>,
+    const void* fns[] = {(const void*)mgx_obs_kernel<true, false, true, MGX_OBS_THREADS, MGX_OBS_THREADS / MGX_WAVE, MgxObsShapeR3>,
+                         (const void*)mgx_obs_kernel<false, false, true, MGX_OBS_THREADS, MGX_OBS_THREADS / MGX_WAVE, MgxObsShapeR3>,
+                         (const void*)mgx_obs_kernel<true, false, false>, (const void*)mgx_obs_kernel<false, false, false>,
                          (const void*)mgx_obs_kernel<true, false, true>,  (const void*)mgx_obs_kernel<false, false, true>,
                          (const void*)mgx_obs_kernel<true, true, false>,  (const void*)mgx_obs_kernel<false, true, false>,
                          (const void*)mgx_obs_kernel<true, true, false, 512, 4>, (const void*)mgx_obs_kernel<false, true, false, 512, 4>,
@@ -328,16 +376,16 @@ static int size_obs_lds(mgx_engine* e) {
   return MGX_OK;
 }
 
-template <bool X, bool PL, int NTH = MGX_OBS_THREADS, int EW = NTH / MGX_WAVE>
+template <bool X, bool PL, int NTH = MGX_OBS_THREADS, int EW = NTH / MGX_WAVE, class K = MgxObsShapeDyn>
 static void launch_obs_t(mgx_engine* e, bool with_rewards, const uint8_t* mask) {
   dim3 grid(e->d.E), block(NTH);
   MgxDev dd = e->d;
   if (PL)  // the interpreted sections are addressed relative to their LDS copy
     for (int k = MGX_SEC_INV_FEATURES; k < MGX_SEC_WORDLIST; k++) dd.sec[k] -= e->obs_blk_start;
   if (with_rewards)
-    hipLaunchKernelGGL((mgx_obs_kernel<true, X, PL, NTH, EW>), grid, block, e->lds_obs, e->stream, dd, e->pool_tokens, e->pool_prefix, mask, e->obs_blk_start, e->obs_blk_words, (int)e->rewards_early);
+    hipLaunchKernelGGL((mgx_obs_kernel<true, X, PL, NTH, EW, K>), grid, block, e->lds_obs, e->stream, dd, e->pool_tokens, e->pool_prefix, mask, e->obs_blk_start, e->obs_blk_words, (int)e->rewards_early);
   else
-    hipLaunchKernelGGL((mgx_obs_kernel<false, X, PL, NTH, EW>), grid, block, e->lds_obs, e->stream, dd, e->pool_tokens, e->pool_prefix, mask, e->obs_blk_start, e->obs_blk_words, (int)e->rewards_early);
+    hipLaunchKernelGGL((mgx_obs_kernel<false, X, PL, NTH, EW, K>), grid, block, e->lds_obs, e->stream, dd, e->pool_tokens, e->pool_prefix, mask, e->obs_blk_start, e->obs_blk_words, (int)e->rewards_early);
 }
 // Device-memory copy of e->d, brought up to date (stream-ordered) whenever the host table changed.
 static const MgxDev* dev_copy(mgx_engine* e) {
@@ -392,7 +440,9 @@ static int launch_obs(mgx_engine* e, bool with_rewards, const uint8_t* mask = nu
   if (e->d.obsval) mgx_launch_values(e->stream, e->d, dev_copy(e), 0, mask);
   MGX_TRACE_POINT(e, "values kernel");
   if (e->rewards_ext) with_rewards = false;
-  if (e->d.X && e->obs_threads == 512 && e->obs_ew == 4) launch_obs_t<true, false, 512, 4>(e, with_rewards, mask);
+  // a program whose shape equals a preset's runs that preset's instance of the kernel (shape = compile-time constants)
+  if (e->obs_variant == 3) launch_obs_t<false, true, MGX_OBS_THREADS, MGX_OBS_THREADS / MGX_WAVE, MgxObsShapeR3>(e, with_rewards, mask);
+  else if (e->d.X && e->obs_threads == 512 && e->obs_ew == 4) launch_obs_t<true, false, 512, 4>(e, with_rewards, mask);
   else if (e->d.X && e->obs_threads == 512 && e->obs_ew == 3) launch_obs_t<true, false, 512, 3>(e, with_rewards, mask);
   else if (e->d.X && e->obs_threads == 512) launch_obs_t<true, false, 512, 2>(e, with_rewards, mask);
   else if (e->d.X) launch_obs_t<true, false>(e, with_rewards, mask);
@@ -902,6 +952,7 @@ void mgx_destroy(mgx_engine* e) {
   for (void* p : e->allocs) (void)hipFree(p);
   if (e->d_pool) (void)hipFree(e->d_pool);
   if (e->d_stage) (void)hipFree(e->d_stage);
+  if (e->d_objs) (void)hipFree(e->d_objs);
   if (e->h_flags) (void)hipHostFree(e->h_flags);
   for (int i = 0; i <= MGX_T_COUNT; i++) if (e->ev[i]) (void)hipEventDestroy(e->ev[i]);
   if (e->world_done) (void)hipEventDestroy(e->world_done);
@@ -1411,6 +1462,33 @@ int mgx_get_objects(mgx_engine* e, int32_t env, int32_t* out, int32_t* n_objects
   return MGX_OK;
 }
 
+int mgx_get_objects_batch(mgx_engine* e, const int32_t* envs, int32_t n_envs, int32_t* out, int32_t* n_objects) {
+  if (!e || !envs || !out || !n_objects || n_envs <= 0) return fail(MGX_ERR_BAD_ARG, "mgx_get_objects_batch: bad argument");
+  const MgxDev& d = e->d;
+  for (int i = 0; i < n_envs; i++)
+    if (envs[i] < 0 || envs[i] >= d.E) return fail(MGX_ERR_BAD_ARG, "mgx_get_objects_batch: env index out of range");
+  HIP_TRY(hipSetDevice(e->device));
+  const size_t rec = (size_t)d.S * MGX_OBJ_RECORD_WORDS, n = (size_t)n_envs;
+  if (n > e->objs_cap) {
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (e->d_objs) (void)hipFree(e->d_objs);
+    e->d_objs = nullptr;
+    e->objs_cap = 0;
+    HIP_TRY(hipMalloc((void**)&e->d_objs, n * (2 + rec) * 4));
+    e->objs_cap = n;
+  }
+  int32_t* d_envs = e->d_objs;
+  int32_t* d_counts = e->d_objs + e->objs_cap;
+  int32_t* d_recs = e->d_objs + 2 * e->objs_cap;
+  HIP_TRY(hipMemcpyAsync(d_envs, envs, n * 4, hipMemcpyHostToDevice, e->stream));
+  hipLaunchKernelGGL(mgx_objects_kernel, dim3((unsigned)n), dim3(256), 0, e->stream, dev_copy(e), (const int32_t*)d_envs, d_recs, d_counts);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(n_objects, d_counts, n * 4, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipMemcpyAsync(out, d_recs, n * rec * 4, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return MGX_OK;
+}
+
 int mgx_get_reward_state(mgx_engine* e, int32_t env, float* out) {
   if (!e || !out || env < 0 || env >= e->d.E) return fail(MGX_ERR_BAD_ARG, "mgx_get_reward_state: bad argument");
   const MgxDev& d = e->d;
@@ -1578,6 +1656,7 @@ int mgx_get_step_timing(mgx_engine* e, float* ms_out) {
   return MGX_OK;
 }
 
+int32_t mgx_obs_variant(const mgx_engine* e) { return e ? e->obs_variant : 0; }
 int32_t mgx_num_envs(const mgx_engine* e) { return e ? e->d.E : 0; }
 int32_t mgx_num_agents(const mgx_engine* e) { return e ? e->d.A : 0; }
 int32_t mgx_num_tokens(const mgx_engine* e) { return e ? e->d.T : 0; }

@@ -94,10 +94,11 @@ struct MgxBase {
 //   grid u16[HW] | offsets i8x2[NOFF] | loc u8[CP] (packed window coordinate of offset j) | minobs u32[S+1] |
 //   visited u32[S] | tokinfo u32[S] (start | count << 16) | dyn u16[S] (slots whose token list is built per step) |
 //   agents u32[A] (slot | rc << 16) | aginfo u32[A] | spawn u16[A] | vstat f32[A] | written i32[A] |
-//   rwinfo u32[A] (reward start | count << 16) | misc u32[4] | pool u16[POOL+8] | rows u32[WAVES*4][Tpad+16] |
+//   rwinfo u32[A] (reward start | count << 16) | misc u32[4] | rows u32[WAVES*4][Tpad+16] |
 //   cell u16[A][CP], vj u8[A][CP], vcount u32[A]: per agent the occupied window cells in window order (slot + 1 and
 //   window index j of each), compacted | X: vmask u8[A][CP] territory token of each listed cell, obs values |
-//   blk i32[blk_words]: program sections INV_FEATURES..OBS_VALUES (PL variants only) | gtok u32[A][GT] global tokens
+//   blk i32[blk_words]: program sections INV_FEATURES..OBS_VALUES (PL variants only) | gtok u32[A][GT] global tokens |
+//   pool u16[POOL+8] per-object token lists (lean games: last; extended games: behind misc)
 // CP = NOFF rounded up to 16: stride of the per-agent lists.
 __host__ __device__ inline int mgx_align16(int x) { return (x + 15) & ~15; }
 struct MgxObsLds {
@@ -141,7 +142,11 @@ __host__ __device__ inline MgxObsLds mgx_obs_lds_layout(int HW, int NOFF, int S,
   l.written = o; o += mgx_align16(A * 4);
   l.rwinfo = o; o += mgx_align16(A * 4);
   l.misc = o; o += 16;
-  l.pool = o; o += mgx_align16((pool_tokens + 8) * 2);
+  // The token pool's size follows the maps (run-time); every other region only the program's shape.  Lean games put it
+  // LAST, so that a kernel specialised for a shape (MgxObsShape) has every other offset as a compile-time constant; the
+  // extended variant keeps it here (measured at rung 4: 4.76 ms here, 5.01 ms at the end of the layout).
+  const bool pool_last = !X;
+  if (!pool_last) { l.pool = o; o += mgx_align16((pool_tokens + 8) * 2); }
   l.row_words = (T + 3) & ~3;
   l.row_pitch = l.row_words + 16;  // + one trash word per lane of a 16-lane row: masked-off stores land there
 #ifndef MGX_OBS_PITCH_OLD
@@ -176,6 +181,7 @@ __host__ __device__ inline MgxObsLds mgx_obs_lds_layout(int HW, int NOFF, int S,
   }
   if (!blk_early) { l.blk = o; o += mgx_align16(blk_words * 4); }
   l.gtok = o; o += mgx_align16(A * GT * 4);
+  if (pool_last) { l.pool = o; o += mgx_align16((pool_tokens + 8) * 2); }
   l.total = o;
   return l;
 }
@@ -183,6 +189,33 @@ __host__ __device__ inline MgxObsLds mgx_obs_lds_layout(int HW, int NOFF, int S,
 // Wavefront sum (every lane gets the total).
 __device__ __forceinline__ uint32_t mgx_wave_sum(uint32_t x) {
   return (uint32_t)__builtin_amdgcn_readlane(mgx_wave_incl_scan((int)x), MGX_WAVE - 1);
+}
+
+// Shape policy of the kernel.  MgxObsShapeDyn: every size comes from the engine's table at run time (any program).
+// MgxObsShape<...>: the sizes of ONE compiled program as compile-time constants — map, agents, slots, token budget,
+// window, value base, interpreted block, global-token flags — generated for the benchmark presets at build() time
+// (mgx_presets_gen.h); the engine launches that instance when a program's shape equals it (mgx_create) and the generic
+// one otherwise.  With the shape fixed the LDS layout offsets, the loop bounds over agents / window cells and the index
+// arithmetic are immediates: the generic kernel spent as many scalar as vector instructions, most of them on exactly
+// that arithmetic, and ~290 v_readlane reloads of spilled layout offsets.
+struct MgxObsShapeDyn {
+  static constexpr bool fixed = false;
+  static constexpr int H = 0, W = 0, A = 0, S = 0, T = 0, NOFF = 0, BASE = 0, NOV = 0, NT = 0, NRW = 0, FLAGS = 0, MAX_STEPS = 0, BLKW = 0,
+                       MASK_FEAT = 0, REWARDS_EARLY = 0;
+};
+template <int H_, int W_, int A_, int S_, int T_, int NOFF_, int BASE_, int NOV_, int NT_, int NRW_, int FLAGS_, int MAX_STEPS_, int BLKW_,
+          int MASK_FEAT_, int REWARDS_EARLY_>
+struct MgxObsShape {
+  static constexpr bool fixed = true;
+  static constexpr int H = H_, W = W_, A = A_, S = S_, T = T_, NOFF = NOFF_, BASE = BASE_, NOV = NOV_, NT = NT_, NRW = NRW_, FLAGS = FLAGS_,
+                       MAX_STEPS = MAX_STEPS_, BLKW = BLKW_, MASK_FEAT = MASK_FEAT_, REWARDS_EARLY = REWARDS_EARLY_;
+};
+// does an engine table + launch parameters have this shape?  (host)
+template <class K>
+inline bool mgx_obs_shape_matches(const MgxDev& d, int blk_words, int rewards_early) {
+  return K::fixed && d.H == K::H && d.W == K::W && d.A == K::A && d.S == K::S && d.T == K::T && d.NOFF == K::NOFF && d.base == K::BASE &&
+         d.n_obs_values == K::NOV && d.NT == K::NT && d.NRW == K::NRW && d.flags == K::FLAGS && d.max_steps == K::MAX_STEPS &&
+         blk_words == K::BLKW && d.aoe_mask_feat == K::MASK_FEAT && rewards_early == K::REWARDS_EARLY;
 }
 
 // PL: the program sections this kernel interprets (inventory feature ids, game-value code, reward records, obs
@@ -195,21 +228,26 @@ __device__ __forceinline__ uint32_t mgx_wave_sum(uint32_t x) {
 // is all a static object (walls ...) ever shows; only the other objects get a per-step list behind them.
 // NTH: threads per workgroup — 256, or 512 for envs with many agents (more wavefronts over the same per-env LDS).
 // EW: wavefronts that take part in the encode (each owns four staging rows in LDS); the others wait at the barrier behind it.
-template <bool WITH_REWARDS, bool X, bool PL, int NTH = MGX_OBS_THREADS, int EW = NTH / MGX_WAVE>
+template <bool WITH_REWARDS, bool X, bool PL, int NTH = MGX_OBS_THREADS, int EW = NTH / MGX_WAVE, class K = MgxObsShapeDyn>
 __global__ void __launch_bounds__(NTH) mgx_obs_kernel(MgxDev d, int pool_tokens, int pool_prefix, const uint8_t* env_mask,
-                                                                  int blk_start, int blk_words, int rewards_early) {
+                                                                  int blk_start, int blk_words_arg, int rewards_early_arg) {
   MGX_KERNARG_ENTRY(d);
   extern __shared__ __align__(16) uint8_t smem[];
   const int env = blockIdx.x;
   if (env_mask && !env_mask[env]) return;  // episode restart: only the restarted envs get initial observations
   const int tid = threadIdx.x, lane = tid & (MGX_WAVE - 1);
   const int wave = __builtin_amdgcn_readfirstlane(tid / MGX_WAVE);  // wave-uniform: per-agent values and branches go scalar
-  const int HW = d.H * d.W, A = d.A, S = d.S, T = d.T, NOFF = d.NOFF;
-  const int GT = mgx_obs_gt(d.n_obs_values, d.base);
-  const bool want_mask = X && d.aoe_mask_feat != 0 && d.NT > 0;
+  constexpr bool FX = K::fixed;   // the shape is a compile-time constant (every FX ? K::x : d.x below folds)
+  const int dH = FX ? K::H : d.H, dW = FX ? K::W : d.W, A = FX ? K::A : d.A, S = FX ? K::S : d.S, T = FX ? K::T : d.T,
+            NOFF = FX ? K::NOFF : d.NOFF, HW = dH * dW;
+  const int dBase = FX ? K::BASE : d.base, NOV = FX ? K::NOV : d.n_obs_values, dNT = FX ? K::NT : d.NT, dNRW = FX ? K::NRW : d.NRW,
+            dFlags = FX ? K::FLAGS : d.flags, dMaxSteps = FX ? K::MAX_STEPS : d.max_steps, dMaskFeat = FX ? K::MASK_FEAT : d.aoe_mask_feat;
+  const int blk_words = FX ? K::BLKW : blk_words_arg, rewards_early = FX ? K::REWARDS_EARLY : rewards_early_arg;
+  const int GT = mgx_obs_gt(NOV, dBase);
+  const bool want_mask = X && dMaskFeat != 0 && dNT > 0;
   const int xmode = mgx_obs_xmode(X, want_mask, S, d.P[MGX_H_NUM_TAGS]);
   const bool pack_mask = (xmode & MGX_OX_PACK) != 0, owner8 = (xmode & MGX_OX_OWNER8) != 0;
-  const MgxObsLds L = mgx_obs_lds_layout(HW, NOFF, S, A, T, pool_tokens, xmode, d.n_obs_values, PL ? blk_words : 0, GT,
+  const MgxObsLds L = mgx_obs_lds_layout(HW, NOFF, S, A, T, pool_tokens, xmode, NOV, PL ? blk_words : 0, GT,
                                          rewards_early != 0, EW);
   const int CP = L.cp;
   uint16_t* s_grid = (uint16_t*)(smem + L.grid);
@@ -256,7 +294,7 @@ __global__ void __launch_bounds__(NTH) mgx_obs_kernel(MgxDev d, int pool_tokens,
   MgxEnvT<VP, X> ev(d, vp, env);
   ev.step = step;
   ev.xl = e.xl;
-  const MgxBase B((uint32_t)d.base);
+  const MgxBase B((uint32_t)dBase);
   const int hr = d.feat[14], wr = d.feat[15];  // obs_height >> 1, obs_width >> 1 (stored by the host)
 
   // RewardHelper::compute_entries (reward.hpp:56-77) + truncation/termination (mettagrid_c.cpp:1086-1096) of one agent
@@ -268,7 +306,7 @@ __global__ void __launch_bounds__(NTH) mgx_obs_kernel(MgxDev d, int pool_tokens,
     const float ep = d.episode_rewards[e.ao(a)];
     float total = 0.f;
     for (int k = 0; k < nrw; k++, rw += MGX_RW_WORDS) {
-      float* prev = &d.ag_rprev[e.ao(a) * d.NRW + k];
+      float* prev = &d.ag_rprev[e.ao(a) * dNRW + k];
       const float pv = *prev;
       MgxCtx vc = mgx_ctx(slot, slot);
       float val = ev.template eval_code<0>(rw[MGX_RW_GV_START], rw[MGX_RW_GV_COUNT], slot, vc, 0);
@@ -279,7 +317,7 @@ __global__ void __launch_bounds__(NTH) mgx_obs_kernel(MgxDev d, int pool_tokens,
     float reward = total != 0.f ? total : 0.f;  // rewards were zeroed at the top of the step; += total
     d.rewards[e.ao(a)] = reward;
     d.episode_rewards[e.ao(a)] = __fadd_rn(ep, reward);
-    if (d.max_steps > 0 && step >= (uint32_t)d.max_steps) {
+    if (dMaxSteps > 0 && step >= (uint32_t)dMaxSteps) {
       if (d.truncates) d.truncations[e.ao(a)] = 1;
       else d.terminals[e.ao(a)] = 1;
     }
@@ -458,7 +496,7 @@ __global__ void __launch_bounds__(NTH) mgx_obs_kernel(MgxDev d, int pool_tokens,
     // One lane per (agent, reward entry): the entries of an agent are evaluated side by side (their loads in flight
     // together) and then summed in entry order by the agent's first lane, exactly like the serial loop of
     // agent_rewards (reward.hpp:56-77: total += val or val - prev, entry by entry).
-    const int NRW = d.NRW;
+    const int NRW = dNRW;
     if (NRW <= MGX_WAVE) {
       const int per = MGX_WAVE / NRW;  // agents per pass
       for (int a0 = 0; a0 < A; a0 += per) {
@@ -490,7 +528,7 @@ __global__ void __launch_bounds__(NTH) mgx_obs_kernel(MgxDev d, int pool_tokens,
           const float reward = total != 0.f ? total : 0.f;  // rewards were zeroed at the top of the step; += total
           d.rewards[e.ao(a)] = reward;
           d.episode_rewards[e.ao(a)] = __fadd_rn(ep, reward);
-          if (d.max_steps > 0 && step >= (uint32_t)d.max_steps) {
+          if (dMaxSteps > 0 && step >= (uint32_t)dMaxSteps) {
             if (d.truncates) d.truncations[e.ao(a)] = 1;
             else d.terminals[e.ao(a)] = 1;
           }
@@ -505,7 +543,7 @@ __global__ void __launch_bounds__(NTH) mgx_obs_kernel(MgxDev d, int pool_tokens,
                       // The per-type ownership maps are current here: mgx_terr_kernel runs right before this kernel.
       for (int cellidx = tid; cellidx < HW; cellidx += NTH) {
         uint16_t owner = 0xFFFF;
-        for (int ti = 0; ti < d.NT && owner == 0xFFFF; ti++) owner = d.terr_owner[((size_t)env * d.NT + ti) * (size_t)HW + cellidx];
+        for (int ti = 0; ti < dNT && owner == 0xFFFF; ti++) owner = d.terr_owner[((size_t)env * dNT + ti) * (size_t)HW + cellidx];
         if (owner8) s_owner8[cellidx] = (uint8_t)owner; else s_owner[cellidx] = owner;  // (0xFFFF -> 0xFF: tag ids stop at 254 then)
       }
       // the observers' own tag bitsets, once per env instead of one HBM round trip per masked window cell
@@ -516,8 +554,8 @@ __global__ void __launch_bounds__(NTH) mgx_obs_kernel(MgxDev d, int pool_tokens,
       }
     }
     if (d.obsval)  // query-backed obs values: evaluated by mgx_values_kernel (one env per lane) right before this kernel
-      for (int i = tid; i < A * d.n_obs_values; i += NTH) s_obsval[i] = d.obsval[(size_t)env * A * d.n_obs_values + i];
-    if (want_mask || (d.obsval && d.n_obs_values > 0)) __syncthreads();  // read by other threads below
+      for (int i = tid; i < A * NOV; i += NTH) s_obsval[i] = d.obsval[(size_t)env * A * NOV + i];
+    if (want_mask || (d.obsval && NOV > 0)) __syncthreads();  // read by other threads below
   }
 
   // ---- phase 1: per agent the list of window cells that will emit tokens, in window order (ballot compaction), and
@@ -542,8 +580,8 @@ __global__ void __launch_bounds__(NTH) mgx_obs_kernel(MgxDev d, int pool_tokens,
       auto probe = [&](int x, char2 o, bool ok) -> uint32_t {
         const uint32_t ag = s_agents[x];
         const int r = (int)((ag >> 24) & 0xFF) + o.x, c = (int)((ag >> 16) & 0xFF) + o.y;
-        const bool inb = ok && (unsigned)r < (unsigned)d.H && (unsigned)c < (unsigned)d.W;
-        const uint32_t cs = inb ? (uint32_t)s_grid[inb ? __mul24(r, d.W) + c : 0] : 0u;
+        const bool inb = ok && (unsigned)r < (unsigned)dH && (unsigned)c < (unsigned)dW;
+        const uint32_t cs = inb ? (uint32_t)s_grid[inb ? __mul24(r, dW) + c : 0] : 0u;
         if (step > 0 && cs) atomicMin(&s_minobs[cs - 1], (uint32_t)x);
         return cs;
       };
@@ -587,13 +625,13 @@ __global__ void __launch_bounds__(NTH) mgx_obs_kernel(MgxDev d, int pool_tokens,
       for (int j = lane; j < ((NOFF + MGX_WAVE - 1) & ~(MGX_WAVE - 1)); j += MGX_WAVE) {  // whole wavefront in every pass (ballots)
         const char2 o = j == lane ? offs_p0 : j == lane + MGX_WAVE ? offs_p1 : s_offs[min(j, NOFF - 1)];
         const int r = r0 + o.x, c = c0 + o.y;
-        const bool inb = j < NOFF && (unsigned)r < (unsigned)d.H && (unsigned)c < (unsigned)d.W;
-        const uint32_t cs = inb ? (uint32_t)s_grid[inb ? __mul24(r, d.W) + c : 0] : 0u;  // map <= 255 x 255
+        const bool inb = j < NOFF && (unsigned)r < (unsigned)dH && (unsigned)c < (unsigned)dW;
+        const uint32_t cs = inb ? (uint32_t)s_grid[inb ? __mul24(r, dW) + c : 0] : 0u;  // map <= 255 x 255
         bool keep = cs != 0;
         uint32_t mv = 0;  // _emit_tile_observability_tokens (:337-362): 1 = the cell's owner tag is one of mine, 2 = not
         if constexpr (X) {
           if (want_mask && inb) {
-            const uint32_t ow = owner8 ? (uint32_t)s_owner8[r * d.W + c] : (uint32_t)s_owner[r * d.W + c];
+            const uint32_t ow = owner8 ? (uint32_t)s_owner8[r * dW + c] : (uint32_t)s_owner[r * dW + c];
             if (ow != (owner8 ? 0xFFu : 0xFFFFu)) { mv = ((s_agtags[a * MGX_TAG_WORDS + (ow >> 5)] >> (ow & 31)) & 1u) ? 1u : 2u; keep = true; }  // mask-only cells still emit one token
           }
         }
@@ -620,18 +658,18 @@ __global__ void __launch_bounds__(NTH) mgx_obs_kernel(MgxDev d, int pool_tokens,
     int pos = 0;
     auto put = [&](int f, uint32_t v) { g[pos++] = 0xFEu | ((uint32_t)(f & 0xFF) << 8) | ((v & 0xFF) << 16); };
     const uint32_t info = s_aginfo[a];
-    if (d.flags & MGX_G_COMPLETION) {
+    if (dFlags & MGX_G_COMPLETION) {
       uint32_t pct = 0;
-      if (d.max_steps > 0) pct = step >= (uint32_t)d.max_steps ? 255u : (256u * step / (uint32_t)d.max_steps);
+      if (dMaxSteps > 0) pct = step >= (uint32_t)dMaxSteps ? 255u : (256u * step / (uint32_t)dMaxSteps);
       put(d.feat[MGX_F_COMPLETION], pct);
     }
-    if (d.flags & MGX_G_LAST_ACTION) put(d.feat[MGX_F_LAST_ACTION], info & 0xFF);
-    if ((d.flags & MGX_G_LAST_ACTION_MOVE) && d.feat[MGX_F_LAST_ACTION_MOVE] != 0)
+    if (dFlags & MGX_G_LAST_ACTION) put(d.feat[MGX_F_LAST_ACTION], info & 0xFF);
+    if ((dFlags & MGX_G_LAST_ACTION_MOVE) && d.feat[MGX_F_LAST_ACTION_MOVE] != 0)
       put(d.feat[MGX_F_LAST_ACTION_MOVE], (info >> 8) & 1);
     // last_reward: the reference reads the reward buffer it zeroed at the top of the step (:937-938,722-726),
     // so the token is always round(0 * 100) = 0.
-    if (d.flags & MGX_G_LAST_REWARD) put(d.feat[MGX_F_LAST_REWARD], 0);
-    if (d.flags & MGX_G_LOCAL_POSITION) {
+    if (dFlags & MGX_G_LAST_REWARD) put(d.feat[MGX_F_LAST_REWARD], 0);
+    if (dFlags & MGX_G_LOCAL_POSITION) {
       uint16_t sp = s_spawn[a];
       int dc = c0 - (int)(sp & 0xFF), dr = (int)(sp >> 8) - r0;
       if (dc > 0) put(d.feat[MGX_F_LP_EAST], (uint32_t)min(dc, 255));
@@ -639,13 +677,13 @@ __global__ void __launch_bounds__(NTH) mgx_obs_kernel(MgxDev d, int pool_tokens,
       if (dr > 0) put(d.feat[MGX_F_LP_NORTH], (uint32_t)min(dr, 255));
       else if (dr < 0) put(d.feat[MGX_F_LP_SOUTH], (uint32_t)min(-dr, 255));
     }
-    for (int i = 0; i < d.n_obs_values; i++) {  // _emit_obs_value_tokens :1207-1238
+    for (int i = 0; i < NOV; i++) {  // _emit_obs_value_tokens :1207-1238
       VP V = vp + d.sec[MGX_SEC_OBS_VALUES] + i * MGX_OV_WORDS;
       uint32_t rem;
       bool ext = false;
       if constexpr (X) ext = d.obsval != nullptr;
       if (ext) {
-        rem = s_obsval[a * d.n_obs_values + i];
+        rem = s_obsval[a * NOV + i];
       } else {
         MgxCtx vc = mgx_ctx(my_slot, my_slot);
         rem = (uint32_t)ev.template eval_code<0>(V[MGX_OV_GV_START], V[MGX_OV_GV_COUNT], my_slot, vc, 0);
@@ -711,7 +749,7 @@ __global__ void __launch_bounds__(NTH) mgx_obs_kernel(MgxDev d, int pool_tokens,
       const int tot = __shfl(incl, lane | 15);
       int pos = base_pos + incl - n;
       if constexpr (X) {
-        if (mask) { if (pos < T) s_row[pos] = loc | ((uint32_t)d.aoe_mask_feat << 8) | (mask << 16); pos++; n--; }
+        if (mask) { if (pos < T) s_row[pos] = loc | ((uint32_t)dMaskFeat << 8) | (mask << 16); pos++; n--; }
       }
       // Token lists of up to MGX_SMALL_LIST entries (walls, plain objects) are copied by the cell's own lane; longer
       // ones (agents carrying an inventory: the observer itself is always one) by the 16 lanes of the row, one list

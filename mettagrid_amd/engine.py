@@ -67,6 +67,7 @@ def load_lib():
     L.mgx_get_current_steps.argtypes = [vp, vp]
     L.mgx_get_stats.argtypes = [vp, i32, vp, vp, vp, vp]
     L.mgx_get_objects.argtypes = [vp, i32, vp, C.POINTER(i32)]
+    L.mgx_get_objects_batch.argtypes = [vp, vp, i32, vp, vp]
     L.mgx_get_invalid_index_extra.argtypes = [vp, i32, vp, vp]
     L.mgx_get_reward_state.argtypes = [vp, i32, vp]
     L.mgx_poll_errors.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(i32)]
@@ -80,7 +81,7 @@ def load_lib():
     L.mgx_count_objects_with_tag.argtypes = [vp, i32, i32, C.POINTER(i32)]
     L.mgx_set_profiling.argtypes = [vp, i32]
     L.mgx_get_step_timing.argtypes = [vp, vp]
-    for name in ("mgx_num_envs", "mgx_num_agents", "mgx_num_tokens"):
+    for name in ("mgx_num_envs", "mgx_num_agents", "mgx_num_tokens", "mgx_obs_variant"):
         getattr(L, name).argtypes = [vp]
         getattr(L, name).restype = i32
     L.mgx_state_bytes.argtypes = [vp]
@@ -349,6 +350,22 @@ class BatchedMettaGrid:
         _check(self.L.mgx_get_objects(self.h, env, out.ctypes.data, C.byref(n)))
         return out[: n.value]
 
+    def raw_objects_batch(self, envs) -> list:
+        """``raw_objects`` of many envs with one kernel and one device->host copy (include/mgx.h mgx_get_objects_batch)."""
+        idx = np.ascontiguousarray(np.asarray(envs, dtype=np.int32).reshape(-1))
+        if idx.size == 0:
+            return []
+        out = np.zeros((idx.size, self.prog.max_objects, OBJ_RECORD_WORDS), np.int32)
+        n = np.zeros(idx.size, np.int32)
+        _check(self.L.mgx_get_objects_batch(self.h, idx.ctypes.data, int(idx.size), out.ctypes.data, n.ctypes.data))
+        return [out[i, : n[i]] for i in range(idx.size)]
+
+    def grid_objects_batch(self, envs) -> list:
+        """``grid_objects()`` dicts (cpp/bindings/mettagrid_py.cpp:28-139) of many envs; the per-agent reward state is still
+        one small copy per env."""
+        return [objects_from_raw(self.prog, raw, self.current_stat_reward(int(e)))
+                for e, raw in zip(np.asarray(envs).reshape(-1), self.raw_objects_batch(envs))]
+
     def current_stat_reward(self, env: int = 0) -> np.ndarray:
         out = np.zeros(self.A, np.float32)
         _check(self.L.mgx_get_reward_state(self.h, env, out.ctypes.data))
@@ -440,6 +457,11 @@ class BatchedMettaGrid:
         """(world update, observation + rewards) of the most recent step in milliseconds."""
         t = self.step_timing_segments_ms()
         return t["actions"] + t["aoe"] + t["tail"], t["obs"] + t["rewards"]
+
+    @property
+    def obs_variant(self) -> int:
+        """0: generic observation kernel; 3: the instance compiled for the shape of BASELINE.json configs[2] (gen_presets.py)."""
+        return int(self.L.mgx_obs_variant(self.h))
 
     @property
     def state_bytes(self) -> int:

@@ -74,3 +74,39 @@ def test_digest_covers_far_invalid_action_indices():
                             ora.current_step)
     got = int(eng.state_digests()[0])
     assert got == want and got != plain and got != before
+
+
+@pytest.mark.parametrize("name", ["rung3", "rung4", "dynamic"])
+def test_batched_object_export_equals_per_env_path_and_oracle(name):
+    """mgx_get_objects_batch (one kernel + one copy for a list of envs, any order, repeats allowed) == mgx_get_objects per
+    env == the oracle's object dump, after objects have moved, traded, been removed and spawned."""
+    spec_f, map_f, steps, invalid = hp.SCENARIOS[name]
+    steps = min(steps, 40)
+    E = 9
+    maps = [map_f(s) for s in range(E)]
+    prog = hp.compile_scenario(name, spec_f(), *maps[0].shape)
+    cms = np.stack([prog.class_map(m) for m in maps])
+    seeds = np.arange(E, dtype=np.uint32) + 5
+    eng = BatchedMettaGrid(prog, cms, seeds, buffers="host")
+    oracles = [op.OracleSim(prog, cms[i], int(seeds[i])) for i in range(E)]
+    for o in oracles:
+        o.reinit_buffers()
+    acts = [hp.make_actions(prog, i, steps, invalid) for i in range(E)]
+    for t in range(steps):
+        eng.actions[:] = np.concatenate([acts[i][0][t] for i in range(E)])
+        eng.vibe_actions[:] = np.concatenate([acts[i][1][t] for i in range(E)])
+        eng.step()
+        for i, o in enumerate(oracles):
+            o.step(acts[i][0][t], acts[i][1][t])
+    order = [8, 0, 3, 3, 7, 1]
+    batch = eng.raw_objects_batch(order)
+    assert len(batch) == len(order)
+    for e, raw in zip(order, batch):
+        assert np.array_equal(raw, eng.raw_objects(e)), f"{name} env {e}: batch != per-env export"
+        assert np.array_equal(raw, oracles[e].raw_objects()), f"{name} env {e}: export != oracle"
+    dicts = eng.grid_objects_batch([2, 4])
+    assert dicts[0] == eng.grid_objects(2) and dicts[1] == eng.grid_objects(4)
+    assert eng.raw_objects_batch([]) == []
+    with pytest.raises(ValueError):
+        eng.raw_objects_batch([E])
+    eng.close()

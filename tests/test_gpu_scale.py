@@ -69,6 +69,8 @@ def _run_and_check(E, sample, steps, seed0=0, rung=3, actions=None, obs_tokens=N
         check(t + 1)
     bits, first = eng.poll_errors()
     assert bits == 0, (bits, first)
+    if obs_tokens is None and E >= 150:   # configs[2] at its own shape runs the specialised observation kernel
+        assert eng.obs_variant == (3 if rung == 3 else 0), eng.obs_variant
     return eng, T
 
 
