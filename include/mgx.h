@@ -163,6 +163,12 @@ int mgx_count_objects_with_tag(mgx_engine* e, int32_t env, int32_t tag_id, int32
  * buffers), n_rows = E*A.  scale: float32 [256] HOST memory, scale[f] = max(normalization of feature f, 1)
  * (grid_obs_wrapper.py:39-44; the Python mirror derives it from the compiled program).  Enqueued on the engine's stream. */
 int mgx_decode_obs(mgx_engine* e, const uint8_t* tokens, int64_t n_rows, float* box, int32_t num_features, const float* scale);
+/* The fused form of the same decode: from the next observation pass on, the observation kernel writes every
+ * agent's dense box [E*A][num_features][obs_h][obs_w] into `box` (device memory, caller-owned) INSTEAD of the token rows —
+ * the bound observation buffer is then neither written nor read back.  dtype: 1 = float32, bit-identical to GridObsWrapper's
+ * box; 2 = bfloat16 = that float32 box rounded to nearest even; 0 (or box = NULL) switches back to token rows.  scale: float
+ * [256] host memory as for mgx_decode_obs.  Token statistics (tokens_written ...) are kept as on the token path. */
+int mgx_set_box_output(mgx_engine* e, void* box, int32_t dtype, int32_t num_features, const float* scale);
 
 /* One 64-bit digest per env (uint64 [E], host memory) of everything the episode signature is made of: the
  * mgx_get_objects records of the live slots, every stat value and "key exists" flag (mgx_get_stats), episode rewards,

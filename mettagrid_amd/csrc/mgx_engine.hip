@@ -182,6 +182,11 @@ __global__ void __launch_bounds__(256) mgx_objects_kernel(const MgxDev* __restri
   }
 }
 
+// dense-output instances of the observation kernel (mgx_obs_box.hip)
+bool mgx_launch_obs_box(hipStream_t stream, const MgxDev& dd, size_t lds, int pool_tokens, int pool_prefix, const uint8_t* mask, int blk_start,
+                        int blk_words, int rewards_early, bool with_rewards, bool X, bool PL, int threads, int ew, void* box, const float* scale,
+                        int C, int dtype);
+bool mgx_obs_box_set_lds(size_t lds);
 // token decode kernel (mgx_decode.hip)
 int mgx_launch_decode(hipStream_t stream, const uint8_t* tokens, float* box, const float* scale_dev, long long rows, int T, int C, int H, int W);
 
@@ -225,6 +230,8 @@ struct mgx_engine {
   size_t lds_world = 0, lds_obs = 0;
   int obs_threads = MGX_OBS_THREADS, obs_ew = MGX_OBS_THREADS / MGX_WAVE;
   int obs_variant = 0;   // 0: generic observation kernel; 3: the instance specialised for the shape of BASELINE.json configs[2]
+  int box_dtype = 0, box_C = 0;   // mgx_set_box_output: the observation kernel writes the dense box instead of token rows
+  void* box_out = nullptr;
   int pool_tokens = 0;   // capacity of the LDS token pool (entries), including the class-tag prefix
   int pool_prefix = 0;   // entries of the per-class static tag table at the head of the pool
   bool prog_in_lds = false;
@@ -371,6 +378,7 @@ static int size_obs_lds(mgx_engine* e) {
                          (const void*)mgx_obs_kernel<true, true, false, 512, 3>, (const void*)mgx_obs_kernel<false, true, false, 512, 3>,
                          (const void*)mgx_obs_kernel<true, true, false, 512, 2>, (const void*)mgx_obs_kernel<false, true, false, 512, 2>};
     for (const void* f : fns) HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_obs));
+    if (!mgx_obs_box_set_lds(e->lds_obs)) return fail(MGX_ERR_HIP, "cannot raise the dense-output observation kernels' dynamic LDS limit");
     cur_max = e->lds_obs;
   }
   return MGX_OK;
@@ -383,9 +391,9 @@ static void launch_obs_t(mgx_engine* e, bool with_rewards, const uint8_t* mask) 
   if (PL)  // the interpreted sections are addressed relative to their LDS copy
     for (int k = MGX_SEC_INV_FEATURES; k < MGX_SEC_WORDLIST; k++) dd.sec[k] -= e->obs_blk_start;
   if (with_rewards)
-    hipLaunchKernelGGL((mgx_obs_kernel<true, X, PL, NTH, EW, K>), grid, block, e->lds_obs, e->stream, dd, e->pool_tokens, e->pool_prefix, mask, e->obs_blk_start, e->obs_blk_words, (int)e->rewards_early);
+    hipLaunchKernelGGL((mgx_obs_kernel<true, X, PL, NTH, EW, K>), grid, block, e->lds_obs, e->stream, dd, e->pool_tokens, e->pool_prefix, mask, e->obs_blk_start, e->obs_blk_words, (int)e->rewards_early, (void*)nullptr, (const float*)nullptr, 0, 0);
   else
-    hipLaunchKernelGGL((mgx_obs_kernel<false, X, PL, NTH, EW, K>), grid, block, e->lds_obs, e->stream, dd, e->pool_tokens, e->pool_prefix, mask, e->obs_blk_start, e->obs_blk_words, (int)e->rewards_early);
+    hipLaunchKernelGGL((mgx_obs_kernel<false, X, PL, NTH, EW, K>), grid, block, e->lds_obs, e->stream, dd, e->pool_tokens, e->pool_prefix, mask, e->obs_blk_start, e->obs_blk_words, (int)e->rewards_early, (void*)nullptr, (const float*)nullptr, 0, 0);
 }
 // Device-memory copy of e->d, brought up to date (stream-ordered) whenever the host table changed.
 static const MgxDev* dev_copy(mgx_engine* e) {
@@ -440,6 +448,18 @@ static int launch_obs(mgx_engine* e, bool with_rewards, const uint8_t* mask = nu
   if (e->d.obsval) mgx_launch_values(e->stream, e->d, dev_copy(e), 0, mask);
   MGX_TRACE_POINT(e, "values kernel");
   if (e->rewards_ext) with_rewards = false;
+  if (e->box_dtype != MGX_BOX_OFF) {   // fused dense output (mgx_set_box_output): the BOX instances live in mgx_obs_box.hip
+    MgxDev dd = e->d;
+    const bool pl = !e->d.X && e->obs_blk_lds;
+    if (pl)
+      for (int k = MGX_SEC_INV_FEATURES; k < MGX_SEC_WORDLIST; k++) dd.sec[k] -= e->obs_blk_start;
+    if (!mgx_launch_obs_box(e->stream, dd, e->lds_obs, e->pool_tokens, e->pool_prefix, mask, e->obs_blk_start, e->obs_blk_words,
+                            (int)e->rewards_early, with_rewards, e->d.X != 0, pl, e->obs_threads, e->obs_ew, e->box_out, e->d_scale,
+                            e->box_C, e->box_dtype))
+      return fail(MGX_ERR_PROGRAM, "mgx_step: no dense-output instance of the observation kernel for this configuration");
+    HIP_TRY(hipGetLastError());
+    return MGX_OK;
+  }
   // a program whose shape equals a preset's runs that preset's instance of the kernel (shape = compile-time constants)
   if (e->obs_variant == 3) launch_obs_t<false, true, MGX_OBS_THREADS, MGX_OBS_THREADS / MGX_WAVE, MgxObsShapeR3>(e, with_rewards, mask);
   else if (e->d.X && e->obs_threads == 512 && e->obs_ew == 4) launch_obs_t<true, false, 512, 4>(e, with_rewards, mask);
@@ -1619,6 +1639,26 @@ int mgx_decode_obs(mgx_engine* e, const uint8_t* tokens, int64_t n_rows, float* 
   if (rc == -1) return fail(MGX_ERR_PROGRAM, "mgx_decode_obs: the box of one agent does not fit the decode kernel's LDS");
   if (rc) return fail(MGX_ERR_HIP, "mgx_decode_obs: launch failed");
   return MGX_OK;
+}
+
+int mgx_set_box_output(mgx_engine* e, void* box, int32_t dtype, int32_t num_features, const float* scale) {
+  if (!e) return fail(MGX_ERR_BAD_ARG, "mgx_set_box_output: null engine");
+  if (dtype == MGX_BOX_OFF || !box) { e->box_dtype = MGX_BOX_OFF; e->box_out = nullptr; return MGX_OK; }
+  if ((dtype != MGX_BOX_F32 && dtype != MGX_BOX_BF16) || !scale || num_features < 1 || num_features > 256)
+    return fail(MGX_ERR_BAD_ARG, "mgx_set_box_output: bad argument");
+#ifdef MGX_CPU_EMU
+  return fail(MGX_ERR_PROGRAM, "mgx_set_box_output: the observation kernel is not part of the sanitizer build");
+#endif
+  HIP_TRY(hipSetDevice(e->device));
+  if (!e->d_scale) { int rc = e->alloc(&e->d_scale, 256); if (rc) return rc; }
+  if (!e->scale_valid || memcmp(e->scale_host, scale, sizeof e->scale_host) != 0) {
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    memcpy(e->scale_host, scale, sizeof e->scale_host);
+    HIP_TRY(hipMemcpyAsync(e->d_scale, e->scale_host, sizeof e->scale_host, hipMemcpyHostToDevice, e->stream));
+    e->scale_valid = true;
+  }
+  e->box_out = box; e->box_dtype = dtype; e->box_C = num_features;
+  return MGX_OK;   // (from the next observation pass on; the box of the observations already made: mgx_decode_obs)
 }
 
 int mgx_poll_errors(mgx_engine* e, uint32_t* bits, int32_t* first_env) {

@@ -25,6 +25,7 @@
 #include "mgx_world.h"
 
 #define MGX_OBS_THREADS 256
+enum { MGX_BOX_OFF = 0, MGX_BOX_F32 = 1, MGX_BOX_BF16 = 2 };   // mgx_set_box_output dtypes
 #ifdef MGX_OBS_STOP  // profiling builds only: leave the kernel after phase k to attribute its time (scripts/obs_phases.sh)
 #define MGX_PHASE_END(k) do { if (MGX_OBS_STOP == (k)) return; } while (0)
 #else
@@ -228,9 +229,15 @@ inline bool mgx_obs_shape_matches(const MgxDev& d, int blk_words, int rewards_ea
 // is all a static object (walls ...) ever shows; only the other objects get a per-step list behind them.
 // NTH: threads per workgroup — 256, or 512 for envs with many agents (more wavefronts over the same per-env LDS).
 // EW: wavefronts that take part in the encode (each owns four staging rows in LDS); the others wait at the barrier behind it.
-template <bool WITH_REWARDS, bool X, bool PL, int NTH = MGX_OBS_THREADS, int EW = NTH / MGX_WAVE, class K = MgxObsShapeDyn>
+// BOX (fused form): false = token rows u8[T][3] to MgxDev::obs (the reference's buffer); true = the policy's
+// dense input instead — the box [C][H][W] of GridObsWrapper._convert (python/src/mettagrid/envs/grid_obs_wrapper.py:57-95:
+// value / scale[feature] added into cell (feature, y, x) in token order, global tokens on the centre cell) as float32
+// (box_dtype MGX_BOX_F32) or bfloat16 (MGX_BOX_BF16: the float32 sum rounded to nearest even once) — written straight from
+// the LDS staging row; the token buffer is neither written nor read back.
+template <bool WITH_REWARDS, bool X, bool PL, int NTH = MGX_OBS_THREADS, int EW = NTH / MGX_WAVE, class K = MgxObsShapeDyn, bool BOX = false>
 __global__ void __launch_bounds__(NTH) mgx_obs_kernel(MgxDev d, int pool_tokens, int pool_prefix, const uint8_t* env_mask,
-                                                                  int blk_start, int blk_words_arg, int rewards_early_arg) {
+                                                                  int blk_start, int blk_words_arg, int rewards_early_arg,
+                                                                  void* box_out, const float* box_scale, int box_C, int box_dtype) {
   MGX_KERNARG_ENTRY(d);
   extern __shared__ __align__(16) uint8_t smem[];
   const int env = blockIdx.x;
@@ -324,6 +331,17 @@ __global__ void __launch_bounds__(NTH) mgx_obs_kernel(MgxDev d, int pool_tokens,
   };
 
   MGX_TICK0();
+  if constexpr (BOX) {
+    // The boxes of the env's agents are 99 % zeros: all of them are streamed out NOW with 16-byte stores by every thread
+    // of the workgroup, under the staging and classification phases; the encode phase only stores the few hundred values.
+    const size_t env_bytes = (size_t)A * (size_t)(box_C * (2 * hr + 1) * (2 * wr + 1)) * (box_dtype == MGX_BOX_F32 ? 4 : 2);
+    uint8_t* eb = (uint8_t*)box_out + (size_t)env * env_bytes;
+    if ((env_bytes & 15) == 0 && (((uintptr_t)eb) & 15) == 0) {
+      for (size_t i = tid; i < env_bytes / 16; i += NTH) ((uint4*)eb)[i] = make_uint4(0u, 0u, 0u, 0u);
+    } else {
+      for (size_t i = tid; i < env_bytes / 2; i += NTH) ((uint16_t*)eb)[i] = 0;
+    }
+  }
   // The classification of object slot `tid` (phase 0b) needs only global data: its loads are issued first, so they
   // are in flight together with the staging loads below instead of one barrier later.
   uint16_t pre_cls = MGX_DEAD_CLASS;
@@ -380,6 +398,8 @@ __global__ void __launch_bounds__(NTH) mgx_obs_kernel(MgxDev d, int pool_tokens,
   const bool dyn_tags = X && d.obj_tags != nullptr;
   // ---- phase 0b: classify the object slots.  Static classes show their class tag list (pool prefix); everything
   // else is queued for the list builder. ----
+  if constexpr (BOX) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this thread's zero stores are out: no value stored
+                                                                         // behind a barrier can be overtaken by one of them
   __syncthreads();
   MGX_TICK(8);
   MGX_PHASE_END(1);
@@ -804,6 +824,39 @@ __global__ void __launch_bounds__(NTH) mgx_obs_kernel(MgxDev d, int pool_tokens,
       s_written[a] = base_pos;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // LDS row complete before it is read back
+    if constexpr (BOX) {
+      // ---- the agent's dense box from its staging row: the cell values are stored over the zeros the whole workgroup
+      // streamed out at the start of the kernel (waited for in front of the first barrier).  Tokens that share a cell are
+      // adjacent in a row this kernel built (the tag tokens of one object): the first lane of such a run adds the rest in
+      // token order. ----
+      const bool f32 = box_dtype == MGX_BOX_F32;
+      const int Hh = 2 * hr + 1, Ww = 2 * wr + 1, cells = box_C * Hh * Ww;
+      const int bytes = cells * (f32 ? 4 : 2);
+      uint8_t* bx = (uint8_t*)box_out + ((size_t)env * A + ac) * (size_t)bytes;
+      auto key_of = [&](uint32_t tok) -> uint32_t {        // (cell, feature) of a token; 0xFFFFFFFF = padding
+        const uint32_t lc = tok & 0xFFu;
+        return lc == 0xFFu ? 0xFFFFFFFFu : ((lc == 0xFEu ? (uint32_t)((hr << 4) | wr) : lc) | (tok & 0xFF00u));
+      };
+      for (int k = rl; k < T && av; k += 16) {
+        const uint32_t tok = s_row[k];
+        const uint32_t key = key_of(tok);
+        if (key == 0xFFFFFFFFu) continue;
+        if (k > 0 && key_of(s_row[k - 1]) == key) continue;   // a later token of a run: its first lane adds it
+        const int f = (int)((key >> 8) & 0xFFu), y = (int)((key >> 4) & 0xFu), x = (int)(key & 0xFu);
+        const float sc = box_scale[f];
+        float sum = __fdiv_rn((float)((tok >> 16) & 0xFFu), sc);
+        for (int j = k + 1; j < T && key_of(s_row[j]) == key; j++) sum = __fadd_rn(sum, __fdiv_rn((float)((s_row[j] >> 16) & 0xFFu), sc));
+        if (y < Hh && x < Ww && f < box_C) {
+          const int cellidx = (f * Hh + y) * Ww + x;
+          if (f32) {
+            ((float*)bx)[cellidx] = sum;
+          } else {   // bfloat16, round to nearest even (the sums are finite and non-negative)
+            const uint32_t u = __float_as_uint(sum);
+            ((uint16_t*)bx)[cellidx] = (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+          }
+        }
+      }
+    } else {
     // ---- pack 4 tokens (4 x u32, low 3 bytes valid) into 12 bytes and store them: the row's 16 lanes sweep it ----
     uint8_t* out = d.obs + ((size_t)env * A + ac) * (size_t)T * 3;
     for (int q = rl; q * 4 < T && av; q += 16) {
@@ -818,6 +871,7 @@ __global__ void __launch_bounds__(NTH) mgx_obs_kernel(MgxDev d, int pool_tokens,
         uint32_t w[3] = {w0, w1, w2};
         for (int b = 0; b < 12 && q * 12 + b < 3 * T; b++) out[q * 12 + b] = (uint8_t)(w[b >> 2] >> (8 * (b & 3)));
       }
+    }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
   }

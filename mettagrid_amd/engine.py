@@ -73,6 +73,7 @@ def load_lib():
     L.mgx_poll_errors.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(i32)]
     L.mgx_set_inventory.argtypes = [vp, i32, i32, vp, vp, i32]
     L.mgx_decode_obs.argtypes = [vp, vp, i64, vp, i32, vp]
+    L.mgx_set_box_output.argtypes = [vp, vp, i32, i32, vp]
     L.mgx_state_digests.argtypes = [vp, vp]
     L.mgx_set_map_pool.argtypes = [vp, vp, i32]
     L.mgx_reset_envs_from_pool.argtypes = [vp, vp, vp, vp]
@@ -420,6 +421,24 @@ class BatchedMettaGrid:
         for i, z in enumerate(self.prog.feature_norms):
             scale[i] = max(float(z), 1.0)
         return scale
+
+    def set_box_output(self, out=None):
+        """Fused form of ``decode_obs`` (include/mgx.h mgx_set_box_output): from the next observation pass on the observation
+        kernel writes the dense box of every agent into ``out`` — a contiguous torch CUDA tensor [E*A, C, H, W], float32
+        (bit-identical to ``GridObsWrapper._convert``) or bfloat16 (that box rounded to nearest even) — instead of the token
+        rows.  ``None`` switches back to token rows.  The tensor is kept alive here."""
+        import torch
+        if out is None:
+            self._box = None
+            _check(self.L.mgx_set_box_output(self.h, None, 0, 0, None))
+            return
+        Cn = len(self.prog.feature_norms)
+        Hh, Ww = int(self.prog.words[K.H_OBS_HEIGHT]), int(self.prog.words[K.H_OBS_WIDTH])
+        if tuple(out.shape) != (self.E * self.A, Cn, Hh, Ww) or out.dtype not in (torch.float32, torch.bfloat16) or not out.is_contiguous():
+            raise ValueError(f"out must be a contiguous float32 / bfloat16 tensor of shape {(self.E * self.A, Cn, Hh, Ww)}")
+        scale = self.feature_scale()
+        self._box = out
+        _check(self.L.mgx_set_box_output(self.h, out.data_ptr(), 1 if out.dtype == torch.float32 else 2, Cn, scale.ctypes.data))
 
     def decode_obs(self, out=None, tokens=None):
         """Dense float32 box [rows, C, H, W] of the current observations (``GridObsWrapper._convert``), computed on the

@@ -13,6 +13,7 @@ hipcc $F -DMGX_SLOT=1 -c $C/mgx_world_fast.hip -o $O/f1.o &
 hipcc $F -c $C/mgx_world_x.hip -o $O/x.o &
 hipcc $F -c $C/mgx_aoe.hip -o $O/a.o &
 hipcc $F -c $C/mgx_decode.hip -o $O/d.o &
+hipcc $F -c $C/mgx_obs_box.hip -o $O/b.o &
 for job in $(jobs -p); do wait $job; done
 hipcc --offload-arch=gfx950 -shared -fPIC -o $ROOT/mettagrid_amd/libmgx_timing.so $O/*.o
 echo built libmgx_timing.so

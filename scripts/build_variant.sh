@@ -15,6 +15,7 @@ hipcc $F $(x fast) -DMGX_SLOT=1 -c $C/mgx_world_fast.hip -o $O/f1.o &
 hipcc $F $(x x) -c $C/mgx_world_x.hip -o $O/x.o &
 hipcc $F $(x aoe) -c $C/mgx_aoe.hip -o $O/a.o &
 hipcc $F $(x decode) -c $C/mgx_decode.hip -o $O/d.o &
+hipcc $F $(x box) -c $C/mgx_obs_box.hip -o $O/b.o &
 for job in $(jobs -p); do wait $job; done
 mkdir -p $ROOT/build
 hipcc --offload-arch=gfx950 -shared -fPIC -o $ROOT/build/libmgx_$NAME.so $O/*.o

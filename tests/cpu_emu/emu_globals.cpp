@@ -6,3 +6,7 @@ alignas(16) uint8_t smem[160 * 1024];         // dynamic LDS of the (not emulate
 alignas(16) uint8_t aoe_lds[160 * 1024];     // dynamic LDS of mgx_aoe_kernel
 // the token-decode kernel is wavefront-cooperative (ballot / shuffles): not part of the sanitizer build
 int mgx_launch_decode(hipStream_t, const uint8_t*, float*, const float*, long long, int, int, int, int) { return -2; }
+// ... and so are the dense-output instances of the observation kernel
+struct MgxDev;
+bool mgx_launch_obs_box(hipStream_t, const MgxDev&, size_t, int, int, const uint8_t*, int, int, int, bool, bool, bool, int, int, void*, const float*, int, int) { return false; }
+bool mgx_obs_box_set_lds(size_t) { return true; }

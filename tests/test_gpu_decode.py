@@ -97,3 +97,70 @@ def test_decode_of_live_observations_at_scale():
     total = ((o[..., 2].double() / scale[o[..., 1].long()]) * valid).sum().item()
     assert abs(box.double().sum().item() - total) <= 1e-6 * max(1.0, total)
     assert torch.isfinite(box).all().item() and (box >= 0).all().item()
+
+
+def _bf16_bits(x: np.ndarray) -> np.ndarray:
+    """float32 -> bfloat16 bit patterns, round to nearest even (finite inputs)."""
+    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    return ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint16)
+
+
+@pytest.mark.parametrize("name", ["rung3", "rung4", "lit", "crowd", "torture_base10", "rung4_full"])
+def test_fused_box_output_equals_decode_of_the_token_path(name):
+    """mgx_set_box_output (fused form): the observation kernel writes the dense box straight from its LDS
+    staging rows.  Two engines on identical seeds and actions — one on the token path (whose rows go through the numpy
+    restatement of GridObsWrapper._convert, oracle/obs_decode.py, and through the standalone decode kernel), one on the fused
+    path — must give the same box after every step: float32 bit for bit, bfloat16 = the float32 box rounded to nearest even.
+    Rewards, flags and the final state digests must not notice the output mode."""
+    import torch
+
+    import helpers as hp
+    spec_f, map_f, steps, invalid = hp.SCENARIOS[name]
+    steps = min(steps, 14)
+    E = 5
+    maps = [map_f(s) for s in range(E)]
+    prog = hp.compile_scenario(name, spec_f(), *maps[0].shape)
+    cms = np.stack([prog.class_map(m) for m in maps])
+    seeds = np.arange(E, dtype=np.uint32) + 3
+    A, C = prog.num_agents, len(prog.feature_norms)
+    H, W = int(prog.words[13]), int(prog.words[14])      # MGX_H_OBS_HEIGHT / WIDTH
+    tok_eng = BatchedMettaGrid(prog, cms, seeds, buffers="device")
+    engs = {torch.float32: BatchedMettaGrid(prog, cms, seeds, buffers="device"), torch.bfloat16: BatchedMettaGrid(prog, cms, seeds, buffers="device")}
+    boxes = {dt: torch.full((E * A, C, H, W), 7.0, dtype=dt, device="cuda") for dt in engs}
+    for dt, eng in engs.items():
+        eng.set_box_output(boxes[dt])
+    scale = obs_decode.feature_scale(prog.feature_norms)
+    acts = [hp.make_actions(prog, i, steps, invalid) for i in range(E)]
+    for t in range(steps):
+        a = torch.from_numpy(np.concatenate([acts[i][0][t] for i in range(E)])).cuda()
+        v = torch.from_numpy(np.concatenate([acts[i][1][t] for i in range(E)])).cuda()
+        for eng in [tok_eng, *engs.values()]:
+            eng.actions.copy_(a)
+            eng.vibe_actions.copy_(v)
+        torch.cuda.synchronize()
+        for eng in [tok_eng, *engs.values()]:
+            eng.step()
+            eng.sync()
+        torch.cuda.synchronize()
+        want = obs_decode.decode(tok_eng.obs.cpu().numpy(), C, H, W, scale)
+        standalone = tok_eng.decode_obs()
+        tok_eng.sync()
+        assert np.array_equal(standalone.cpu().numpy(), want)
+        assert np.array_equal(boxes[torch.float32].cpu().numpy(), want), f"{name} step {t + 1}: fused float32 box differs"
+        got16 = boxes[torch.bfloat16].view(torch.int16).cpu().numpy().view(np.uint16)
+        assert np.array_equal(got16, _bf16_bits(want)), f"{name} step {t + 1}: fused bfloat16 box differs"
+        for eng in engs.values():
+            assert torch.equal(eng.rewards, tok_eng.rewards) and torch.equal(eng.truncations, tok_eng.truncations)
+    dig = tok_eng.state_digests()
+    for eng in engs.values():
+        assert np.array_equal(eng.state_digests(), dig)      # token statistics included
+        assert eng.poll_errors()[0] == 0
+    # back to token rows
+    eng = engs[torch.float32]
+    eng.set_box_output(None)
+    eng.actions.zero_(); eng.vibe_actions.zero_(); tok_eng.actions.zero_(); tok_eng.vibe_actions.zero_()
+    torch.cuda.synchronize()
+    eng.step(); tok_eng.step(); eng.sync(); tok_eng.sync()
+    assert torch.equal(eng.obs, tok_eng.obs)
+    with pytest.raises(ValueError):
+        eng.set_box_output(torch.zeros((1, C, H, W), device="cuda"))

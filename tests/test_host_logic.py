@@ -182,3 +182,41 @@ def test_state_digest_many_equals_scalar_digest():
                           o.current_step, o.invalid_index_extra()))
         got = sg.state_digest_many(dumps)
         assert [int(g) for g in got] == [sg.state_digest(*d) for d in dumps]
+
+
+def test_more_than_thirteen_resources_is_refused_cleanly_at_every_layer():
+    """R <= 13 is the engine's inventory limit (one 4-bit id per item in the order word; 13 = the bucket count of libstdc++'s
+    smallest unordered_map table, so insertion order is 'new node at the head').  The reference has no such limit
+    (objects/inventory.hpp:45): a config with 14+ resources must be refused with a message that names the limit — by the spec
+    compiler, by the lowering of a reference config tree, and by mgx_create itself when handed a forged program."""
+    import ctypes as C
+    import json
+    import os
+
+    import ref_tree
+    from mettagrid_amd import engine, from_reference as fr, presets
+    from mettagrid_amd import spec as S
+    from mettagrid_amd.compiler import UnsupportedFeature, compile_spec
+    from mettagrid_amd.fmt import K
+    for n in (14, 29):
+        sp = presets.rung2_spec()
+        sp.resource_names = [f"r{i}" for i in range(n)]
+        with pytest.raises(UnsupportedFeature, match="at most 13 resources"):
+            compile_spec(sp, 32, 32)
+    # through the reference's config tree (fixture made by the reference's own converter): resource list grown to 14
+    here = os.path.dirname(os.path.abspath(__file__))
+    doc = json.load(open(os.path.join(here, "golden", "ref_chains.json")))
+    cfg = ref_tree.load(doc["config"])
+    cfg.resource_names = list(cfg.resource_names) + [f"extra{i}" for i in range(14 - len(cfg.resource_names))]
+    with pytest.raises(UnsupportedFeature, match="at most 13 resources"):
+        fr.compile_reference_config(cfg, len(doc["map"]), len(doc["map"][0]))
+    # a forged blob: header says 14 resources.  mgx_create validates before it touches the device.
+    prog = compile_spec(presets.rung2_spec(), 32, 32)
+    words = np.ascontiguousarray(prog.words, dtype=np.int32).copy()
+    words[K.H_NUM_RESOURCES] = 14
+    L = engine.load_lib()
+    maps = np.zeros((1, 32, 32), np.uint16)
+    seeds = np.zeros(1, np.uint32)
+    h = C.c_void_p()
+    rc = L.mgx_create(words.ctypes.data, words.size, maps.ctypes.data, seeds.ctypes.data, 1, 0, C.byref(h))
+    assert rc == -3 and b"resources<=13" in L.mgx_last_error()
