@@ -259,6 +259,7 @@ struct mgx_engine {
   }
   bool verbose = false;
   bool rewards_early = false;  // reward expressions have no stat operands: evaluated beside the token-cache phase
+  bool rewards_mid = false;    // extended games: ... read nothing the observation kernel writes: evaluated during its encode phase
   int slot = 0;                // constant-memory slot of the lean world kernel (mgx_world_fast.hip, MGX_SLOT)
   int32_t* d_vibe_ids = nullptr;  // mgx_set_joint_actions: action index of each vibe action
   int32_t vibe_ids_host[256] = {};
@@ -352,7 +353,7 @@ static int size_obs_lds(mgx_engine* e) {
   e->lds_obs = lds_for(e->obs_ew);
   e->obs_variant = 0;
   if (!getenv("MGX_OBS_GENERIC")) {
-    if (!d.X && e->obs_blk_lds && mgx_obs_shape_matches<MgxObsShapeR3>(d, e->obs_blk_words, (int)e->rewards_early)) e->obs_variant = 3;
+    if (!d.X && e->obs_blk_lds && mgx_obs_shape_matches<MgxObsShapeR3>(d, e->obs_blk_words, (e->rewards_early ? 1 : e->rewards_mid ? 2 : 0))) e->obs_variant = 3;
     // (an instance for the shape of configs[3], MgxObsShapeR4, was measured too: 5.07 ms against the generic kernel's 5.01 —
     // the extended kernel's time is barrier and LDS latency, not scalar arithmetic; it is not built)
   }
@@ -360,7 +361,7 @@ static int size_obs_lds(mgx_engine* e) {
     return fail(MGX_ERR_PROGRAM, "map/object count too large for the LDS staging of the observation kernel");
   if (e->verbose || getenv("MGX_VERBOSE"))
     fprintf(stderr, "[mgx] obs: lds=%zu B pool=%d tokens (prefix %d) blk_lds=%d rewards_early=%d\n", e->lds_obs, e->pool_tokens,
-            e->pool_prefix, (int)e->obs_blk_lds, (int)e->rewards_early);
+            e->pool_prefix, (int)e->obs_blk_lds, (e->rewards_early ? 1 : e->rewards_mid ? 2 : 0));
   // The attribute is per kernel and process-wide: keep one maximum and only ever raise it, so that a second engine
   // with a smaller requirement cannot lower the limit under a live one.
   static std::mutex mu;
@@ -391,9 +392,9 @@ static void launch_obs_t(mgx_engine* e, bool with_rewards, const uint8_t* mask) 
   if (PL)  // the interpreted sections are addressed relative to their LDS copy
     for (int k = MGX_SEC_INV_FEATURES; k < MGX_SEC_WORDLIST; k++) dd.sec[k] -= e->obs_blk_start;
   if (with_rewards)
-    hipLaunchKernelGGL((mgx_obs_kernel<true, X, PL, NTH, EW, K>), grid, block, e->lds_obs, e->stream, dd, e->pool_tokens, e->pool_prefix, mask, e->obs_blk_start, e->obs_blk_words, (int)e->rewards_early, (void*)nullptr, (const float*)nullptr, 0, 0);
+    hipLaunchKernelGGL((mgx_obs_kernel<true, X, PL, NTH, EW, K>), grid, block, e->lds_obs, e->stream, dd, e->pool_tokens, e->pool_prefix, mask, e->obs_blk_start, e->obs_blk_words, (e->rewards_early ? 1 : e->rewards_mid ? 2 : 0), (void*)nullptr, (const float*)nullptr, 0, 0);
   else
-    hipLaunchKernelGGL((mgx_obs_kernel<false, X, PL, NTH, EW, K>), grid, block, e->lds_obs, e->stream, dd, e->pool_tokens, e->pool_prefix, mask, e->obs_blk_start, e->obs_blk_words, (int)e->rewards_early, (void*)nullptr, (const float*)nullptr, 0, 0);
+    hipLaunchKernelGGL((mgx_obs_kernel<false, X, PL, NTH, EW, K>), grid, block, e->lds_obs, e->stream, dd, e->pool_tokens, e->pool_prefix, mask, e->obs_blk_start, e->obs_blk_words, (e->rewards_early ? 1 : e->rewards_mid ? 2 : 0), (void*)nullptr, (const float*)nullptr, 0, 0);
 }
 // Device-memory copy of e->d, brought up to date (stream-ordered) whenever the host table changed.
 static const MgxDev* dev_copy(mgx_engine* e) {
@@ -454,7 +455,7 @@ static int launch_obs(mgx_engine* e, bool with_rewards, const uint8_t* mask = nu
     if (pl)
       for (int k = MGX_SEC_INV_FEATURES; k < MGX_SEC_WORDLIST; k++) dd.sec[k] -= e->obs_blk_start;
     if (!mgx_launch_obs_box(e->stream, dd, e->lds_obs, e->pool_tokens, e->pool_prefix, mask, e->obs_blk_start, e->obs_blk_words,
-                            (int)e->rewards_early, with_rewards, e->d.X != 0, pl, e->obs_threads, e->obs_ew, e->box_out, e->d_scale,
+                            (e->rewards_early ? 1 : e->rewards_mid ? 2 : 0), with_rewards, e->d.X != 0, pl, e->obs_threads, e->obs_ew, e->box_out, e->d_scale,
                             e->box_C, e->box_dtype))
       return fail(MGX_ERR_PROGRAM, "mgx_step: no dense-output instance of the observation kernel for this configuration");
     HIP_TRY(hipGetLastError());
@@ -897,6 +898,27 @@ int mgx_create(const int32_t* program, size_t program_words, const uint16_t* cla
       }
     }
     e->rewards_early = pure;
+    // Extended games: the reward expressions may still be evaluated before the kernel's end — by a wavefront that has no
+    // share of the encode — when no operand is something this kernel writes (the cell.visited agent stat, the token game
+    // stats) and none is a query (those go through mgx_values_kernel).
+    {
+      bool safe = d.X != 0;
+      for (int k = 0; k < n_rw && safe; k++) {
+        const int32_t* code = P + d.sec[MGX_SEC_GV_CODE] + rw[k * MGX_RW_WORDS + MGX_RW_GV_START] * MGX_GV_WORDS;
+        for (int i = 0; i < rw[k * MGX_RW_WORDS + MGX_RW_GV_COUNT]; i++) {
+          const int32_t* ins = code + i * MGX_GV_WORDS;
+          const int op = ins[MGX_GV_OP];
+          if (op == MGX_GOP_QUERY_INVENTORY || op == MGX_GOP_QUERY_COUNT) safe = false;
+          if (op == MGX_GOP_STAT) {
+            const int id = ins[MGX_GV_A1];
+            if (ins[MGX_GV_A0] != 1 && id == d.wk[MGX_S_CELL_VISITED]) safe = false;
+            if (ins[MGX_GV_A0] == 1 && (id == d.wk[MGX_S_GAME_TOKENS_WRITTEN] || id == d.wk[MGX_S_GAME_TOKENS_FREE] ||
+                                        id == d.wk[MGX_S_GAME_TOKENS_DROPPED])) safe = false;
+          }
+        }
+      }
+      e->rewards_mid = safe && !getenv("MGX_REWARDS_LATE");
+    }
     auto has_query = [&](int start, int count) {
       for (int i = 0; i < count; i++) {
         const int op = P[d.sec[MGX_SEC_GV_CODE] + (start + i) * MGX_GV_WORDS + MGX_GV_OP];

@@ -249,7 +249,13 @@ __global__ void __launch_bounds__(NTH) mgx_obs_kernel(MgxDev d, int pool_tokens,
             NOFF = FX ? K::NOFF : d.NOFF, HW = dH * dW;
   const int dBase = FX ? K::BASE : d.base, NOV = FX ? K::NOV : d.n_obs_values, dNT = FX ? K::NT : d.NT, dNRW = FX ? K::NRW : d.NRW,
             dFlags = FX ? K::FLAGS : d.flags, dMaxSteps = FX ? K::MAX_STEPS : d.max_steps, dMaskFeat = FX ? K::MASK_FEAT : d.aoe_mask_feat;
-  const int blk_words = FX ? K::BLKW : blk_words_arg, rewards_early = FX ? K::REWARDS_EARLY : rewards_early_arg;
+  const int blk_words = FX ? K::BLKW : blk_words_arg, rewards_mode = FX ? K::REWARDS_EARLY : rewards_early_arg;
+  // when the reward expressions read nothing this kernel writes (host: mgx_create), they need not wait for its end:
+  //   1 = evaluated early, beside the token-list phase (lean games);
+  //   2 = evaluated by a wavefront that takes no part in the encode, during the encode (EW < wavefronts: extended games
+  //       with many agents), instead of by 64 threads behind the final barrier while everybody else idles
+  const int rewards_early = rewards_mode == 1 ? 1 : 0;
+  const bool rewards_mid = rewards_mode == 2 && EW < NTH / MGX_WAVE;
   const int GT = mgx_obs_gt(NOV, dBase);
   const bool want_mask = X && dMaskFeat != 0 && dNT > 0;
   const int xmode = mgx_obs_xmode(X, want_mask, S, d.P[MGX_H_NUM_TAGS]);
@@ -392,6 +398,26 @@ __global__ void __launch_bounds__(NTH) mgx_obs_kernel(MgxDev d, int pool_tokens,
       s_spawn[i] = spawn;
       s_vstat[i] = vs;
       s_rwinfo[i] = ((uint32_t)C[MGX_C_REWARD_START] & 0xFFFFu) | ((uint32_t)C[MGX_C_REWARD_COUNT] << 16);
+      if constexpr (X) {
+        if (want_mask)   // the observer's own tag bitset (friend / foe of a cell's owner tag), once per env
+#pragma unroll
+          for (int w = 0; w < MGX_TAG_WORDS; w++)
+            s_agtags[i * MGX_TAG_WORDS + w] = d.obj_tags ? d.obj_tags[e.so(slot) * MGX_TAG_WORDS + w] : (uint32_t)C[MGX_C_TAGS + w];
+      }
+    }
+    if constexpr (X) {
+      // The territory owner of every cell (TerritoryTracker::compute_observability_at :254-273: the first territory type
+      // with an owner decides; mgx_terr_kernel keeps the per-type maps current) and the query-backed obs values are plain
+      // per-env data: staged here with the grid, one round trip, instead of behind a barrier of their own in the middle
+      // of the kernel.
+      if (want_mask)
+        for (int cellidx = tid; cellidx < HW; cellidx += NTH) {
+          uint16_t owner = 0xFFFF;
+          for (int ti = 0; ti < dNT && owner == 0xFFFF; ti++) owner = d.terr_owner[((size_t)env * dNT + ti) * (size_t)HW + cellidx];
+          if (owner8) s_owner8[cellidx] = (uint8_t)owner; else s_owner[cellidx] = owner;  // (0xFFFF -> 0xFF: tag ids stop at 254 then)
+        }
+      if (d.obsval)  // evaluated by mgx_values_kernel (one env per lane) right before this kernel
+        for (int i = tid; i < A * NOV; i += NTH) s_obsval[i] = d.obsval[(size_t)env * A * NOV + i];
     }
     if (tid == 0) { s_misc[0] = (uint32_t)pool_prefix; s_misc[1] = 0; }  // pool top, number of per-step lists
   }
@@ -558,26 +584,6 @@ __global__ void __launch_bounds__(NTH) mgx_obs_kernel(MgxDev d, int pool_tokens,
       for (int a = lane; a < A; a += MGX_WAVE) agent_rewards(a);
     }
   }
-  if constexpr (X) {
-    if (want_mask) {  // TerritoryTracker::compute_observability_at (:254-273): first territory with an owner decides.
-                      // The per-type ownership maps are current here: mgx_terr_kernel runs right before this kernel.
-      for (int cellidx = tid; cellidx < HW; cellidx += NTH) {
-        uint16_t owner = 0xFFFF;
-        for (int ti = 0; ti < dNT && owner == 0xFFFF; ti++) owner = d.terr_owner[((size_t)env * dNT + ti) * (size_t)HW + cellidx];
-        if (owner8) s_owner8[cellidx] = (uint8_t)owner; else s_owner[cellidx] = owner;  // (0xFFFF -> 0xFF: tag ids stop at 254 then)
-      }
-      // the observers' own tag bitsets, once per env instead of one HBM round trip per masked window cell
-      for (int i = tid; i < A * MGX_TAG_WORDS; i += NTH) {
-        const int slot = (int)(s_agents[i / MGX_TAG_WORDS] & 0xFFFF);
-        s_agtags[i] = d.obj_tags ? d.obj_tags[e.so(slot) * MGX_TAG_WORDS + (i % MGX_TAG_WORDS)]
-                                 : (uint32_t)e.cls_of(slot)[MGX_C_TAGS + (i % MGX_TAG_WORDS)];
-      }
-    }
-    if (d.obsval)  // query-backed obs values: evaluated by mgx_values_kernel (one env per lane) right before this kernel
-      for (int i = tid; i < A * NOV; i += NTH) s_obsval[i] = d.obsval[(size_t)env * A * NOV + i];
-    if (want_mask || (d.obsval && NOV > 0)) __syncthreads();  // read by other threads below
-  }
-
   // ---- phase 1: per agent the list of window cells that will emit tokens, in window order (ballot compaction), and
   // the first observer (lowest agent index) of every object.  The encode loop then only walks real entries. ----
   // (the wavefront that evaluates the early rewards is left out when another free one exists: its job is as long as
@@ -723,6 +729,8 @@ __global__ void __launch_bounds__(NTH) mgx_obs_kernel(MgxDev d, int pool_tokens,
   // ---- phase 2: encode.  One agent per 16-lane DPP row, four agents per wavefront at a time: an agent sees ~15-20
   // occupied cells, so a whole wavefront per agent left three quarters of the lanes idle.  Scans are row scans (four
   // DPP steps), row-wide values travel by ds_bpermute, long token lists are copied by the 16 lanes of their row. ----
+  if (WITH_REWARDS && rewards_mid && wave == (NTH / MGX_WAVE) - 1)
+    for (int a = lane; a < A; a += MGX_WAVE) agent_rewards(a);
   for (int a0 = wave < EW ? wave * 4 : A; a0 < A; a0 += EW * 4) {
     const int a = a0 + row;
     const bool av = a < A;          // this row has an agent
@@ -914,7 +922,7 @@ __global__ void __launch_bounds__(NTH) mgx_obs_kernel(MgxDev d, int pool_tokens,
     }
   }
   MGX_TICK(13);
-  if (WITH_REWARDS && !rewards_early) {
+  if (WITH_REWARDS && !rewards_early && !rewards_mid) {
     // (reward expressions with query operands never reach this kernel: mgx_values_kernel evaluates them, one env per
     // lane, after it — the host launches this kernel without rewards then)
     for (int a = tid; a < A; a += NTH) agent_rewards(a);
