@@ -201,6 +201,10 @@ int mgx_get_step_timing(mgx_engine* e, float* ms_out /* [MGX_T_COUNT] */);
 /* Which instance of the observation kernel the engine launches: 0 = the generic one (shape read at run time), 3 = the
  * instance compiled for the shape of BASELINE.json configs[2] (mettagrid_amd/gen_presets.py). Diagnostic. */
 int32_t mgx_obs_variant(const mgx_engine* e);
+/* How the action dispatch of MettaGrid::_step (mettagrid_c.cpp:966-999) is executed: 0 = one lane per env, agents one
+ * after another; 1 = one lane per agent, in rounds ordered by the agents' cell footprints (mgx_act.h) — chosen at
+ * mgx_create when every handler an action can reach stays with its actor and target.  Same results. Diagnostic. */
+int32_t mgx_act_variant(const mgx_engine* e);
 int32_t mgx_num_envs(const mgx_engine* e);
 int32_t mgx_num_agents(const mgx_engine* e);   /* per env */
 int32_t mgx_num_tokens(const mgx_engine* e);

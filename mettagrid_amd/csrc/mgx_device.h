@@ -38,6 +38,10 @@ struct MgxDev {
                           // sec[] entries are relative to it in that kernel's copy of this table)
   int x_aoe_lds;          // 1: the extended world kernel runs the AoE phase itself and keeps its scratch in LDS
   int defer_book;         // 1: per-action bookkeeping stats are applied in one batched pass at the end of the tick
+  int act_par;            // 1: the action dispatch runs in mgx_act_kernel (one lane per AGENT, conflict-ordered rounds; mgx_act.h)
+  int act_tick;           // 1: ... and the per-agent on_tick handlers too (lean games), one lane per agent
+  int act_ngset;          // game-scope stats the action-phase handlers SET (StatsMutation): applied in agent order at the end
+  int act_gset_ids[4];
   int feat[16];
   int wk[32];             // well-known stat ids (MGX_S_*)
 

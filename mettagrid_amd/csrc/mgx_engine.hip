@@ -227,7 +227,7 @@ struct mgx_engine {
   float* h_rew = nullptr;
   int32_t *h_act = nullptr, *h_vact = nullptr;
   bool external = false;
-  size_t lds_world = 0, lds_obs = 0;
+  size_t lds_world = 0, lds_obs = 0, lds_act = 0;
   int obs_threads = MGX_OBS_THREADS, obs_ew = MGX_OBS_THREADS / MGX_WAVE;
   int obs_variant = 0;   // 0: generic observation kernel; 3: the instance specialised for the shape of BASELINE.json configs[2]
   int box_dtype = 0, box_C = 0;   // mgx_set_box_output: the observation kernel writes the dense box instead of token rows
@@ -886,6 +886,119 @@ int mgx_create(const int32_t* program, size_t program_words, const uint16_t* cla
     d.flat_top = flat ? 1 : 0;
     if (getenv("MGX_VERBOSE")) fprintf(stderr, "[mgx] action-phase handlers on the %s VM\n", flat ? "register" : "LDS");
   }
+  {  // Can the action dispatch run with one lane per AGENT (mgx_act.h)?  Every handler an action reaches must stay with
+     // its actor and target, look at no game-wide state, and the order of game-stat SETs must be recoverable.
+    bool par = !getenv("MGX_ACT_SERIAL");
+    int ap = 1;
+    while (ap < d.A) ap <<= 1;
+    if (d.A > 64) par = false;
+    if (!d.X && 16 * ap > 256) par = false;   // mgx_act_fast.hip: 16 envs per workgroup of at most 256 lanes
+    // Measured (MI355X, 65 536 envs): 64 agents per env 4.92 -> 2.0 ms; 16 agents per env 0.445 -> 0.52 ms — four envs share
+    // a wavefront there and a round costs what 2.4 serial steps cost, so lean games stay lane per env unless asked.
+    if (!d.X && !getenv("MGX_ACT_LEAN")) par = false;
+    if (d.X && !d.flat_top) par = false;      // tag mutations, query recomputation / filters: lane-per-env VM
+    const int32_t* mh = P + d.sec[MGX_SEC_MOVE_HANDLERS];
+    for (int k = 0; k < d.n_move_handlers; k++)
+      if (mh[k * MGX_MH_WORDS + MGX_MH_MAX_RANGE] != 1) par = false;   // footprint = own cell + the cell ahead
+    for (int c = 0; c < P[MGX_H_NUM_CLASSES]; c++) {
+      const int32_t* C = P + d.sec[MGX_SEC_CLASSES] + c * MGX_C_WORDS;
+      if (d.X && C[MGX_C_KIND] == MGX_KIND_AGENT && C[MGX_C_TERR_COUNT] > 0) par = false;   // a moving territory source re-registers
+    }
+    std::vector<int> gset;
+    const int n_code = mgx_sec_cnt(P, MGX_SEC_GV_CODE), n_vals = mgx_sec_cnt(P, MGX_SEC_OBS_VALUES);
+    auto pure_value = [&](int rec) {   // reads inventories, agent-scope stats and constants only
+      if (rec < 0) return true;
+      if (rec >= n_vals) return false;
+      const int32_t* V = P + d.sec[MGX_SEC_OBS_VALUES] + rec * MGX_OV_WORDS;
+      for (int q = 0; q < V[MGX_OV_GV_COUNT]; q++) {
+        const int at = V[MGX_OV_GV_START] + q;
+        if (at < 0 || at >= n_code) return false;
+        const int32_t* g = P + d.sec[MGX_SEC_GV_CODE] + at * MGX_GV_WORDS;
+        if (g[MGX_GV_OP] == MGX_GOP_QUERY_INVENTORY || g[MGX_GV_OP] == MGX_GOP_QUERY_COUNT) return false;
+        if (g[MGX_GV_OP] == MGX_GOP_STAT && g[MGX_GV_A0] == 1) return false;
+      }
+      return true;
+    };
+    const int n_atoms = mgx_sec_cnt(P, MGX_SEC_ATOMS), n_hd = mgx_sec_cnt(P, MGX_SEC_HANDLERS);
+    bool saw_use_target = false;
+    auto local = [&](std::vector<int> todo, bool may_move) {   // every handler reachable from `todo`
+      std::vector<char> hseen(n_hd, 0);
+      std::vector<int> stack;
+      auto push = [&](int h) { if (h >= 0 && h < n_hd && !hseen[h]) { hseen[h] = 1; stack.push_back(h); } };
+      for (int h : todo) push(h);
+      bool use_target = false;
+      while (!stack.empty()) {
+        const int32_t* hd = P + d.sec[MGX_SEC_HANDLERS] + stack.back() * MGX_HD_WORDS;
+        stack.pop_back();
+        if (hd[MGX_HD_KIND] != MGX_HK_LEAF) {
+          const int32_t* kids = P + d.sec[MGX_SEC_CHILDREN] + hd[MGX_HD_CHILD_START];
+          for (int i = 0; i < hd[MGX_HD_CHILD_COUNT]; i++) push(kids[i]);
+          continue;
+        }
+        for (int i = 0; i < hd[MGX_HD_MUT_COUNT]; i++) {
+          const int32_t* m = P + d.sec[MGX_SEC_MUTS] + (hd[MGX_HD_MUT_START] + i) * MGX_MU_WORDS;
+          switch (m[MGX_MU_OP]) {
+            case MGX_MOP_RESOURCE_DELTA: case MGX_MOP_CLEAR_INVENTORY: case MGX_MOP_ATTACK: case MGX_MOP_CHANGE_VIBE: break;
+            case MGX_MOP_RESOURCE_TRANSFER: if (d.X && m[MGX_MU_A4]) return false; break;   // may remove the emptied object
+            case MGX_MOP_RELOCATE: case MGX_MOP_SWAP: if (!may_move) return false; break;
+            case MGX_MOP_USE_TARGET: use_target = true; break;
+            case MGX_MOP_STATS:
+              if (!pure_value(m[MGX_MU_A3])) return false;
+              if (m[MGX_MU_A0] == 0 && std::find(gset.begin(), gset.end(), m[MGX_MU_A2]) == gset.end()) gset.push_back(m[MGX_MU_A2]);
+              break;
+            case MGX_MOP_GAME_VALUE: {
+              if (!pure_value(m[MGX_MU_A1]) || !pure_value(m[MGX_MU_A2])) return false;   // (a game-scope target is impure too)
+              break;
+            }
+            default: return false;
+          }
+        }
+        std::vector<int> pcs{hd[MGX_HD_FILTER_PC]};
+        std::vector<char> aseen(n_atoms, 0);
+        while (!pcs.empty()) {
+          const int pc = pcs.back();
+          pcs.pop_back();
+          if (pc < 0 || pc >= n_atoms || aseen[pc]) continue;
+          aseen[pc] = 1;
+          const int32_t* a = P + d.sec[MGX_SEC_ATOMS] + pc * MGX_AT_WORDS;
+          switch (a[MGX_AT_OP]) {
+            case MGX_FOP_VIBE: case MGX_FOP_RESOURCE: case MGX_FOP_SHARED_TAG: case MGX_FOP_TAG: case MGX_FOP_TARGET_LOC_EMPTY:
+            case MGX_FOP_TARGET_IS_USABLE: case MGX_FOP_PERIODIC: case MGX_FOP_TRUE: break;
+            case MGX_FOP_GAME_VALUE: if (!pure_value(a[MGX_AT_A1]) || !pure_value(a[MGX_AT_A2])) return false; break;
+            case MGX_FOP_MAX_DISTANCE: if (a[MGX_AT_A2] >= 0) return false; break;
+            default: return false;
+          }
+          pcs.push_back(a[MGX_AT_ON_TRUE]);
+          pcs.push_back(a[MGX_AT_ON_FALSE]);
+        }
+      }
+      saw_use_target = use_target;   // UseTarget applies the target's on_use / the actor's on_after_use: roots of the action phase
+      return true;
+    };
+    std::vector<int> act_roots, tick_roots;
+    for (int k = 0; k < d.n_move_handlers; k++) act_roots.push_back(mh[k * MGX_MH_WORDS + MGX_MH_HANDLER]);
+    for (int c = 0; c < P[MGX_H_NUM_CLASSES]; c++) {
+      const int32_t* C = P + d.sec[MGX_SEC_CLASSES] + c * MGX_C_WORDS;
+      act_roots.push_back(C[MGX_C_ON_USE]);
+      act_roots.push_back(C[MGX_C_ON_AFTER_USE]);
+      tick_roots.push_back(C[MGX_C_ON_TICK]);
+    }
+    if (par && !local(act_roots, true)) par = false;
+    bool tick = false;
+    if (par && !d.X) {   // the lean kernel is the whole world update: its on_tick handlers must be lane-local as well
+      if (d.any_on_tick && (!local(tick_roots, false) || saw_use_target)) par = false;   // (an on_tick handler that uses itself: lane per env)
+      tick = par;
+    }
+    if (gset.size() > 4) par = false;
+#ifdef MGX_CPU_EMU
+    par = false;   // wavefront-cooperative (ballot / readlane): not part of the sanitizer build
+#endif
+    d.act_par = par ? 1 : 0;
+    d.act_tick = (par && tick) ? 1 : 0;
+    d.act_ngset = par ? (int)gset.size() : 0;
+    for (int k = 0; k < 4; k++) d.act_gset_ids[k] = (par && k < (int)gset.size()) ? gset[k] : -1;
+    if (getenv("MGX_VERBOSE")) fprintf(stderr, "[mgx] action dispatch: one lane per %s\n", par ? "agent (conflict-ordered rounds)" : "env");
+  }
   {  // reward code made only of inventory / constant arithmetic reads nothing the observation kernel writes
     bool pure = !d.X;
     const int32_t* rw = P + d.sec[MGX_SEC_REWARDS];
@@ -955,6 +1068,13 @@ int mgx_create(const int32_t* program, size_t program_words, const uint16_t* cla
             : (e->slot == 0 ? mgx_world_fast_set_lds_s0(e->lds_world) : mgx_world_fast_set_lds_s1(e->lds_world)))) {
     mgx_destroy(e);
     return fail(MGX_ERR_HIP, "mgx_create: cannot raise the world kernel's dynamic LDS limit");
+  }
+  if (d.act_par) {
+    e->lds_act = (d.X ? mgx_act_x_lds_bytes(d.A, d.x_aoe_lds != 0) : mgx_act_fast_lds_bytes(d.A)) + (e->prog_in_lds ? (size_t)e->prog_lds_words * 4 : 0);
+    if (!(d.X ? mgx_act_x_set_lds(e->lds_act) : (e->slot == 0 ? mgx_act_fast_set_lds_s0(e->lds_act) : mgx_act_fast_set_lds_s1(e->lds_act)))) {
+      mgx_destroy(e);
+      return fail(MGX_ERR_HIP, "mgx_create: cannot raise the action kernel's dynamic LDS limit");
+    }
   }
   if (e->verbose && d.X)
     fprintf(stderr, "[mgx] extended world kernel: %zu bytes of private memory per lane\n", mgx_world_x_private_bytes());
@@ -1321,12 +1441,23 @@ int mgx_step(mgx_engine* e) {
     const int pw = e->prog_lds_words;
     if (e->world_after) HIP_TRY(hipStreamWaitEvent(e->stream, e->world_after->world_done, 0));
     MGX_TRACE_POINT(e, "before world");
+    const bool x_events = d.n_schedule > 0 || (d.any_on_tick && !d.tick_in_aoe);   // what is left of the action launch behind mgx_act_kernel
     if (!d.X) {
-      if (e->slot == 0) mgx_launch_world_fast_s0(e->prog_in_lds, e->lds_world, e->stream, e->d, pw);
-      else mgx_launch_world_fast_s1(e->prog_in_lds, e->lds_world, e->stream, e->d, pw);
+      if (d.act_par) {
+        if (e->slot == 0) mgx_launch_act_fast_s0(e->prog_in_lds, e->lds_act, e->stream, e->d, pw);
+        else mgx_launch_act_fast_s1(e->prog_in_lds, e->lds_act, e->stream, e->d, pw);
+      } else {
+        if (e->slot == 0) mgx_launch_world_fast_s0(e->prog_in_lds, e->lds_world, e->stream, e->d, pw);
+        else mgx_launch_world_fast_s1(e->prog_in_lds, e->lds_world, e->stream, e->d, pw);
+      }
       MGX_MARK(1); MGX_MARK(2); MGX_MARK(3);
     } else if (e->aoe_local && (d.NF > 0 || d.NM > 0 || d.NT > 0)) {
-      mgx_launch_world_x(e->prog_in_lds, e->lds_world, e->stream, e->d, dev_copy_world_x(e), pw, MGX_PH_ACTIONS);
+      if (d.act_par) {
+        mgx_launch_act_x(e->prog_in_lds, e->lds_act, e->stream, e->d, dev_copy_world_x(e), pw);
+        if (x_events) mgx_launch_world_x(e->prog_in_lds, e->lds_world, e->stream, e->d, dev_copy_world_x(e), pw, MGX_PH_EVENTS);
+      } else {
+        mgx_launch_world_x(e->prog_in_lds, e->lds_world, e->stream, e->d, dev_copy_world_x(e), pw, MGX_PH_ACTIONS | MGX_PH_EVENTS);
+      }
       MGX_TRACE_POINT(e, "world kernel (actions)");
       MGX_MARK(1);
       int trc = launch_terr(e);  // the per-agent territory effects read the ownership map
@@ -1337,7 +1468,12 @@ int mgx_step(mgx_engine* e) {
       if (!d.cov_in_aoe) mgx_launch_world_x(e->prog_in_lds, e->lds_world, e->stream, e->d, dev_copy_world_x(e), pw, MGX_PH_TAIL);
       MGX_MARK(3);
     } else {
-      mgx_launch_world_x(e->prog_in_lds, e->lds_world, e->stream, e->d, dev_copy_world_x(e), pw, MGX_PH_ALL);
+      if (d.act_par) {
+        mgx_launch_act_x(e->prog_in_lds, e->lds_act, e->stream, e->d, dev_copy_world_x(e), pw);
+        mgx_launch_world_x(e->prog_in_lds, e->lds_world, e->stream, e->d, dev_copy_world_x(e), pw, MGX_PH_ALL & ~MGX_PH_ACTIONS);
+      } else {
+        mgx_launch_world_x(e->prog_in_lds, e->lds_world, e->stream, e->d, dev_copy_world_x(e), pw, MGX_PH_ALL);
+      }
       MGX_MARK(1); MGX_MARK(2); MGX_MARK(3);
     }
     MGX_TRACE_POINT(e, "world kernel");
@@ -1719,6 +1855,7 @@ int mgx_get_step_timing(mgx_engine* e, float* ms_out) {
 }
 
 int32_t mgx_obs_variant(const mgx_engine* e) { return e ? e->obs_variant : 0; }
+int32_t mgx_act_variant(const mgx_engine* e) { return e ? e->d.act_par : 0; }
 int32_t mgx_num_envs(const mgx_engine* e) { return e ? e->d.E : 0; }
 int32_t mgx_num_agents(const mgx_engine* e) { return e ? e->d.A : 0; }
 int32_t mgx_num_tokens(const mgx_engine* e) { return e ? e->d.T : 0; }

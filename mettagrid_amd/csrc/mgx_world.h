@@ -101,10 +101,18 @@ MGX_DBG_LINKAGE __device__ unsigned long long mgx_dbg_cycles[16];
 #define MGX_WORLD_EPG 64
 #endif
 #define MGX_WORLD_THREADS (MGX_WAVE * (MGX_WORLD_EPG / MGX_WORLD_LPW))
+#ifdef MGX_ACT_TU
+// Agent-parallel action kernel (mgx_act.h): a workgroup owns MGX_WORLD_EPG envs, each env a run of A' = blockDim / EPG
+// consecutive lanes (A' = agents per env rounded up to a power of two, <= 64: an env never straddles a wavefront).
+__device__ __forceinline__ int mgx_act_shift() { return (31 - __clz((int)blockDim.x)) - (31 - __clz(MGX_WORLD_EPG)); }
+__device__ __forceinline__ int mgx_world_lane() { return (int)(threadIdx.x >> mgx_act_shift()); }
+#else
 __device__ __forceinline__ int mgx_world_lane() {  // index of this lane's env inside the workgroup's 64-env group
   return (int)((threadIdx.x >> 6) * MGX_WORLD_LPW + (threadIdx.x & (MGX_WAVE - 1)));
 }
+#endif
 
+#define MGX_ACT_GSET 4
 // Extended handler VM: frames and handler contexts per lane (see MgxEnvT::vm_run).
 #define MGX_VM_FRAMES 6
 #define MGX_VM_CTXS 6
@@ -128,6 +136,9 @@ __host__ __device__ inline int mgx_world_xlds_off(int A) { return ((A * MGX_WORL
 __host__ __device__ inline int mgx_world_lds_fixed(int A, bool X, bool aoe_lds = true) {
   int o = ((A * MGX_WORLD_EPG + 15) & ~15) + ((mgx_world_alds_bytes(A) + 15) & ~15);
   if (X) o += MGX_VM_WORDS * MGX_WORLD_EPG * 4 + (aoe_lds ? 28 * MGX_WORLD_EPG * 4 + 8 * MGX_WORLD_EPG * 8 : 0);
+#ifdef MGX_ACT_TU
+  o += MGX_ACT_GSET * MGX_WORLD_EPG * 8;  // (order position + 1) << 32 | f32 bits of the last game-stat set, per env
+#endif
   return o;
 }
 __device__ __forceinline__ MgxALds mgx_world_alds(uint8_t* lds, int A, int lane) {
@@ -178,6 +189,21 @@ struct MgxEnvT {  // per-lane view of one env
   MgxALds al_;
   mutable int cur_agent, cur_slot;  // agent whose action is being executed (LDS write-through of its position)
   mutable int grid_dirty;           // a grid cell was written since do_move last looked at the move target
+#ifdef MGX_ACT_TU
+  int act_pos = 0;  // this lane's place in the order the reference walks the agents in (shuffled order / agent index)
+  // StatsMutation on a game-scope stat from concurrently running agents: the set of the LAST agent in order must win.
+  // Each set goes to a per-env LDS cell as (position + 1) << 32 | value bits under a 64-bit max; mgx_act_body applies the
+  // surviving value when the phase is over.  (The host only selects this kernel when nothing reads those stats mid-phase.)
+  __device__ __forceinline__ unsigned long long* act_gset_cells() const {
+    return (unsigned long long*)(mgx_dyn_lds + mgx_world_lds_fixed(d.A, X, d.x_aoe_lds != 0) - MGX_ACT_GSET * MGX_WORLD_EPG * 8);
+  }
+  __device__ __forceinline__ void act_gstat_set(int id, float v) const {
+    int k = 0;
+    while (k < d.act_ngset - 1 && d.act_gset_ids[k] != id) k++;
+    const unsigned long long w = ((unsigned long long)(act_pos + 1) << 32) | (unsigned long long)__float_as_uint(v);
+    atomicMax(act_gset_cells() + k * MGX_WORLD_EPG + mgx_world_lane(), w);
+  }
+#endif
 #ifdef MGX_CONST_DEV
   __device__ MgxEnvT(const MgxDev&, PP prog, int e) : P_(prog), env_(e), step(0), cur_agent(-1), cur_slot(-1), grid_dirty(1) {
 #else
@@ -749,7 +775,11 @@ struct MgxEnvT {  // per-lane view of one env
     }
     return pc == MGX_PC_PASS;
   }
+#ifdef MGX_ACT_TU  // the lane-per-agent kernels only run programs whose action-phase handlers evaluate no query (MgxDev::act_par)
+  static constexpr int TOPQ = 0;
+#else
   static constexpr int TOPQ = X ? 3 : 0;  // query nesting available to top-level filter/value evaluation
+#endif
 
   // ---- grid (core/grid.hpp:75-113) ----
   __device__ __forceinline__ uint16_t& cell(int r, int c) const { return d.grid[(size_t)envi() * d.H * d.W + r * d.W + c]; }
@@ -919,9 +949,11 @@ struct MgxEnvT {  // per-lane view of one env
         int moved = transfer(s, t, a2, amount);
         int sa = agent_of(s);
         if (moved > 0 && sa >= 0) astat_add(sa, d.wk[MGX_S_RES_DEPOSITED_BASE] + a2, (float)moved);
+#ifndef MGX_ACT_TU
         if constexpr (X) {
           if (m[MGX_MU_A4] && (d.obj_order[so(s)] & 0xF) == 0xF) remove_object(s);  // resource_mutation.hpp:88-97
         }
+#endif
         break;
       }
       case MGX_MOP_CLEAR_INVENTORY: {  // resource_mutation.hpp:111-128
@@ -950,7 +982,11 @@ struct MgxEnvT {  // per-lane view of one env
       case MGX_MOP_STATS: {  // stats_mutation.hpp:21-41
         int e = resolve(c, a1);
         float v = eval_value<TOPQ>(a3, e, c, 0);
+#ifdef MGX_ACT_TU
+        if (a0 == 0) act_gstat_set(a2, v);
+#else
         if (a0 == 0) gstat_set(a2, v);
+#endif
         else { int a = agent_of(e); if (a >= 0) astat_set(a, a2, v); }
         break;
       }
@@ -995,6 +1031,7 @@ struct MgxEnvT {  // per-lane view of one env
         }
         break;
       }
+#ifndef MGX_ACT_TU  // (tag mutations, object creation / removal, query mutations never reach the lane-per-agent kernels)
       case MGX_MOP_PUSH_OBJECT: {  // push_object_mutation.hpp:33-67
         if (c.actor < 0 || c.target < 0) { c.mutation_failed = true; break; }
         uint16_t arc = d.obj_rc[so(c.actor)], trc = d.obj_rc[so(c.target)];
@@ -1058,6 +1095,7 @@ struct MgxEnvT {  // per-lane view of one env
         }
         break;
       }
+#endif
       default: flag(4u); break;
     }
   }
@@ -1782,6 +1820,50 @@ struct MgxEnvT {  // per-lane view of one env
     }
   }
 
+  // bookkeeping_flush for ONE agent (the lane-per-agent kernel, mgx_act.h: every lane flushes its own agent)
+  __device__ MGX_BIG void bookkeeping_flush_one(int i) const {
+    const int A = d.A, lane = AL().lane;
+    const int s_max = d.wk[MGX_S_MAX_STEPS_WITHOUT_MOTION], s_failed = d.wk[MGX_S_ACTION_FAILED];
+    const int li = i * MGX_WORLD_EPG + lane;
+    const uint32_t res0 = (uint32_t)(uint16_t)AL().act[li], res1 = (uint32_t)(uint16_t)AL().act[A * MGX_WORLD_EPG + li];
+    if (!((res0 | res1) & 1)) return;
+    auto stat_of = [&](uint32_t r) {
+      const int kind = (r >> 1) & 3;
+      const int base = kind == MGX_AK_NOOP ? MGX_S_NOOP_SUCCESS : kind == MGX_AK_MOVE ? MGX_S_MOVE_SUCCESS : MGX_S_VIBE_SUCCESS;
+      return (r & 1) ? d.wk[base + ((r & 8) ? 0 : 1)] : -1;
+    };
+    const int id0 = stat_of(res0), id1 = stat_of(res1);
+    const int nfail = ((res0 & 9) == 1 ? 1 : 0) + ((res1 & 9) == 1 ? 1 : 0);
+    const size_t sb = ao(i) * d.NSP;
+    uint32_t swm = d.ag_swm[ao(i)];
+    const float v0 = d.ag_stats[sb + max(id0, 0)], v1 = d.ag_stats[sb + max(id1, 0)];
+    const float vf = d.ag_stats[sb + max(s_failed, 0)];
+    float mx = d.ag_stats[sb + max(s_max, 0)];
+    const uint32_t tw = d.ag_touched[ao(i) * d.NSW + (max(s_max, 0) >> 5)];
+    bool set_max = false;
+#pragma unroll
+    for (int call = 0; call < 2; call++) {
+      const uint32_t r = call ? res1 : res0;
+      if (!(r & 1)) continue;
+      if (r & 16) swm = 0;
+      else { swm += 1; if ((float)swm > mx) { mx = (float)swm; set_max = true; } }
+    }
+    d.ag_swm[ao(i)] = swm;
+    d.ag_prev[ao(i)] = AL().prev[li];
+    if (set_max && s_max >= 0) {
+      d.ag_stats[sb + s_max] = mx;
+      d.ag_touched[ao(i) * d.NSW + (s_max >> 5)] = tw | (1u << (s_max & 31));
+    }
+    // (id0 == id1 cannot happen: the primary stream never holds a vibe action, the vibe stream nothing else)
+    if (id0 >= 0) d.ag_stats[sb + id0] = __fadd_rn(v0, 1.f);
+    if (id1 >= 0) d.ag_stats[sb + id1] = __fadd_rn(v1, 1.f);
+    if (nfail && s_failed >= 0) {
+      float f = __fadd_rn(vf, 1.f);
+      if (nfail > 1) f = __fadd_rn(f, 1.f);
+      d.ag_stats[sb + s_failed] = f;
+    }
+  }
+
   // `cnt` (<= 8) consecutive generator outputs, same stream as cnt calls of rng_next: word i of the incremental twist
   // needs the OLD words i + 1 and i + 397, and none of the words this block rewrites is within 397 of another.
   __device__ __forceinline__ void rng_block(uint32_t (&r)[8], uint32_t cnt) const {
@@ -1911,11 +1993,77 @@ __device__ __forceinline__ void mgx_swap(uint8_t* order, int lane, int i, int j)
   order[j * MGX_WORLD_EPG + lane] = a;
 }
 
+// std::shuffle (bits/stl_algo.h:3729-3795): one draw for an even n, then paired draws.  The generator outputs
+// are produced eight at a time (rng_block): one round trip for the state words of the whole shuffle instead of
+// three dependent ones per draw.  A Lemire rejection (probability < 1e-7) simply consumes one more output.
+template <class ENV>
+__device__ __forceinline__ void mgx_shuffle_order(const ENV& e, uint8_t* order, int lane, int A) {
+  if (A >= 2) {
+    const uint32_t ndraw = (uint32_t)A / 2;  // A even: 1 + (A - 2) / 2, A odd: (A - 1) / 2
+    uint32_t j = 0;                          // draws done
+    while (j < ndraw) {
+      uint32_t r[8];
+      const uint32_t cnt = min(8u, ndraw - j);
+      e.rng_block(r, cnt);
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        if ((uint32_t)q < cnt) {
+          const bool first_even = (A & 1) == 0 && j == 0;
+          const uint32_t i = (A & 1) == 0 ? 2 * j : 2 * j + 1;  // index of the pair's first element (paired draws)
+          const uint32_t sft = i + 1;
+          const uint32_t range = first_even ? 2u : sft * (sft + 1);
+          const unsigned long long pr = (unsigned long long)r[q] * range;
+          const uint32_t low = (uint32_t)pr;
+          const bool accept = low >= range || low >= (0u - range) % range;
+          if (accept) {
+            const uint32_t x = (uint32_t)(pr >> 32);
+            if (first_even) {
+              mgx_swap(order, lane, 1, (int)x);
+            } else {
+              mgx_swap(order, lane, (int)i, (int)(x / (sft + 1)));
+              mgx_swap(order, lane, (int)i + 1, (int)(x % (sft + 1)));
+            }
+            j++;
+          }
+        }
+      }
+    }
+  }
+}
+
+// One agent's action of one stream (the body of the dispatch loop, mettagrid_c.cpp:966-999): invalid-index bookkeeping,
+// the stream / kind check, ActionHandler::handle_action and the executed / success rows.
+template <class ENV, class PP>
+__device__ __forceinline__ void mgx_dispatch_one(const ENV& e, const MgxDev& d, PP acts, const MgxALds& al, int ai, int stream, int lane, int repeats) {
+  const int A = d.A;
+  int a = al.act[(stream * A + ai) * MGX_WORLD_EPG + lane];
+  if (a < 0 || a >= d.nact) {  // _handle_invalid_action :914-919
+    a = (stream == 0 ? d.actions : d.vibe_actions)[e.ao(ai)];  // the raw index (the staged copy is saturated to int16)
+    for (int rep = 0; rep < repeats; rep++) {
+      e.astat_add(ai, d.wk[MGX_S_INVALID_INDEX], 1.f);
+      if (a < 0 && a >= -MGX_INVALID_WINDOW) e.astat_add(ai, d.wk[MGX_S_INVALID_NEG_BASE] + a + MGX_INVALID_WINDOW, 1.f);
+      else if (a >= d.nact && a < d.nact + MGX_INVALID_WINDOW) e.astat_add(ai, d.wk[MGX_S_INVALID_POS_BASE] + a - d.nact, 1.f);
+      else e.invalid_extra(ai, a);
+    }
+    d.success[e.ao(ai)] = 0;
+    al.act[(stream * A + ai) * MGX_WORLD_EPG + lane] = 0;  // no handle_action call: empty result byte
+    return;
+  }
+  const bool is_vibe = acts[a * MGX_AC_WORDS + MGX_AC_KIND] == MGX_AK_VIBE;
+  if (is_vibe != (stream == 1)) { al.act[(stream * A + ai) * MGX_WORLD_EPG + lane] = 0; return; }
+  if (e.handle_action(ai, a, stream)) {
+    d.executed[e.ao(ai)] = a;
+    d.success[e.ao(ai)] = 1;
+  }
+}
+
 // phases (extended variant; the lean one always runs everything): MGX_PH_ACTIONS = steps 1-6 of _step (snapshot, ++step,
 // shuffle, action dispatch, timestep events, per-agent on_tick), MGX_PH_AOE = fixed AoE + territory per agent, mobile
 // AoE, deferred AoE registration (the general, serial form; games whose area effects only touch their target run
 // mgx_aoe_kernel instead: one lane per AGENT), MGX_PH_TAIL = game on_tick + coverage tracking.
-enum { MGX_PH_ACTIONS = 1, MGX_PH_AOE = 2, MGX_PH_TAIL = 4, MGX_PH_ALL = 7 };
+// MGX_PH_EVENTS = timestep events + the serial per-agent on_tick loop (part of MGX_PH_ACTIONS' launch unless the dispatch
+// itself ran in mgx_act_kernel).
+enum { MGX_PH_ACTIONS = 1, MGX_PH_AOE = 2, MGX_PH_TAIL = 4, MGX_PH_EVENTS = 8, MGX_PH_ALL = 15 };
 template <class PP, bool X>
 __device__ __forceinline__ void mgx_world_body(const MgxDev& d, PP P, uint8_t* order, MgxXLds xl, MgxALds al, int lane, int env, int phases) {
   MgxEnvT<PP, X> e(d, P, env);
@@ -1924,7 +2072,14 @@ __device__ __forceinline__ void mgx_world_body(const MgxDev& d, PP P, uint8_t* o
   MGX_TICK0();
   if constexpr (!X) phases = MGX_PH_ALL;
   const bool act = (phases & MGX_PH_ACTIONS) != 0;
+  const bool evt = (phases & MGX_PH_EVENTS) != 0;
   e.step = act ? ++d.step[env] : d.step[env];
+  if constexpr (X) {
+    if (phases == MGX_PH_EVENTS && !(d.any_on_tick && !d.tick_in_aoe)) {  // launched behind mgx_act_kernel: most steps have no event due
+      const uint32_t k = d.next_event[env];
+      if (k >= (uint32_t)d.n_schedule || (uint32_t)d.P[d.sec[MGX_SEC_SCHEDULE] + k * MGX_SC_WORDS + MGX_SC_TIMESTEP] > e.step) return;
+    }
+  }
   if (act) {  // executed_actions / _action_success cleared (mettagrid_c.cpp:944,962-964): done here (a few 16-byte
               // stores per env) instead of two memset launches per step
     if ((A & 3) == 0) {
@@ -1971,40 +2126,7 @@ __device__ __forceinline__ void mgx_world_body(const MgxDev& d, PP P, uint8_t* o
   }
   e.al_ = al;
   MGX_TICK(0);
-  // std::shuffle (bits/stl_algo.h:3729-3795): one draw for an even n, then paired draws.  The generator outputs
-  // are produced eight at a time (rng_block): one round trip for the state words of the whole shuffle instead of
-  // three dependent ones per draw.  A Lemire rejection (probability < 1e-7) simply consumes one more output.
-  if (A >= 2 && act) {
-    const uint32_t ndraw = (uint32_t)A / 2;  // A even: 1 + (A - 2) / 2, A odd: (A - 1) / 2
-    uint32_t j = 0;                          // draws done
-    while (j < ndraw) {
-      uint32_t r[8];
-      const uint32_t cnt = min(8u, ndraw - j);
-      e.rng_block(r, cnt);
-#pragma unroll
-      for (int q = 0; q < 8; q++) {
-        if ((uint32_t)q < cnt) {
-          const bool first_even = (A & 1) == 0 && j == 0;
-          const uint32_t i = (A & 1) == 0 ? 2 * j : 2 * j + 1;  // index of the pair's first element (paired draws)
-          const uint32_t sft = i + 1;
-          const uint32_t range = first_even ? 2u : sft * (sft + 1);
-          const unsigned long long pr = (unsigned long long)r[q] * range;
-          const uint32_t low = (uint32_t)pr;
-          const bool accept = low >= range || low >= (0u - range) % range;
-          if (accept) {
-            const uint32_t x = (uint32_t)(pr >> 32);
-            if (first_even) {
-              mgx_swap(order, lane, 1, (int)x);
-            } else {
-              mgx_swap(order, lane, (int)i, (int)(x / (sft + 1)));
-              mgx_swap(order, lane, (int)i + 1, (int)(x % (sft + 1)));
-            }
-            j++;
-          }
-        }
-      }
-    }
-  }
+  if (act) mgx_shuffle_order(e, order, lane, A);
   // Action dispatch (mettagrid_c.cpp:966-999).  The reference loops over priority levels max..0 and, inside each,
   // over the primary then the vibe stream.  Every real action handler has priority 0 and the only thing the
   // higher (empty) levels do is repeat the invalid-index bookkeeping, so one pass per stream with the invalid-index
@@ -2013,34 +2135,13 @@ __device__ __forceinline__ void mgx_world_body(const MgxDev& d, PP P, uint8_t* o
   const int repeats = d.max_priority + 1;
   MGX_TICK(1);
   for (int stream = 0; stream < (act ? 2 : 0); stream++) {
-    for (int k = 0; k < A; k++) {
-      int ai = order[k * MGX_WORLD_EPG + lane];
-      int a = al.act[(stream * A + ai) * MGX_WORLD_EPG + lane];
-      if (a < 0 || a >= d.nact) {  // _handle_invalid_action :914-919
-        a = (stream == 0 ? d.actions : d.vibe_actions)[e.ao(ai)];  // the raw index (the staged copy is saturated to int16)
-        for (int rep = 0; rep < repeats; rep++) {
-          e.astat_add(ai, d.wk[MGX_S_INVALID_INDEX], 1.f);
-          if (a < 0 && a >= -MGX_INVALID_WINDOW) e.astat_add(ai, d.wk[MGX_S_INVALID_NEG_BASE] + a + MGX_INVALID_WINDOW, 1.f);
-          else if (a >= d.nact && a < d.nact + MGX_INVALID_WINDOW) e.astat_add(ai, d.wk[MGX_S_INVALID_POS_BASE] + a - d.nact, 1.f);
-          else e.invalid_extra(ai, a);
-        }
-        d.success[e.ao(ai)] = 0;
-        al.act[(stream * A + ai) * MGX_WORLD_EPG + lane] = 0;  // no handle_action call: empty result byte
-        continue;
-      }
-      bool is_vibe = acts[a * MGX_AC_WORDS + MGX_AC_KIND] == MGX_AK_VIBE;
-      if (is_vibe != (stream == 1)) { al.act[(stream * A + ai) * MGX_WORLD_EPG + lane] = 0; continue; }
-      if (e.handle_action(ai, a, stream)) {
-        d.executed[e.ao(ai)] = a;
-        d.success[e.ao(ai)] = 1;
-      }
-    }
+    for (int k = 0; k < A; k++) mgx_dispatch_one(e, d, acts, al, order[k * MGX_WORLD_EPG + lane], stream, lane, repeats);
     MGX_TICK(2 + stream);
   }
   if constexpr (X) {
-    if (act && d.n_schedule > 0) e.process_events();  // mettagrid_c.cpp:1009-1011
+    if (evt && d.n_schedule > 0) e.process_events();  // mettagrid_c.cpp:1009-1011
   }
-  if (d.any_on_tick && act && !d.tick_in_aoe) {
+  if (d.any_on_tick && evt && !d.tick_in_aoe) {
     for (int i = 0; i < A; i++) {  // per-agent on_tick (mettagrid_c.cpp:1019-1024); slot and class come from LDS
       const int li = i * MGX_WORLD_EPG + lane;
       const int slot = al.slot[li];
@@ -2124,6 +2225,15 @@ void mgx_launch_world_fast_s0(bool prog_lds, size_t lds, hipStream_t stream, con
 void mgx_launch_world_fast_s1(bool prog_lds, size_t lds, hipStream_t stream, const MgxDev& d, int prog_words);
 bool mgx_world_fast_set_lds_s0(size_t lds);  // raises the kernels' dynamic LDS limit (needed past 64 KB)
 bool mgx_world_fast_set_lds_s1(size_t lds);
+// the lane-per-agent action kernels (mgx_act_fast.hip, mgx_act_x.hip; mgx_act.h)
+size_t mgx_act_fast_lds_bytes(int A);
+void mgx_launch_act_fast_s0(bool prog_lds, size_t lds, hipStream_t stream, const MgxDev& d, int prog_words);
+void mgx_launch_act_fast_s1(bool prog_lds, size_t lds, hipStream_t stream, const MgxDev& d, int prog_words);
+bool mgx_act_fast_set_lds_s0(size_t lds);
+bool mgx_act_fast_set_lds_s1(size_t lds);
+void mgx_launch_act_x(bool prog_lds, size_t lds, hipStream_t stream, const MgxDev& d, const MgxDev* dev_copy, int prog_words);
+bool mgx_act_x_set_lds(size_t lds);
+size_t mgx_act_x_lds_bytes(int A, bool aoe_lds);
 // ... and of the extended one (mgx_world_x.hip)
 void mgx_launch_world_x(bool prog_lds, size_t lds, hipStream_t stream, const MgxDev& d, const MgxDev* dev_copy, int prog_words, int phases);
 bool mgx_world_x_set_lds(size_t lds);

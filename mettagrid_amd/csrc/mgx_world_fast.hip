@@ -79,3 +79,12 @@ void MGX_CAT(mgx_launch_world_fast_s, MGX_SLOT)(bool prog_lds, size_t lds, hipSt
   if (prog_lds) hipLaunchKernelGGL((mgx_world_kernel_fast<true>), grid, block, lds, stream, prog_words);
   else hipLaunchKernelGGL((mgx_world_kernel_fast<false>), grid, block, lds, stream, prog_words);
 }
+
+#if defined(MGX_WORLD_TIMING) && MGX_SLOT == 0  // instrumented developer build only (scripts/world_timing.py); not part of the ABI
+extern "C" int mgx_debug_world_cycles(unsigned long long* out, int reset) {
+  hipDeviceSynchronize();
+  hipMemcpyFromSymbol(out, HIP_SYMBOL(mgx_dbg_cycles), sizeof(unsigned long long) * 16);
+  if (reset) { unsigned long long z[16] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(mgx_dbg_cycles), z, sizeof z); }
+  return 0;
+}
+#endif

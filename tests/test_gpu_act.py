@@ -1,0 +1,138 @@
+"""GPU: the action dispatch with one lane per AGENT (csrc/mgx_act.h) — agents of an env run side by side in rounds
+ordered by their cell footprints — must give what the reference's one-after-another walk in shuffled order gives
+(mettagrid_c.cpp:966-999).  Checked three ways: every scenario of the parity suite again with the lean games forced onto
+that kernel; crowded arenas where most agents touch another agent every step (attack / loot / swap chains, the case a
+swapped agent attacks from its new cell before a later agent's turn); and the two kernels against each other on thousands
+of envs by state digest."""
+import os
+
+import numpy as np
+import pytest
+
+import helpers as hp
+import oracle_py as op
+from mettagrid_amd import presets
+from mettagrid_amd.compiler import compile_spec
+from mettagrid_amd.engine import BatchedMettaGrid
+from mettagrid_amd.mapgen import random_class_maps, random_map
+
+pytestmark = pytest.mark.gpu
+
+
+def _against_oracle(prog, cms, seeds, steps, rng_seed, where, expect_variant):
+    import torch
+    E, A = len(cms), prog.num_agents
+    eng = BatchedMettaGrid(prog, cms, seeds, buffers="device")
+    assert eng.act_variant == expect_variant, (where, eng.act_variant)
+    oracles = [op.OracleSim(prog, cms[i], int(seeds[i])) for i in range(E)]
+    for o in oracles:
+        o.reinit_buffers()
+    rng = np.random.default_rng(rng_seed)
+    n_act = len(prog.action_names)
+    for t in range(steps):
+        a = rng.integers(-1, n_act + 1, E * A).astype(np.int32)
+        v = rng.integers(0, n_act, E * A).astype(np.int32)
+        eng.actions.copy_(torch.from_numpy(a)); eng.vibe_actions.copy_(torch.from_numpy(v)); torch.cuda.synchronize()
+        eng.step()
+        snap = eng.snapshot()
+        for i, o in enumerate(oracles):
+            o.step(a[i * A:(i + 1) * A], v[i * A:(i + 1) * A])
+            hp.compare_snapshots(o.snapshot(), {k: x[i * A:(i + 1) * A] for k, x in snap.items()}, f"{where} env {i} step {t + 1}")
+    bits = 0
+    for o in oracles:
+        bits |= int(o.error)
+    assert eng.poll_errors()[0] == bits     # (crowded arenas may overflow the token budget: both sides flag it)
+    snap = eng.snapshot()
+    for i, o in enumerate(oracles):
+        mine = {k: x[i * A:(i + 1) * A] for k, x in snap.items()}
+        pa = hp.payload_from_raw(prog, o.raw_objects(), o.current_stat_reward(), o.raw_stats(), o.snapshot(), steps, int(seeds[i]))
+        pb = hp.payload_from_raw(prog, eng.raw_objects(i), eng.current_stat_reward(i), eng.raw_stats(i), mine, steps, int(seeds[i]))
+        assert pa == pb, f"{where} env {i}: signature payload differs: {hp.diff_payload(pa, pb)}"
+    eng.close()
+
+
+@pytest.mark.parametrize("name", list(hp.SCENARIOS))
+def test_every_scenario_with_lean_games_on_the_agent_kernel(name, monkeypatch):
+    monkeypatch.setenv("MGX_ACT_LEAN", "1")
+    from test_gpu_parity import test_step_parity
+    test_step_parity(name, "device")
+
+
+def test_crowded_lean_arena(monkeypatch):
+    """16 agents of two teams on a 9x9 floor (rung-3 rules: attack + loot, same-team swap, extractors, chests): nearly every
+    move meets another agent, chains of three and more are the rule."""
+    monkeypatch.setenv("MGX_ACT_LEAN", "1")
+    prog = compile_spec(presets.rung3_spec(), 11, 11, max_objects=192)
+    E = 24
+    maps = [random_map(11, 11, {"wall": 3, "extractor": 4, "chest": 2}, {"red": 8, "blue": 8}, 900 + s) for s in range(E)]
+    cms = np.stack([prog.class_map(m) for m in maps])
+    _against_oracle(prog, cms, np.arange(E, dtype=np.uint32) + 77, 60, 5, "crowded lean arena", 1)
+
+
+def test_crowded_extended_arena():
+    """BASELINE.json configs[3] rules (64 agents, four teams) squeezed into 20x20: AoE, territory and events run behind a
+    dispatch in which a third of the agents conflict with somebody every step."""
+    prog = compile_spec(presets.rung4_spec(obs_tokens=400), 20, 20, max_objects=presets.RUNG4_MAX_OBJECTS)
+    objs = {"wall": 8, "extractor": 6, "chest": 4, "healer_red": 1, "healer_blue": 1, "healer_green": 1, "healer_yellow": 1,
+            "flag_red": 1, "flag_blue": 1, "flag_green": 1, "flag_yellow": 1, "hub": 1, "wire": 3}
+    E = 8
+    maps = [random_map(20, 20, dict(objs), dict(presets.RUNG4_AGENTS), 300 + s) for s in range(E)]
+    cms = np.stack([prog.class_map(m) for m in maps])
+    _against_oracle(prog, cms, np.arange(E, dtype=np.uint32) + 5, 56, 6, "crowded extended arena", 1)
+
+
+@pytest.mark.parametrize("rung", [3, 4])
+def test_agent_kernel_equals_env_kernel_by_digest(rung, monkeypatch):
+    """Same maps, seeds and action traces through both kernels: equal state digests after every tenth step, 8 192 envs."""
+    import torch
+    E = 8192
+    if rung == 3:
+        prog = compile_spec(presets.rung3_spec(), 32, 32, max_objects=192)
+        maps = random_class_maps(prog, 32, 32, {"wall": 40, "extractor": 8, "chest": 4}, {"red": 8, "blue": 8}, range(1024))
+        steps = 120
+    else:
+        prog = compile_spec(presets.rung4_spec(), 64, 64, max_objects=presets.RUNG4_MAX_OBJECTS)
+        maps = random_class_maps(prog, 64, 64, presets.RUNG4_OBJECTS, presets.RUNG4_AGENTS, range(512))
+        steps = 60
+    cms = maps[np.arange(E) % len(maps)]
+    seeds = np.arange(E, dtype=np.uint32)
+    monkeypatch.setenv("MGX_ACT_LEAN", "1")
+    par = BatchedMettaGrid(prog, cms, seeds, buffers="device")
+    monkeypatch.setenv("MGX_ACT_SERIAL", "1")
+    ser = BatchedMettaGrid(prog, cms, seeds, buffers="device")
+    assert (par.act_variant, ser.act_variant) == (1, 0)
+    A, n_act = prog.num_agents, len(prog.action_names)
+    gen = torch.Generator(device="cuda").manual_seed(7 + rung)
+    for t in range(steps):
+        a = torch.randint(-1, n_act + 1, (E * A,), dtype=torch.int32, device="cuda", generator=gen)
+        v = torch.randint(0, n_act, (E * A,), dtype=torch.int32, device="cuda", generator=gen)
+        for eng in (par, ser):
+            eng.actions.copy_(a); eng.vibe_actions.copy_(v)
+            eng.wait_for_caller(); eng.step(); eng.caller_waits()
+        if (t + 1) % 10 == 0:
+            dp, ds = par.state_digests(), ser.state_digests()
+            bad = np.nonzero(dp != ds)[0]
+            assert len(bad) == 0, f"rung {rung} step {t + 1}: envs {bad[:8].tolist()} differ ({len(bad)})"
+    assert par.poll_errors()[0] == 0 and ser.poll_errors()[0] == 0
+    par.close(); ser.close()
+
+
+def test_variant_choice(monkeypatch):
+    """Extended games whose action handlers stay with actor and target take the agent kernel; a handler that mutates tags
+    (rung-4 `dynamic` scenario), more than 64 agents, or MGX_ACT_SERIAL keep the env kernel."""
+    def variant(name):
+        spec_f, map_f, _, _ = hp.SCENARIOS[name]
+        m = map_f(0)
+        prog = hp.compile_scenario(name, spec_f(), *m.shape)
+        eng = BatchedMettaGrid(prog, prog.class_map(m)[None], [1], buffers="host")
+        v = eng.act_variant
+        eng.close()
+        return v
+    assert variant("rung4_full") == 1
+    assert variant("rung3") == 0            # lean games: lane per env unless MGX_ACT_LEAN is set (measured slower at 16 agents)
+    assert variant("crowd") == 0            # 70 agents
+    monkeypatch.setenv("MGX_ACT_LEAN", "1")
+    assert variant("rung3") == 1
+    assert variant("crowd") == 0
+    monkeypatch.setenv("MGX_ACT_SERIAL", "1")
+    assert variant("rung4_full") == 0
