@@ -205,6 +205,10 @@ int32_t mgx_obs_variant(const mgx_engine* e);
  * after another; 1 = one lane per agent, in rounds ordered by the agents' cell footprints (mgx_act.h) — chosen at
  * mgx_create when every handler an action can reach stays with its actor and target.  Same results. Diagnostic. */
 int32_t mgx_act_variant(const mgx_engine* e);
+/* Which code runs the handlers of the action phase: 0 = the interpreter; 3 / 4 = the straight-line code the build generated
+ * for BASELINE.json configs[2] / configs[3] (mettagrid_amd/gen_handlers.py), selected when the program's handler tables
+ * hash to the preset's fingerprint.  Same results. Diagnostic. */
+int32_t mgx_handler_variant(const mgx_engine* e);
 int32_t mgx_num_envs(const mgx_engine* e);
 int32_t mgx_num_agents(const mgx_engine* e);   /* per env */
 int32_t mgx_num_tokens(const mgx_engine* e);

@@ -51,6 +51,49 @@ __device__ __forceinline__ void mgx_act_apply_gsets(const ENV& e, const MgxDev& 
   }
 }
 
+// std::shuffle of the env's agent order (bits/stl_algo.h:3729-3795; same draws as mgx_shuffle_order) with the order held one
+// element per lane — lane p of the env's run holds order[p] — so that a swap is one cross-lane read instead of four
+// dependent LDS accesses.  The generator's outputs are drawn by the run's first lane, eight at a time, and broadcast.
+// Every lane of the wavefront executes the same sequence (runs that are done, or not in use, swap nothing).
+template <class ENV>
+__device__ __forceinline__ int mgx_act_shuffle(const ENV& e, int A, int p, int segbase, bool env_valid) {
+  int ord = p;
+  const uint32_t nd = (env_valid && A >= 2) ? (uint32_t)A / 2 : 0u;  // A even: 1 + (A - 2) / 2 draws, A odd: (A - 1) / 2
+  uint32_t j = 0;                                                      // draws done (the same in every lane of the run)
+  auto swap = [&](int a, int b) {   // a < 0: nothing
+    const int src = a < 0 ? p : p == a ? b : p == b ? a : p;
+    ord = __shfl(ord, segbase + src);
+  };
+  while (__any(j < nd)) {
+    uint32_t r[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+    const uint32_t cnt = j < nd ? min(8u, nd - j) : 0u;
+    if (p == 0 && cnt > 0) e.rng_block(r, cnt);
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      const uint32_t rq = (uint32_t)__shfl((int)r[q], segbase);
+      int a1 = -1, b1 = 0, a2 = -1, b2 = 0;
+      if ((uint32_t)q < cnt) {
+        const bool first_even = (A & 1) == 0 && j == 0;
+        const uint32_t i = (A & 1) == 0 ? 2 * j : 2 * j + 1;  // index of the pair's first element (paired draws)
+        const uint32_t sft = i + 1;
+        const uint32_t range = first_even ? 2u : sft * (sft + 1);
+        const unsigned long long pr = (unsigned long long)rq * range;
+        const uint32_t low = (uint32_t)pr;
+        const bool accept = low >= range || low >= (0u - range) % range;   // (Lemire: a rejection consumes one more output)
+        if (accept) {
+          const uint32_t x = (uint32_t)(pr >> 32);
+          if (first_even) { a1 = 1; b1 = (int)x; }
+          else { a1 = (int)i; b1 = (int)(x / (sft + 1)); a2 = (int)i + 1; b2 = (int)(x % (sft + 1)); }
+          j++;
+        }
+      }
+      swap(a1, b1);
+      swap(a2, b2);
+    }
+  }
+  return ord;
+}
+
 // envl: env inside the workgroup, p: lane inside the env's run, seg: the run's lanes inside the wavefront
 template <class PP, bool X>
 __device__ __forceinline__ void mgx_act_body(const MgxDev& d, PP P, uint8_t* order, MgxALds al, int envl, int p, int env, bool valid,
@@ -82,16 +125,19 @@ __device__ __forceinline__ void mgx_act_body(const MgxDev& d, PP P, uint8_t* ord
     if (al.cls) al.cls[li] = cls;
     al.act[li] = mgx_sat16(a); al.act[A * MGX_WORLD_EPG + li] = mgx_sat16(v);
     if (d.flags & MGX_G_LAST_ACTION_MOVE) d.ag_stepprev[e.ao(i)] = rc;  // mettagrid_c.cpp:929-931
-    order[li] = (uint8_t)i;
     d.executed[e.ao(i)] = 0;
     d.success[e.ao(i)] = 0;
   }
   mgx_act_fence();
   MGX_TICK(0);
-  if (valid && p == 0) mgx_shuffle_order(e, order, envl, A);  // one generator per env: its draws are serial
-  mgx_act_fence();
+  const int segbase = wl - p;
+  const int ai = mgx_act_shuffle(e, A, p, segbase, env < d.E);
   MGX_TICK(1);
-  const int ai = valid ? (int)order[p * MGX_WORLD_EPG + envl] : 0;
+  // footprints u32[A'][EPG] (by order position) and, when the map is small enough, cell -> order position of the pending
+  // agent standing there u8[EPG][H * W] (entries are validated against the footprints, so stale ones are harmless)
+  uint32_t* fps = (uint32_t*)(mgx_dyn_lds + mgx_world_lds_fixed(A, X, d.x_aoe_lds != 0));
+  const int apad = (int)(blockDim.x / MGX_WORLD_EPG);
+  uint8_t* cmap = (uint8_t*)(fps + apad * MGX_WORLD_EPG) + (size_t)envl * ((d.H * d.W + 15) & ~15);
   e.act_pos = p;
   PP acts = P + d.sec[MGX_SEC_ACTIONS];
   const int repeats = d.max_priority + 1;
@@ -138,6 +184,34 @@ __device__ __forceinline__ void mgx_act_body(const MgxDev& d, PP P, uint8_t* ord
       if ((pend & seg & ((1ull << wl) - 1ull)) != 0ull) clear = false;
 #endif
       bool hit = false;  // an earlier pending agent acts on THIS agent's cell
+      if (d.act_map) {
+        // Every conflict is local: the other agent stands on my target cell, or next to my cell / my target cell and acts
+        // on it.  Pending agents publish footprint and cell; a lane then looks at the 17 cells that matter.
+        if (pending) {
+          fps[p * MGX_WORLD_EPG + envl] = F;
+          cmap[(own >> 8) * d.W + (own & 0xFF)] = (uint8_t)p;
+        }
+        mgx_act_fence();
+        if (pending) {
+          auto at = [&](int r, int c, uint32_t& Fj) -> bool {   // an earlier pending agent standing on (r, c)?
+            if (r < 0 || c < 0 || r >= d.H || c >= d.W) return false;
+            const int j = cmap[r * d.W + c];
+            if (j >= p || !((pend >> (segbase + j)) & 1ull)) return false;
+            Fj = fps[j * MGX_WORLD_EPG + envl];
+            return (Fj >> 16) == (uint32_t)((r << 8) | c);
+          };
+          uint32_t Fj;
+          const int orow = (int)(own >> 8), ocol = (int)(own & 0xFF), trow = (int)(tgt >> 8), tcol = (int)(tgt & 0xFF);
+          if (tgt != own && at(trow, tcol, Fj)) clear = false;                      // tgt == oj
+#pragma unroll
+          for (int k = 0; k < 9; k++) {
+            if (k == 4) continue;
+            const int dr = k / 3 - 1, dc = k % 3 - 1;
+            if (at(orow + dr, ocol + dc, Fj) && (Fj & 0xFFFFu) == own) { clear = false; hit = true; }   // own == tj
+            if (tgt != own && at(trow + dr, tcol + dc, Fj) && (Fj & 0xFFFFu) == tgt) clear = false;     // tgt == tj
+          }
+        }
+      } else
       for (unsigned long long m = pend; m;) {  // wave-uniform walk over the pending lanes
         const int j = __builtin_ctzll(m);
         m &= m - 1;
@@ -205,7 +279,7 @@ __device__ __forceinline__ void mgx_act_entry(const MgxDev& d, int prog_words) {
   const unsigned long long seg = sh >= 6 ? ~0ull : (((1ull << (1 << sh)) - 1ull) << (wl & ~((1 << sh) - 1)));
   const MgxALds al = mgx_world_alds(mgx_dyn_lds, d.A, envl);
   if (PROG_LDS) {
-    int32_t* lprog = (int32_t*)(mgx_dyn_lds + mgx_world_lds_fixed(d.A, X, d.x_aoe_lds != 0));
+    int32_t* lprog = (int32_t*)(mgx_dyn_lds + mgx_world_lds_fixed(d.A, X, d.x_aoe_lds != 0, d.act_lds_extra));
     const int4* src = (const int4*)(d.P + d.hot_lo);
     int4* dst = (int4*)lprog;
     for (int i = threadIdx.x; i < prog_words / 4; i += blockDim.x) dst[i] = src[i];

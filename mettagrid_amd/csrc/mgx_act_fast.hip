@@ -14,6 +14,10 @@
 #define MGX_TU_NS MGX_CAT(mgx_tu_actf, MGX_SLOT)
 #define MGX_CONST_DEV 1
 #define MGX_WORLD_IDS 1
+#ifndef MGX_NO_GEN_HANDLERS
+#define MGX_GEN_HANDLERS MgxGenR3   // straight-line handler code of the preset (mgx_handlers_gen.h), used when MgxDev::gen_prog says so
+#define MGX_GEN_ID 3
+#endif
 // 16 envs per workgroup: 256 lanes at 16 agents per env (four envs per wavefront); games with more agents stay lane per env.
 #define MGX_WORLD_EPG 16
 #define MGX_WORLD_LPW 64
@@ -53,7 +57,8 @@ bool MGX_CAT(mgx_act_fast_set_lds_s, MGX_SLOT)(size_t lds) {
 }
 
 #if MGX_SLOT == 0
-size_t mgx_act_fast_lds_bytes(int A) { return (size_t)mgx_world_lds_fixed(A, false); }
+size_t mgx_act_fast_lds_bytes(int A, int extra) { return (size_t)mgx_world_lds_fixed(A, false, true, extra); }
+int mgx_act_fast_epg() { return MGX_WORLD_EPG; }
 #endif
 
 static std::mutex g_dev_mutex;

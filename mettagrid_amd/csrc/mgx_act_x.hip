@@ -11,6 +11,10 @@
 #define MGX_ACT_TU 1
 #define MGX_TU_NS mgx_tu_actx
 #define MGX_WORLD_IDS 1
+#ifndef MGX_NO_GEN_HANDLERS
+#define MGX_GEN_HANDLERS MgxGenR4   // straight-line handler code of the preset (mgx_handlers_gen.h), used when MgxDev::gen_prog says so
+#define MGX_GEN_ID 4
+#endif
 #define MGX_HOT_PROG 1
 #define MGX_NO_CLS_STAGE 1
 // 4 envs per workgroup: 256 lanes at 64 agents per env (one env per wavefront)
@@ -48,7 +52,8 @@ bool mgx_act_x_set_lds(size_t lds) {
   g_lds_max = lds;
   return true;
 }
-size_t mgx_act_x_lds_bytes(int A, bool aoe_lds) { return (size_t)mgx_world_lds_fixed(A, true, aoe_lds); }
+size_t mgx_act_x_lds_bytes(int A, bool aoe_lds, int extra) { return (size_t)mgx_world_lds_fixed(A, true, aoe_lds, extra); }
+int mgx_act_x_epg() { return MGX_WORLD_EPG; }
 
 void mgx_launch_act_x(bool prog_lds, size_t lds, hipStream_t stream, const MgxDev& d, const MgxDev* dp, int prog_words) {
   int ap = 1;

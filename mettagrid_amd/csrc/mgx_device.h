@@ -38,10 +38,13 @@ struct MgxDev {
                           // sec[] entries are relative to it in that kernel's copy of this table)
   int x_aoe_lds;          // 1: the extended world kernel runs the AoE phase itself and keeps its scratch in LDS
   int defer_book;         // 1: per-action bookkeeping stats are applied in one batched pass at the end of the tick
+  int gen_prog;           // 3 / 4: the program's handler tables equal the preset the build generated straight-line code for (0: none)
   int act_par;            // 1: the action dispatch runs in mgx_act_kernel (one lane per AGENT, conflict-ordered rounds; mgx_act.h)
   int act_tick;           // 1: ... and the per-agent on_tick handlers too (lean games), one lane per agent
   int act_ngset;          // game-scope stats the action-phase handlers SET (StatsMutation): applied in agent order at the end
   int act_gset_ids[4];
+  int act_lds_extra;      // bytes per workgroup behind the game-stat cells: footprints u32[A'][EPG] | cell map u8[EPG][H*W] (0: no cell map)
+  int act_map;            // 1: conflicts are looked up through the cell map (H*W <= 4096); 0: all-pairs walk over the pending lanes
   int feat[16];
   int wk[32];             // well-known stat ids (MGX_S_*)
 

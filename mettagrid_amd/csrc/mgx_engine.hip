@@ -14,6 +14,7 @@
 #include "mgx_device.h"
 #include "mgx_obs.h"
 #include "mgx_presets_gen.h"   // MgxObsShapeR3 / R4: the benchmark presets' shapes (mettagrid_amd/gen_presets.py, written at build())
+#include "mgx_handlers_fp.h"   // fingerprints of the presets' handler tables (mettagrid_amd/gen_handlers.py, written at build())
 #include "mgx_world.h"
 #include "mgx_aoe_local.h"
 
@@ -886,6 +887,25 @@ int mgx_create(const int32_t* program, size_t program_words, const uint16_t* cla
     d.flat_top = flat ? 1 : 0;
     if (getenv("MGX_VERBOSE")) fprintf(stderr, "[mgx] action-phase handlers on the %s VM\n", flat ? "register" : "LDS");
   }
+  {  // Do the handler tables equal a preset the build generated straight-line handler code for (mgx_handlers_gen.h)?
+    unsigned long long h = 0xCBF29CE484222325ull;   // FNV-1a over 32-bit words: mettagrid_amd/gen_handlers.py fingerprint()
+    auto mix = [&](int32_t v) { h = (h ^ (unsigned long long)(uint32_t)v) * 0x100000001B3ull; };
+    const int secs[5] = {MGX_SEC_HANDLERS, MGX_SEC_CHILDREN, MGX_SEC_ATOMS, MGX_SEC_MUTS, MGX_SEC_MOVE_HANDLERS};
+    const int words[5] = {MGX_HD_WORDS, 1, MGX_AT_WORDS, MGX_MU_WORDS, MGX_MH_WORDS};
+    for (int k = 0; k < 5; k++) {
+      const int n = mgx_sec_cnt(P, secs[k]);
+      mix(n);
+      for (int i = 0; i < n * words[k]; i++) mix(P[d.sec[secs[k]] + i]);
+    }
+    mix(P[MGX_H_NUM_CLASSES]);
+    for (int c = 0; c < P[MGX_H_NUM_CLASSES]; c++) {
+      const int32_t* C = P + d.sec[MGX_SEC_CLASSES] + c * MGX_C_WORDS;
+      mix(C[MGX_C_ON_USE]); mix(C[MGX_C_ON_AFTER_USE]); mix(C[MGX_C_ON_TICK]);
+    }
+    mix(P[MGX_H_GAME_ON_TICK]);
+    d.gen_prog = getenv("MGX_NO_GEN") ? 0 : (!d.X && h == MGX_GEN_R3_FP) ? 3 : (d.X && h == MGX_GEN_R4_FP) ? 4 : 0;
+    if (getenv("MGX_VERBOSE")) fprintf(stderr, "[mgx] handler code: %s\n", d.gen_prog ? "generated for this program at build()" : "interpreter");
+  }
   {  // Can the action dispatch run with one lane per AGENT (mgx_act.h)?  Every handler an action reaches must stay with
      // its actor and target, look at no game-wide state, and the order of game-stat SETs must be recoverable.
     bool par = !getenv("MGX_ACT_SERIAL");
@@ -1070,7 +1090,15 @@ int mgx_create(const int32_t* program, size_t program_words, const uint16_t* cla
     return fail(MGX_ERR_HIP, "mgx_create: cannot raise the world kernel's dynamic LDS limit");
   }
   if (d.act_par) {
-    e->lds_act = (d.X ? mgx_act_x_lds_bytes(d.A, d.x_aoe_lds != 0) : mgx_act_fast_lds_bytes(d.A)) + (e->prog_in_lds ? (size_t)e->prog_lds_words * 4 : 0);
+    {  // footprint table + (maps up to 64 x 64) the cell map of the conflict lookup, per workgroup
+      int ap = 1;
+      while (ap < d.A) ap <<= 1;
+      const int epg = d.X ? mgx_act_x_epg() : mgx_act_fast_epg();
+      d.act_map = (d.H * d.W <= 4096 && !getenv("MGX_ACT_NO_MAP")) ? 1 : 0;
+      d.act_lds_extra = ((4 * ap * epg + 15) & ~15) + (d.act_map ? epg * ((d.H * d.W + 15) & ~15) : 0);
+    }
+    e->lds_act = (d.X ? mgx_act_x_lds_bytes(d.A, d.x_aoe_lds != 0, d.act_lds_extra) : mgx_act_fast_lds_bytes(d.A, d.act_lds_extra)) +
+                 (e->prog_in_lds ? (size_t)e->prog_lds_words * 4 : 0);
     if (!(d.X ? mgx_act_x_set_lds(e->lds_act) : (e->slot == 0 ? mgx_act_fast_set_lds_s0(e->lds_act) : mgx_act_fast_set_lds_s1(e->lds_act)))) {
       mgx_destroy(e);
       return fail(MGX_ERR_HIP, "mgx_create: cannot raise the action kernel's dynamic LDS limit");
@@ -1856,6 +1884,7 @@ int mgx_get_step_timing(mgx_engine* e, float* ms_out) {
 
 int32_t mgx_obs_variant(const mgx_engine* e) { return e ? e->obs_variant : 0; }
 int32_t mgx_act_variant(const mgx_engine* e) { return e ? e->d.act_par : 0; }
+int32_t mgx_handler_variant(const mgx_engine* e) { return e ? e->d.gen_prog : 0; }
 int32_t mgx_num_envs(const mgx_engine* e) { return e ? e->d.E : 0; }
 int32_t mgx_num_agents(const mgx_engine* e) { return e ? e->d.A : 0; }
 int32_t mgx_num_tokens(const mgx_engine* e) { return e ? e->d.T : 0; }

@@ -133,11 +133,13 @@ __host__ __device__ inline int mgx_world_xlds_off(int A) { return ((A * MGX_WORL
 // i32[prog_words] (when it fits).
 // (aoe_lds: the deferred-delta and territory-score scratch of the in-kernel AoE phase; games whose AoE runs in
 // mgx_aoe_kernel do without it, which is what lets a fourth 32-env workgroup fit a CU at 64 agents per env)
-__host__ __device__ inline int mgx_world_lds_fixed(int A, bool X, bool aoe_lds = true) {
+// (act_extra: the lane-per-agent kernels' footprint table + cell map, MgxDev::act_lds_extra)
+__host__ __device__ inline int mgx_world_lds_fixed(int A, bool X, bool aoe_lds = true, int act_extra = 0) {
   int o = ((A * MGX_WORLD_EPG + 15) & ~15) + ((mgx_world_alds_bytes(A) + 15) & ~15);
   if (X) o += MGX_VM_WORDS * MGX_WORLD_EPG * 4 + (aoe_lds ? 28 * MGX_WORLD_EPG * 4 + 8 * MGX_WORLD_EPG * 8 : 0);
 #ifdef MGX_ACT_TU
   o += MGX_ACT_GSET * MGX_WORLD_EPG * 8;  // (order position + 1) << 32 | f32 bits of the last game-stat set, per env
+  o += act_extra;
 #endif
   return o;
 }
@@ -174,6 +176,8 @@ struct MgxValueStack {
   __device__ __forceinline__ float pop() { float v = s0; s0 = s1; s1 = s2; s2 = s3; s3 = s4; s4 = s5; s5 = s6; s6 = s7; n--; return v; }
 };
 
+template <class Env> struct MgxGenR3;   // generated at build(): mgx_handlers_gen.h
+template <class Env> struct MgxGenR4;
 template <class PP, bool X>
 struct MgxEnvT {  // per-lane view of one env
   typedef PP ProgPtr;
@@ -195,7 +199,7 @@ struct MgxEnvT {  // per-lane view of one env
   // Each set goes to a per-env LDS cell as (position + 1) << 32 | value bits under a 64-bit max; mgx_act_body applies the
   // surviving value when the phase is over.  (The host only selects this kernel when nothing reads those stats mid-phase.)
   __device__ __forceinline__ unsigned long long* act_gset_cells() const {
-    return (unsigned long long*)(mgx_dyn_lds + mgx_world_lds_fixed(d.A, X, d.x_aoe_lds != 0) - MGX_ACT_GSET * MGX_WORLD_EPG * 8);
+    return (unsigned long long*)(mgx_dyn_lds + mgx_world_lds_fixed(d.A, X, d.x_aoe_lds != 0) - MGX_ACT_GSET * MGX_WORLD_EPG * 8);  // (in front of act_lds_extra)
   }
   __device__ __forceinline__ void act_gstat_set(int id, float v) const {
     int k = 0;
@@ -218,7 +222,11 @@ struct MgxEnvT {  // per-lane view of one env
 #ifdef MGX_WORLD_IDS
   __device__ __forceinline__ int envi() const { return (int)(blockIdx.x * MGX_WORLD_EPG) + mgx_world_lane(); }
   __device__ __forceinline__ PP prog() const {
+#ifdef MGX_ACT_TU
+    if constexpr (std::is_same<PP, MgxLdsProg>::value) return (MgxLdsProg)(int32_t*)(mgx_dyn_lds + mgx_world_lds_fixed(d.A, X, d.x_aoe_lds != 0, d.act_lds_extra));
+#else
     if constexpr (std::is_same<PP, MgxLdsProg>::value) return (MgxLdsProg)(int32_t*)(mgx_dyn_lds + mgx_world_lds_fixed(d.A, X, d.x_aoe_lds != 0));
+#endif
     else return d.P;
   }
   __device__ __forceinline__ MgxALds AL() const { return mgx_world_alds(mgx_dyn_lds, d.A, mgx_world_lane()); }
@@ -692,8 +700,12 @@ struct MgxEnvT {  // per-lane view of one env
   __device__ __forceinline__ int resolve(const MgxCtx& c, int ent) const { return ent == MGX_ENT_ACTOR ? c.actor : c.target; }
   template <int QD>
   __device__ MGX_BIG bool atom(PP a, const MgxCtx& c, int depth) const {
-    int a0 = a[MGX_AT_A0], a1 = a[MGX_AT_A1], a2 = a[MGX_AT_A2];
-    switch (a[MGX_AT_OP]) {
+    return atom_v<QD>(a[MGX_AT_OP], a[MGX_AT_A0], a[MGX_AT_A1], a[MGX_AT_A2], c, depth);
+  }
+  // (operands by value: the generated handler code — mgx_handlers_gen.h — passes them as constants and the switch folds)
+  template <int QD>
+  __device__ MGX_BIG bool atom_v(int op, int a0, int a1, int a2, const MgxCtx& c, int depth) const {
+    switch (op) {
       case MGX_FOP_VIBE: { int e = resolve(c, a0); return e != MGX_SLOT_NONE && (e >= 0 ? (int)d.obj_vibe[so(e)] : 0) == a1; }
       case MGX_FOP_RESOURCE: { int e = resolve(c, a0); return e != MGX_SLOT_NONE && inv_of(e, a1) >= a2; }
       case MGX_FOP_SHARED_TAG: {
@@ -924,8 +936,14 @@ struct MgxEnvT {  // per-lane view of one env
   // Every mutation except the ones that apply a handler (UseTarget, tag changes with lifecycle handlers, materialized
   // query recomputation): those are steps of the handler VMs (run_handler / vm_run), which own all nesting.
   __device__ MGX_BIG void mutate(PP m, MgxCtx& c) const {
-    int a0 = m[MGX_MU_A0], a1 = m[MGX_MU_A1], a2 = m[MGX_MU_A2], a3 = m[MGX_MU_A3];
-    switch (m[MGX_MU_OP]) {
+    const int op = m[MGX_MU_OP];
+    if (op < MGX_MOP_GAME_VALUE) mutate_v(op, m[MGX_MU_A0], m[MGX_MU_A1], m[MGX_MU_A2], m[MGX_MU_A3], m[MGX_MU_A4], c);
+    else if constexpr (X) mutate_ext(m, c);
+    else flag(4u);
+  }
+  // the mutations every variant has (operands by value, see atom_v)
+  __device__ MGX_BIG void mutate_v(int op, int a0, int a1, int a2, int a3, int a4, MgxCtx& c) const {
+    switch (op) {
       case MGX_MOP_RESOURCE_DELTA: {  // resource_mutation.hpp:25-47
         if constexpr (X) {
           if (c.deferred && a0 == MGX_ENT_TARGET && c.target >= 0 && !(cls_of(c.target)[MGX_C_MODIFIER_MASK] & (1 << a1))) {
@@ -951,7 +969,7 @@ struct MgxEnvT {  // per-lane view of one env
         if (moved > 0 && sa >= 0) astat_add(sa, d.wk[MGX_S_RES_DEPOSITED_BASE] + a2, (float)moved);
 #ifndef MGX_ACT_TU
         if constexpr (X) {
-          if (m[MGX_MU_A4] && (d.obj_order[so(s)] & 0xF) == 0xF) remove_object(s);  // resource_mutation.hpp:88-97
+          if (a4 && (d.obj_order[so(s)] & 0xF) == 0xF) remove_object(s);  // resource_mutation.hpp:88-97
         }
 #endif
         break;
@@ -1009,10 +1027,7 @@ struct MgxEnvT {  // per-lane view of one env
         astat_add(xa, d.wk[MGX_S_SWAP], 1.f);
         break;
       }
-      default:
-        if constexpr (X) mutate_ext(m, c);
-        else flag(4u);
-        break;
+      default: flag(4u); break;
     }
   }
   __device__ MGX_BIG void mutate_ext(PP m, MgxCtx& c) const {
@@ -1411,6 +1426,9 @@ struct MgxEnvT {  // per-lane view of one env
   // mutation, no query recomputation and no query filter — flat_top, decided by the host — never need the LDS VM for
   // them: the register VM of the lean variant runs them, frames and contexts in registers)
   __device__ __forceinline__ bool apply_top(int h, MgxCtx& c) const {
+#ifdef MGX_GEN_HANDLERS  // the unit carries straight-line code for one preset's handlers (mgx_handlers_gen.h)
+    if (d.gen_prog == MGX_GEN_ID) return MGX_GEN_HANDLERS<MgxEnvT>::top(*this, h, c);
+#endif
     if constexpr (X) {
       if (d.flat_top) return run_handler(h, c);
       return vm_run(h, 0, 0, 0, c);
@@ -2214,6 +2232,9 @@ __device__ __forceinline__ void mgx_world_entry(const MgxDev& d, int prog_words,
 }
 
 
+#ifdef MGX_GEN_HANDLERS
+#include "mgx_handlers_gen.h"
+#endif
 }  // namespace MGX_TU_NS
 using namespace MGX_TU_NS;
 
@@ -2226,14 +2247,16 @@ void mgx_launch_world_fast_s1(bool prog_lds, size_t lds, hipStream_t stream, con
 bool mgx_world_fast_set_lds_s0(size_t lds);  // raises the kernels' dynamic LDS limit (needed past 64 KB)
 bool mgx_world_fast_set_lds_s1(size_t lds);
 // the lane-per-agent action kernels (mgx_act_fast.hip, mgx_act_x.hip; mgx_act.h)
-size_t mgx_act_fast_lds_bytes(int A);
+size_t mgx_act_fast_lds_bytes(int A, int extra);
+int mgx_act_fast_epg();   // envs per workgroup of the unit
 void mgx_launch_act_fast_s0(bool prog_lds, size_t lds, hipStream_t stream, const MgxDev& d, int prog_words);
 void mgx_launch_act_fast_s1(bool prog_lds, size_t lds, hipStream_t stream, const MgxDev& d, int prog_words);
 bool mgx_act_fast_set_lds_s0(size_t lds);
 bool mgx_act_fast_set_lds_s1(size_t lds);
 void mgx_launch_act_x(bool prog_lds, size_t lds, hipStream_t stream, const MgxDev& d, const MgxDev* dev_copy, int prog_words);
 bool mgx_act_x_set_lds(size_t lds);
-size_t mgx_act_x_lds_bytes(int A, bool aoe_lds);
+size_t mgx_act_x_lds_bytes(int A, bool aoe_lds, int extra);
+int mgx_act_x_epg();
 // ... and of the extended one (mgx_world_x.hip)
 void mgx_launch_world_x(bool prog_lds, size_t lds, hipStream_t stream, const MgxDev& d, const MgxDev* dev_copy, int prog_words, int phases);
 bool mgx_world_x_set_lds(size_t lds);

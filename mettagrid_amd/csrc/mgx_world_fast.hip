@@ -12,6 +12,10 @@
 #define MGX_TU_NS MGX_CAT(mgx_tu_fast, MGX_SLOT)
 #define MGX_CONST_DEV 1
 #define MGX_WORLD_IDS 1
+#ifndef MGX_NO_GEN_HANDLERS
+#define MGX_GEN_HANDLERS MgxGenR3   // straight-line handler code of the preset (mgx_handlers_gen.h), used when MgxDev::gen_prog says so
+#define MGX_GEN_ID 3
+#endif
 // Measured on MI355X (rung 3, 65 536 envs): 32 envs per wavefront, two wavefronts per SIMD is the best split —
 // 64 lanes serialise more distinct handler paths per wavefront, 16 or 8 multiply the instruction stream.
 #ifndef MGX_WORLD_LPW

@@ -82,7 +82,7 @@ def load_lib():
     L.mgx_count_objects_with_tag.argtypes = [vp, i32, i32, C.POINTER(i32)]
     L.mgx_set_profiling.argtypes = [vp, i32]
     L.mgx_get_step_timing.argtypes = [vp, vp]
-    for name in ("mgx_num_envs", "mgx_num_agents", "mgx_num_tokens", "mgx_obs_variant", "mgx_act_variant"):
+    for name in ("mgx_num_envs", "mgx_num_agents", "mgx_num_tokens", "mgx_obs_variant", "mgx_act_variant", "mgx_handler_variant"):
         getattr(L, name).argtypes = [vp]
         getattr(L, name).restype = i32
     L.mgx_state_bytes.argtypes = [vp]
@@ -481,6 +481,11 @@ class BatchedMettaGrid:
     def obs_variant(self) -> int:
         """0: generic observation kernel; 3: the instance compiled for the shape of BASELINE.json configs[2] (gen_presets.py)."""
         return int(self.L.mgx_obs_variant(self.h))
+
+    @property
+    def handler_variant(self) -> int:
+        """0: handler interpreter; 3 / 4: code generated at build() for the rung-3 / rung-4 preset (gen_handlers.py)."""
+        return int(self.L.mgx_handler_variant(self.h))
 
     @property
     def act_variant(self) -> int:

@@ -11,11 +11,13 @@ struct MgxDev;
 bool mgx_launch_obs_box(hipStream_t, const MgxDev&, size_t, int, int, const uint8_t*, int, int, int, bool, bool, bool, int, int, void*, const float*, int, int) { return false; }
 bool mgx_obs_box_set_lds(size_t) { return true; }
 // ... and the lane-per-agent action kernels (ballot / readlane): the sanitizer build never selects them (MgxDev::act_par = 0)
-size_t mgx_act_fast_lds_bytes(int) { return 0; }
+size_t mgx_act_fast_lds_bytes(int, int) { return 0; }
+int mgx_act_fast_epg() { return 1; }
+int mgx_act_x_epg() { return 1; }
 void mgx_launch_act_fast_s0(bool, size_t, hipStream_t, const MgxDev&, int) {}
 void mgx_launch_act_fast_s1(bool, size_t, hipStream_t, const MgxDev&, int) {}
 bool mgx_act_fast_set_lds_s0(size_t) { return true; }
 bool mgx_act_fast_set_lds_s1(size_t) { return true; }
 void mgx_launch_act_x(bool, size_t, hipStream_t, const MgxDev&, const MgxDev*, int) {}
 bool mgx_act_x_set_lds(size_t) { return true; }
-size_t mgx_act_x_lds_bytes(int, bool) { return 0; }
+size_t mgx_act_x_lds_bytes(int, bool, int) { return 0; }

@@ -220,3 +220,14 @@ def test_more_than_thirteen_resources_is_refused_cleanly_at_every_layer():
     h = C.c_void_p()
     rc = L.mgx_create(words.ctypes.data, words.size, maps.ctypes.data, seeds.ctypes.data, 1, 0, C.byref(h))
     assert rc == -3 and b"resources<=13" in L.mgx_last_error()
+
+
+def test_handler_generator_is_deterministic_and_header_is_current():
+    """build() regenerates csrc/mgx_handlers_gen.h from the presets; the text depends on nothing else, and the fingerprints
+    the engine compares against are the ones of the programs the presets compile to today."""
+    from mettagrid_amd import gen_handlers
+    a, fa = gen_handlers.render()
+    b, fb = gen_handlers.render()
+    assert a == b and fa == fb
+    assert open(gen_handlers.OUT).read() == a
+    assert "MGX_GEN_R3_FP" in fa and "MGX_GEN_R4_FP" in fa and "0x0000000000000000" not in fa
