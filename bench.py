@@ -320,7 +320,7 @@ def measure(rung: int, cms: np.ndarray, *, envs: int, steps: int, warmup: int, r
     # Roofline of the dominant kernel (DESIGN.md "Roofline accounting").  Algorithmic bytes per agent-step: the
     # observation kernel owns obs out 3T + reward 4 + terminal 1 + truncation 1 + one read of the env state
     # S_env/A; the world-update kernel owns the two action streams (8) + one pass over S_env/A.
-    names = {"obs": "mgx_obs_kernel", "actions": "mgx_world_kernel_x" if rung == 4 else "mgx_world_kernel_fast"}
+    names = {"obs": "mgx_obs_kernel", "actions": "mgx_act_kernel_x" if rung == 4 else "mgx_world_kernel_fast"}
     dom = "obs" if seg["obs"] >= seg["actions"] else "actions"
     bytes_per_agent_step = per["obs"] if dom == "obs" else per["world"]
     achieved = (E // G) * A * bytes_per_agent_step / (seg[dom] * 1e-3) / 1e9

@@ -343,7 +343,7 @@ static int size_obs_lds(mgx_engine* e) {
   e->obs_ew = e->obs_threads / MGX_WAVE;
   auto lds_for = [&](int ew) {
     return (size_t)mgx_obs_lds_layout(d.H * d.W, d.NOFF, d.S, d.A, d.T, e->pool_tokens, xmode, d.n_obs_values,
-                                      e->obs_blk_lds ? e->obs_blk_words : 0, mgx_obs_gt(d.n_obs_values, d.base),
+                                      e->obs_blk_lds ? e->obs_blk_words : 0, mgx_obs_gt(d.n_obs_values, d.base, d.flags),
                                       e->rewards_early, ew).total;
   };
   if (e->obs_threads == 512) {
@@ -352,6 +352,7 @@ static int size_obs_lds(mgx_engine* e) {
       if (lds_for(ew) <= 53760) { e->obs_ew = ew; break; }
   }
   e->lds_obs = lds_for(e->obs_ew);
+  if (const char* pad = getenv("MGX_OBS_LDS_PAD")) e->lds_obs += (size_t)atoi(pad);   // (occupancy experiments: unused LDS behind the layout)
   e->obs_variant = 0;
   if (!getenv("MGX_OBS_GENERIC")) {
     if (!d.X && e->obs_blk_lds && mgx_obs_shape_matches<MgxObsShapeR3>(d, e->obs_blk_words, (e->rewards_early ? 1 : e->rewards_mid ? 2 : 0))) e->obs_variant = 3;

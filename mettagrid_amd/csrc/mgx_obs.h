@@ -95,7 +95,7 @@ struct MgxBase {
 //   grid u16[HW] | offsets i8x2[NOFF] | loc u8[CP] (packed window coordinate of offset j) | minobs u32[S+1] |
 //   visited u32[S] | tokinfo u32[S] (start | count << 16) | dyn u16[S] (slots whose token list is built per step) |
 //   agents u32[A] (slot | rc << 16) | aginfo u32[A] | spawn u16[A] | vstat f32[A] | written i32[A] |
-//   rwinfo u32[A] (reward start | count << 16) | misc u32[4] | rows u32[WAVES*4][Tpad+16] |
+//   rwinfo u32[A] (reward start | count << 16) | misc u32[4] | trash u32[64] | rows u32[WAVES*4][Tpad] |
 //   cell u16[A][CP], vj u8[A][CP], vcount u32[A]: per agent the occupied window cells in window order (slot + 1 and
 //   window index j of each), compacted | X: vmask u8[A][CP] territory token of each listed cell, obs values |
 //   blk i32[blk_words]: program sections INV_FEATURES..OBS_VALUES (PL variants only) | gtok u32[A][GT] global tokens |
@@ -104,16 +104,21 @@ struct MgxBase {
 __host__ __device__ inline int mgx_align16(int x) { return (x + 15) & ~15; }
 struct MgxObsLds {
   int grid, offs, loc, minobs, visited, tokinfo, dyn, agents, aginfo, spawn, vstat, written, rwinfo, misc, pool, rows, row_words,
-      row_pitch, cell, vj, vcount, cp, blk, gtok, total;
+      row_pitch, cell, vj, vcount, cp, cs, blk, gtok, trash, total;
   int owner, obsval, tscore, vmask, agtags;  // X only: per-cell territory owner u16[HW] (overlaid), obs values u32[A][NOV], mask list
 };
 // Upper bound of the global (location 0xFE) tokens of one agent: completion, last action, last action move, last
 // reward, two local-position tokens and every digit of every obs value (a u32 has at most 32 digits in base 2).
-__host__ __device__ inline int mgx_obs_gt(int NOV, int base) {
+__host__ __device__ inline int mgx_obs_gt(int NOV, int base, int flags) {
   int digits = 1;
   for (unsigned long long v = 0xFFFFFFFFull / (unsigned)base; v > 0; v /= (unsigned)base) digits++;
-  return 6 + NOV * digits;
+  const int fixed = ((flags & MGX_G_COMPLETION) ? 1 : 0) + ((flags & MGX_G_LAST_ACTION) ? 1 : 0) + ((flags & MGX_G_LAST_ACTION_MOVE) ? 1 : 0) +
+                    ((flags & MGX_G_LAST_REWARD) ? 1 : 0) + ((flags & MGX_G_LOCAL_POSITION) ? 2 : 0);
+  return (fixed > 0 ? fixed : 1) + NOV * digits;
 }
+// Lean games whose slot numbers and window indices fit 9 + 7 bits keep the window index of a listed cell in the cell entry
+// itself (no separate index list) and pack the lists at the window size rounded up to even instead of to 16.
+__host__ __device__ inline bool mgx_obs_pack_j(bool X, int S, int NOFF) { return !X && S + 1 <= 512 && NOFF <= 128; }
 // xmode of the extended variant: what the territory observability mask needs in LDS (0 = lean kernel)
 enum { MGX_OX_ON = 1, MGX_OX_MASK = 2, MGX_OX_PACK = 4, MGX_OX_OWNER8 = 8 };
 __host__ __device__ inline int mgx_obs_xmode(bool X, bool want_mask, int S, int num_tags) {
@@ -126,9 +131,11 @@ __host__ __device__ inline MgxObsLds mgx_obs_lds_layout(int HW, int NOFF, int S,
                                                         int xmode = 0, int NOV = 0, int blk_words = 0, int GT = 6,
                                                         bool blk_early = false, int waves = MGX_OBS_WAVES) {
   const bool X = xmode != 0;
+  const bool pack_j = mgx_obs_pack_j(X, S, NOFF);
   MgxObsLds l;
   int o = 0;
   l.cp = (NOFF + 15) & ~15;
+  l.cs = pack_j ? ((NOFF + 1) & ~1) : l.cp;
   // The grid, the window offsets, the list-builder queue, the territory owner map (X) and (when the rewards are
   // evaluated early, blk_early) the program block are dead once the visible-cell lists and the global tokens exist
   // (barrier before the encode phase); the staging rows are first written after it, so the rows overlay them.
@@ -143,13 +150,18 @@ __host__ __device__ inline MgxObsLds mgx_obs_lds_layout(int HW, int NOFF, int S,
   l.written = o; o += mgx_align16(A * 4);
   l.rwinfo = o; o += mgx_align16(A * 4);
   l.misc = o; o += 16;
+  l.trash = o; o += MGX_WAVE * 4;
   // The token pool's size follows the maps (run-time); every other region only the program's shape.  Lean games put it
   // LAST, so that a kernel specialised for a shape (MgxObsShape) has every other offset as a compile-time constant; the
   // extended variant keeps it here (measured at rung 4: 4.76 ms here, 5.01 ms at the end of the layout).
   const bool pool_last = !X;
   if (!pool_last) { l.pool = o; o += mgx_align16((pool_tokens + 8) * 2); }
   l.row_words = (T + 3) & ~3;
-  l.row_pitch = l.row_words + 16;  // + one trash word per lane of a 16-lane row: masked-off stores land there
+  // Masked-off stores of the encode land in a trash word of the storing lane: one block of 64 words for the workgroup (its
+  // wavefronts never collide inside one instruction) instead of 16 words behind every row — 768 B less, which is what takes
+  // the rung-3 layout from 23 088 to 22 320 B and under the 23 040 B that seven workgroups per CU allow (LDS is handed out
+  // in 1 280-byte granules; measured: the 23 088-byte layout ran as fast with 400 B of padding as without, i.e. at six).
+  l.row_pitch = l.row_words;
 #ifndef MGX_OBS_PITCH_OLD
   // ... + padding to 8 words mod 16: the two DPP rows of a 32-lane LDS group write to staging rows two pitches apart
   // (row permutation in the kernel), and 2 * pitch = 16 mod 32 keeps their 16-word spans on disjoint banks for every T
@@ -169,8 +181,8 @@ __host__ __device__ inline MgxObsLds mgx_obs_lds_layout(int HW, int NOFF, int S,
     const int early_bytes = eo - o;
     o += rows_bytes > early_bytes ? rows_bytes : early_bytes;
   }
-  l.cell = o; o += mgx_align16(A * l.cp * 2);
-  l.vj = o; o += mgx_align16(A * l.cp);
+  l.cell = o; o += mgx_align16(A * l.cs * 2);
+  l.vj = o; if (!pack_j) o += mgx_align16(A * l.cp);
   l.vcount = o; o += mgx_align16(A * 4);
   l.vmask = l.obsval = l.tscore = l.agtags = 0;
   if (X) {
@@ -256,13 +268,14 @@ __global__ void __launch_bounds__(NTH) mgx_obs_kernel(MgxDev d, int pool_tokens,
   //       with many agents), instead of by 64 threads behind the final barrier while everybody else idles
   const int rewards_early = rewards_mode == 1 ? 1 : 0;
   const bool rewards_mid = rewards_mode == 2 && EW < NTH / MGX_WAVE;
-  const int GT = mgx_obs_gt(NOV, dBase);
+  const int GT = mgx_obs_gt(NOV, dBase, dFlags);
   const bool want_mask = X && dMaskFeat != 0 && dNT > 0;
   const int xmode = mgx_obs_xmode(X, want_mask, S, d.P[MGX_H_NUM_TAGS]);
   const bool pack_mask = (xmode & MGX_OX_PACK) != 0, owner8 = (xmode & MGX_OX_OWNER8) != 0;
   const MgxObsLds L = mgx_obs_lds_layout(HW, NOFF, S, A, T, pool_tokens, xmode, NOV, PL ? blk_words : 0, GT,
                                          rewards_early != 0, EW);
-  const int CP = L.cp;
+  const int CP = L.cp, CS = L.cs;
+  const bool pack_j = mgx_obs_pack_j(X, S, NOFF);
   uint16_t* s_grid = (uint16_t*)(smem + L.grid);
   char2* s_offs = (char2*)(smem + L.offs);
   uint8_t* s_loc = smem + L.loc;
@@ -283,7 +296,8 @@ __global__ void __launch_bounds__(NTH) mgx_obs_kernel(MgxDev d, int pool_tokens,
   // banks 0, 8 | 24, 16, 24 | 8: DPP rows 0 and 1 (one 32-lane LDS group) take the 1st and 3rd of them, rows 2 and 3 the 2nd
   // and 4th — the two 16-word spans of a group then never share a bank.
   uint32_t* s_row = (uint32_t*)(smem + L.rows) + (wave * 4 + (((row & 1) << 1) | (row >> 1))) * L.row_pitch;
-  const int TRASH = L.row_words + rl;  // s_row[TRASH]: target of this lane's masked-off stores
+  // s_row[TRASH]: this lane's word of the workgroup's trash block, as an index relative to its staging row
+  const int TRASH = (int)(((uint32_t*)(smem + L.trash) + lane) - s_row);
   uint16_t* s_cell = (uint16_t*)(smem + L.cell);
   uint8_t* s_vj = smem + L.vj;
   uint32_t* s_vcount = (uint32_t*)(smem + L.vcount);
@@ -616,8 +630,8 @@ __global__ void __launch_bounds__(NTH) mgx_obs_kernel(MgxDev d, int pool_tokens,
         const unsigned long long m = __ballot(cs != 0);
         if (cs) {
           const int k = __popcll(m & ((1ull << lane) - 1ull));
-          s_cell[x * CP + k] = (uint16_t)cs;
-          s_vj[x * CP + k] = (uint8_t)lane;
+          s_cell[x * CS + k] = (uint16_t)(pack_j ? cs | ((uint32_t)lane << 9) : cs);
+          if (!pack_j) s_vj[x * CP + k] = (uint8_t)lane;
         }
         return __popcll(m);
       };
@@ -632,8 +646,8 @@ __global__ void __launch_bounds__(NTH) mgx_obs_kernel(MgxDev d, int pool_tokens,
         const uint32_t mh = half ? (uint32_t)(m >> 32) : (uint32_t)m;
         if (cs) {
           const int k = (half ? cb : ca) + __popc(mh & ((1u << hl) - 1u));
-          s_cell[x * CP + k] = (uint16_t)cs;
-          s_vj[x * CP + k] = (uint8_t)jt;
+          s_cell[x * CS + k] = (uint16_t)(pack_j ? cs | ((uint32_t)jt << 9) : cs);
+          if (!pack_j) s_vj[x * CP + k] = (uint8_t)jt;
         }
         ca += __popc((uint32_t)m);
         cb += __popc((uint32_t)(m >> 32));
@@ -665,8 +679,8 @@ __global__ void __launch_bounds__(NTH) mgx_obs_kernel(MgxDev d, int pool_tokens,
         const unsigned long long m = __ballot(keep);
         if (keep) {
           const int k = count + __popcll(m & ((1ull << lane) - 1ull));
-          s_cell[a * CP + k] = (uint16_t)(pack_mask ? cs | (mv << 14) : cs);
-          s_vj[a * CP + k] = (uint8_t)j;
+          s_cell[a * CS + k] = (uint16_t)(pack_mask ? cs | (mv << 14) : pack_j ? cs | ((uint32_t)j << 9) : cs);
+          if (!pack_j) s_vj[a * CP + k] = (uint8_t)j;
           if constexpr (X) { if (want_mask && !pack_mask) s_vmask[a * CP + k] = (uint8_t)mv; }
         }
         count += __popcll(m);
@@ -752,10 +766,12 @@ __global__ void __launch_bounds__(NTH) mgx_obs_kernel(MgxDev d, int pool_tokens,
     for (int k0 = 0; k0 < nmax; k0 += 16) {
       const int kk = k0 + rl;
       const bool valid = kk < nvis;
-      uint32_t cs = valid ? (uint32_t)s_cell[ac * CP + kk] : 0u;
+      uint32_t cs = valid ? (uint32_t)s_cell[ac * CS + kk] : 0u;
       uint32_t pmask = 0;
       if constexpr (X) { if (pack_mask) { pmask = cs >> 14; cs &= 0x3FFFu; } }
-      const int j = s_vj[ac * CP + (valid ? kk : 0)];
+      int j;
+      if (pack_j) { j = (int)(cs >> 9); cs &= 0x1FFu; }
+      else j = s_vj[ac * CP + (valid ? kk : 0)];
       const bool has = cs != 0;
       const int slot = has ? (int)cs - 1 : 0;
       const uint32_t info = s_tokinfo[slot];
