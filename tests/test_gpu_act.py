@@ -117,6 +117,59 @@ def test_agent_kernel_equals_env_kernel_by_digest(rung, monkeypatch):
     par.close(); ser.close()
 
 
+def test_large_map_takes_the_all_pairs_conflict_walk(monkeypatch):
+    """Maps above 64 x 64 cells have no cell map in LDS: conflicts are found by walking the pending lanes (ballot + readlane).
+    Same rules, 16 agents crowded into one corner region of an 80 x 96 map would rarely meet — so the arena is forced onto
+    that path with MGX_ACT_NO_MAP as well."""
+    monkeypatch.setenv("MGX_ACT_LEAN", "1")
+    prog = compile_spec(presets.rung3_spec(), 80, 96, max_objects=600)
+    E = 4
+    cms = random_class_maps(prog, 80, 96, {"wall": 150, "extractor": 30, "chest": 10}, {"red": 8, "blue": 8}, range(E))
+    _against_oracle(prog, cms, np.arange(E, dtype=np.uint32) + 3, 12, 8, "80x96 map", 1)
+    monkeypatch.setenv("MGX_ACT_NO_MAP", "1")
+    prog = compile_spec(presets.rung3_spec(), 11, 11, max_objects=192)
+    E = 12
+    maps = [random_map(11, 11, {"wall": 3, "extractor": 4, "chest": 2}, {"red": 8, "blue": 8}, 400 + s) for s in range(E)]
+    cms = np.stack([prog.class_map(m) for m in maps])
+    _against_oracle(prog, cms, np.arange(E, dtype=np.uint32) + 9, 50, 9, "crowded arena, all-pairs walk", 1)
+
+
+def test_auto_reset_behind_the_agent_kernel():
+    """Episodes that end and restart on the device (map pool, max_steps) with the dispatch on the agent kernel: the state
+    digests of both kernels stay equal across restarts."""
+    import torch
+    spec = presets.rung4_spec(max_steps=12)
+    prog = compile_spec(spec, 64, 64, max_objects=presets.RUNG4_MAX_OBJECTS)
+    E = 96
+    maps = random_class_maps(prog, 64, 64, presets.RUNG4_OBJECTS, presets.RUNG4_AGENTS, range(8))
+    cms = maps[np.arange(E) % len(maps)]
+    seeds = np.arange(E, dtype=np.uint32) + 40
+    engines = []
+    for serial in (False, True):
+        if serial:
+            os.environ["MGX_ACT_SERIAL"] = "1"
+        try:
+            eng = BatchedMettaGrid(prog, cms, seeds, buffers="device")
+        finally:
+            os.environ.pop("MGX_ACT_SERIAL", None)
+        eng.set_map_pool(maps)
+        eng.set_auto_reset(True, pool_stride=3)
+        engines.append(eng)
+    par, ser = engines
+    assert (par.act_variant, ser.act_variant) == (1, 0)
+    A, n_act = prog.num_agents, len(prog.action_names)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    for t in range(40):
+        a = torch.randint(0, n_act, (E * A,), dtype=torch.int32, device="cuda", generator=g)
+        v = torch.randint(0, n_act, (E * A,), dtype=torch.int32, device="cuda", generator=g)
+        for eng in engines:
+            eng.actions.copy_(a); eng.vibe_actions.copy_(v)
+            eng.wait_for_caller(); eng.step(); eng.caller_waits()
+        assert np.array_equal(par.state_digests(), ser.state_digests()), f"step {t + 1}"
+        assert torch.equal(par.obs, ser.obs) and torch.equal(par.rewards, ser.rewards) and torch.equal(par.terminals, ser.terminals)
+    par.close(); ser.close()
+
+
 def test_variant_choice(monkeypatch):
     """Extended games whose action handlers stay with actor and target take the agent kernel; a handler that mutates tags
     (rung-4 `dynamic` scenario), more than 64 agents, or MGX_ACT_SERIAL keep the env kernel."""
