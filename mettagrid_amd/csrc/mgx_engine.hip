@@ -362,8 +362,8 @@ static int size_obs_lds(mgx_engine* e) {
   if (e->lds_obs > 160 * 1024)
     return fail(MGX_ERR_PROGRAM, "map/object count too large for the LDS staging of the observation kernel");
   if (e->verbose || getenv("MGX_VERBOSE"))
-    fprintf(stderr, "[mgx] obs: lds=%zu B pool=%d tokens (prefix %d) blk_lds=%d rewards_early=%d\n", e->lds_obs, e->pool_tokens,
-            e->pool_prefix, (int)e->obs_blk_lds, (e->rewards_early ? 1 : e->rewards_mid ? 2 : 0));
+    fprintf(stderr, "[mgx] obs: lds=%zu B pool=%d tokens (prefix %d) blk_lds=%d rewards_early=%d threads=%d encode wavefronts=%d (4 would need %zu B)\n",
+            e->lds_obs, e->pool_tokens, e->pool_prefix, (int)e->obs_blk_lds, (e->rewards_early ? 1 : e->rewards_mid ? 2 : 0), e->obs_threads, e->obs_ew, lds_for(4));
   // The attribute is per kernel and process-wide: keep one maximum and only ever raise it, so that a second engine
   // with a smaller requirement cannot lower the limit under a live one.
   static std::mutex mu;

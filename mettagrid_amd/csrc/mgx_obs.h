@@ -125,6 +125,10 @@ __host__ __device__ inline int mgx_obs_xmode(bool X, bool want_mask, int S, int 
   if (!X) return 0;
   int m = MGX_OX_ON;
   if (want_mask) m |= MGX_OX_MASK | (S + 1 < (1 << 14) ? MGX_OX_PACK : 0) | (num_tags <= 255 ? MGX_OX_OWNER8 : 0);
+  // bits 4-7: words of an agent's tag bitset that can hold a tag of this program (owner tags are tag ids < num_tags)
+  int tw = (num_tags + 31) / 32;
+  tw = tw < 1 ? 1 : tw > MGX_TAG_WORDS ? MGX_TAG_WORDS : tw;
+  m |= tw << 4;
   return m;
 }
 __host__ __device__ inline MgxObsLds mgx_obs_lds_layout(int HW, int NOFF, int S, int A, int T, int pool_tokens,
@@ -189,7 +193,7 @@ __host__ __device__ inline MgxObsLds mgx_obs_lds_layout(int HW, int NOFF, int S,
     // per visible cell: 0 no territory token, 1 friendly, 2 foreign owner — in bits 14-15 of the cell entry when slot
     // numbers leave them free (MGX_OX_PACK), else a byte list of its own
     if ((xmode & MGX_OX_MASK) && !(xmode & MGX_OX_PACK)) { l.vmask = o; o += mgx_align16(A * l.cp); }
-    if (xmode & MGX_OX_MASK) { l.agtags = o; o += mgx_align16(A * MGX_TAG_WORDS * 4); }  // the agents' own tag bitsets (friend / foe of a cell's owner tag)
+    if (xmode & MGX_OX_MASK) { l.agtags = o; o += mgx_align16(A * ((xmode >> 4) & 15) * 4); }  // the agents' own tag bitsets (friend / foe of a cell's owner tag)
     l.obsval = o; o += mgx_align16((A * NOV + 1) * 4);
   }
   if (!blk_early) { l.blk = o; o += mgx_align16(blk_words * 4); }
@@ -272,6 +276,7 @@ __global__ void __launch_bounds__(NTH) mgx_obs_kernel(MgxDev d, int pool_tokens,
   const bool want_mask = X && dMaskFeat != 0 && dNT > 0;
   const int xmode = mgx_obs_xmode(X, want_mask, S, d.P[MGX_H_NUM_TAGS]);
   const bool pack_mask = (xmode & MGX_OX_PACK) != 0, owner8 = (xmode & MGX_OX_OWNER8) != 0;
+  const int TW = (xmode >> 4) & 15;  // tag words kept per agent for the territory mask
   const MgxObsLds L = mgx_obs_lds_layout(HW, NOFF, S, A, T, pool_tokens, xmode, NOV, PL ? blk_words : 0, GT,
                                          rewards_early != 0, EW);
   const int CP = L.cp, CS = L.cs;
@@ -414,9 +419,8 @@ __global__ void __launch_bounds__(NTH) mgx_obs_kernel(MgxDev d, int pool_tokens,
       s_rwinfo[i] = ((uint32_t)C[MGX_C_REWARD_START] & 0xFFFFu) | ((uint32_t)C[MGX_C_REWARD_COUNT] << 16);
       if constexpr (X) {
         if (want_mask)   // the observer's own tag bitset (friend / foe of a cell's owner tag), once per env
-#pragma unroll
-          for (int w = 0; w < MGX_TAG_WORDS; w++)
-            s_agtags[i * MGX_TAG_WORDS + w] = d.obj_tags ? d.obj_tags[e.so(slot) * MGX_TAG_WORDS + w] : (uint32_t)C[MGX_C_TAGS + w];
+          for (int w = 0; w < TW; w++)
+            s_agtags[i * TW + w] = d.obj_tags ? d.obj_tags[e.so(slot) * MGX_TAG_WORDS + w] : (uint32_t)C[MGX_C_TAGS + w];
       }
     }
     if constexpr (X) {
@@ -672,7 +676,7 @@ __global__ void __launch_bounds__(NTH) mgx_obs_kernel(MgxDev d, int pool_tokens,
         if constexpr (X) {
           if (want_mask && inb) {
             const uint32_t ow = owner8 ? (uint32_t)s_owner8[r * dW + c] : (uint32_t)s_owner[r * dW + c];
-            if (ow != (owner8 ? 0xFFu : 0xFFFFu)) { mv = ((s_agtags[a * MGX_TAG_WORDS + (ow >> 5)] >> (ow & 31)) & 1u) ? 1u : 2u; keep = true; }  // mask-only cells still emit one token
+            if (ow != (owner8 ? 0xFFu : 0xFFFFu)) { mv = ((s_agtags[a * TW + (ow >> 5)] >> (ow & 31)) & 1u) ? 1u : 2u; keep = true; }  // mask-only cells still emit one token
           }
         }
         if (step > 0 && cs) atomicMin(&s_minobs[cs - 1], (uint32_t)a);
