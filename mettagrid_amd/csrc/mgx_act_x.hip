@@ -42,9 +42,12 @@ __global__ void __launch_bounds__(256) MGX_WPE_ATTR mgx_act_kernel_x(const MgxDe
 }
 
 static std::mutex g_lds_mutex;
-static size_t g_lds_max = 0;
+static size_t g_lds_max_dev[64] = {0};   // the attribute is per kernel AND per device: one maximum for each
 bool mgx_act_x_set_lds(size_t lds) {
   std::lock_guard<std::mutex> lock(g_lds_mutex);
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+  size_t& g_lds_max = g_lds_max_dev[dev];
   if (lds <= g_lds_max) return true;
   if (hipFuncSetAttribute((const void*)mgx_act_kernel_x<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
       hipFuncSetAttribute((const void*)mgx_act_kernel_x<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)

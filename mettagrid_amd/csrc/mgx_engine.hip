@@ -260,6 +260,7 @@ struct mgx_engine {
   }
   bool verbose = false;
   bool rewards_early = false;  // reward expressions have no stat operands: evaluated beside the token-cache phase
+  bool terr_fresh = false;     // the territory ownership maps were refreshed in this step and nothing behind that can change them
   bool rewards_mid = false;    // extended games: ... read nothing the observation kernel writes: evaluated during its encode phase
   int slot = 0;                // constant-memory slot of the lean world kernel (mgx_world_fast.hip, MGX_SLOT)
   int32_t* d_vibe_ids = nullptr;  // mgx_set_joint_actions: action index of each vibe action
@@ -445,7 +446,8 @@ static int launch_obs(mgx_engine* e, bool with_rewards, const uint8_t* mask = nu
 #endif
   int trc = consume_out_fence(e);
   if (trc) return trc;
-  trc = launch_terr(e);
+  if (!e->terr_fresh) trc = launch_terr(e);   // (mgx_step already refreshed the maps for the area-effect kernel and nothing since can have changed them)
+  e->terr_fresh = false;
   if (trc) return trc;
   MGX_TRACE_POINT(e, "terr kernel");
   if (e->d.obsval) mgx_launch_values(e->stream, e->d, dev_copy(e), 0, mask);
@@ -1495,6 +1497,7 @@ int mgx_step(mgx_engine* e) {
       MGX_TRACE_POINT(e, "aoe kernel");
       MGX_MARK(2);
       if (!d.cov_in_aoe) mgx_launch_world_x(e->prog_in_lds, e->lds_world, e->stream, e->d, dev_copy_world_x(e), pw, MGX_PH_TAIL);
+      else e->terr_fresh = true;   // target-local area effects move no source and change no tag: the ownership maps stay current
       MGX_MARK(3);
     } else {
       if (d.act_par) {

@@ -41,8 +41,11 @@ bool mgx_launch_obs_box(hipStream_t stream, const MgxDev& dd, size_t lds, int po
 
 bool mgx_obs_box_set_lds(size_t lds) {   // per-kernel attribute, only ever raised
   static std::mutex mu;
-  static size_t cur_max = 0;
+  static size_t cur_max_dev[64] = {0};   // ... per device
   std::lock_guard<std::mutex> lock(mu);
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+  size_t& cur_max = cur_max_dev[dev];
   if (lds <= cur_max) return true;
 #define MGX_BOX_KERNELS(X, PL, NTH, EW) (const void*)mgx_obs_kernel<true, X, PL, NTH, EW, MgxObsShapeDyn, true>, (const void*)mgx_obs_kernel<false, X, PL, NTH, EW, MgxObsShapeDyn, true>
   const void* fns[] = {MGX_BOX_KERNELS(false, true, MGX_OBS_THREADS, MGX_OBS_THREADS / MGX_WAVE), MGX_BOX_KERNELS(false, false, MGX_OBS_THREADS, MGX_OBS_THREADS / MGX_WAVE),

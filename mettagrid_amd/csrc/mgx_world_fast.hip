@@ -51,9 +51,12 @@ __global__ void __launch_bounds__(MGX_WORLD_THREADS) MGX_WPE_ATTR mgx_world_kern
 // One process-wide maximum per kernel: the attribute is per kernel, not per engine, and must never be lowered under a
 // live engine that needs more.
 static std::mutex g_lds_mutex;
-static size_t g_lds_max = 0;
+static size_t g_lds_max_dev[64] = {0};   // the attribute is per kernel AND per device: one maximum for each
 bool MGX_CAT(mgx_world_fast_set_lds_s, MGX_SLOT)(size_t lds) {
   std::lock_guard<std::mutex> lock(g_lds_mutex);
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+  size_t& g_lds_max = g_lds_max_dev[dev];
   if (lds <= g_lds_max) return true;
   if (hipFuncSetAttribute((const void*)mgx_world_kernel_fast<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
       hipFuncSetAttribute((const void*)mgx_world_kernel_fast<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)

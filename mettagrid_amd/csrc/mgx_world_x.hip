@@ -85,9 +85,12 @@ void mgx_launch_values(hipStream_t stream, const MgxDev& d, const MgxDev* dp, in
 }
 
 static std::mutex g_lds_mutex;
-static size_t g_lds_max = 0;
+static size_t g_lds_max_dev[64] = {0};   // the attribute is per kernel AND per device: one maximum for each
 bool mgx_world_x_set_lds(size_t lds) {  // process-wide maximum, only ever raised (the attribute is per kernel)
   std::lock_guard<std::mutex> lock(g_lds_mutex);
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+  size_t& g_lds_max = g_lds_max_dev[dev];
   if (lds <= g_lds_max) return true;
   if (hipFuncSetAttribute((const void*)mgx_world_kernel_x<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
       hipFuncSetAttribute((const void*)mgx_world_kernel_x<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)

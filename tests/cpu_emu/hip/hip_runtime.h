@@ -45,6 +45,7 @@ enum { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
 struct hipFuncAttributes { size_t localSizeBytes = 0; };
 static inline const char* hipGetErrorString(hipError_t) { return "emu"; }
 static inline hipError_t hipSetDevice(int) { return hipSuccess; }
+static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 static inline hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n ? n : 1); return *p ? hipSuccess : 1; }
