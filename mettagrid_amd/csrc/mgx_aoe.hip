@@ -70,20 +70,26 @@ __global__ void __launch_bounds__(MGX_AOE_THREADS) MGX_AOE_OCCUPANCY mgx_aoe_ker
   const size_t fb = (size_t)env * d.NF, mb = (size_t)env * d.NM;
   uint32_t* s_pack = s_stage;
   uint32_t* s_info = s_stage + MGX_WAVE;
-  // stage sources [q0, q0 + 64) of one list: lane q loads record q0 + q
-  auto stage = [&](const uint32_t* pack, const uint16_t* obj, const uint16_t* aoe, size_t base, int q0, int n) {
+  // stage sources [q0, q0 + 64) of one list: lane q loads record q0 + q.  The packed location / radius record stays in the
+  // loading lane's register (returned): the range test of every agent against source q reads it with v_readlane, so the
+  // record is a scalar and its unpacking scalar arithmetic; the (object, AoE index) pairs, read by lane-dependent q later,
+  // go to LDS.
+  auto stage = [&](const uint32_t* pack, const uint16_t* obj, const uint16_t* aoe, size_t base, int q0, int n) -> uint32_t {
 #ifdef MGX_CPU_EMU
     for (int q = 0; q < MGX_WAVE; q++)   // work-items run one after another here: each fills the whole staging itself
       if (q0 + q < n) { s_pack[q] = pack[base + q0 + q]; s_info[q] = (uint32_t)obj[base + q0 + q] | ((uint32_t)aoe[base + q0 + q] << 16); }
+    return 0u;
 #else
     __builtin_amdgcn_wave_barrier();     // the previous chunk has been read by every lane
+    uint32_t mine = 0u;
     if (q0 + lane < n) {
-      s_pack[lane] = pack[base + q0 + lane];
+      mine = pack[base + q0 + lane];
       s_info[lane] = (uint32_t)obj[base + q0 + lane] | ((uint32_t)aoe[base + q0 + lane] << 16);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    return mine;
 #endif
   };
   for (int a0 = 0; a0 < d.A; a0 += MGX_WAVE) {   // (more than 64 agents per env: one pass per 64)
@@ -99,8 +105,8 @@ __global__ void __launch_bounds__(MGX_AOE_THREADS) MGX_AOE_OCCUPANCY mgx_aoe_ker
     if (nf > 0) {
       for (int pass = 0; pass < 2; pass++)
         for (int f0 = 0; f0 < nf; f0 += MGX_WAVE) {
-          stage(d.fx_pack, d.fx_obj, d.fx_aoe, fb, f0, nf);
-          if (valid) ag.fixed_chunk(pass, f0, min(MGX_WAVE, nf - f0), s_pack, s_info);
+          const uint32_t mine = stage(d.fx_pack, d.fx_obj, d.fx_aoe, fb, f0, nf);
+          ag.fixed_chunk(valid, pass, f0, min(MGX_WAVE, nf - f0), mine, s_pack, s_info);
         }
       if (valid) ag.fixed_finish();
     }
@@ -108,8 +114,8 @@ __global__ void __launch_bounds__(MGX_AOE_THREADS) MGX_AOE_OCCUPANCY mgx_aoe_ker
     if (valid && d.NT > 0) ag.territory();
     MGX_TICK(3);
     for (int m0 = 0; m0 < nm; m0 += MGX_WAVE) {
-      stage(d.mb_pack, d.mb_obj, d.mb_aoe, mb, m0, nm);
-      if (valid) ag.mobile_chunk(m0, min(MGX_WAVE, nm - m0), s_pack, s_info);
+      const uint32_t mine = stage(d.mb_pack, d.mb_obj, d.mb_aoe, mb, m0, nm);
+      ag.mobile_chunk(valid, m0, min(MGX_WAVE, nm - m0), mine, s_pack, s_info);
     }
     MGX_TICK(4);
     if (valid) {

@@ -92,7 +92,7 @@ struct MgxLocalAgent {
   unsigned long long def_order;
   int def_cnt;
 
-  __device__ __forceinline__ MgxLocalAgent(const Env& env) : e(env), d(env.d) {}
+  __device__ __forceinline__ MgxLocalAgent(const Env& env) : e(env), d(env.d), ai(0), slot(0), r(0), c(0) {}
 
   // ---- load: everything the phase may read of this agent, in three rounds of independent loads ----
   __device__ __forceinline__ void load(int agent, float* stat_cells, const uint8_t* stat_map, const int16_t* stat_ids, int* deferred) {
@@ -387,19 +387,28 @@ struct MgxLocalAgent {
   }
   // AOETracker::apply_fixed (core/aoe_tracker.cpp:278-362), sources [f0, f0 + n) staged in s_pack / s_info (obj | aoe << 16).
   // pass 0: every exit of this agent first; pass 1: the covering sources in registration order.
-  __device__ __forceinline__ void fixed_chunk(int pass, int f0, int n, const uint32_t* s_pack, const uint32_t* s_info) {
-    uint32_t* words = &d.fx_inside[e.ao(ai) * d.FW + (f0 >> 5)];
+  // (`valid`: this lane holds an agent; every lane of the wavefront runs the scan loop — the records come out of lane
+  // registers with v_readlane — and only valid lanes do anything with the result.  `mine`: lane q's packed record.)
+  __device__ __forceinline__ void fixed_chunk(bool valid, int pass, int f0, int n, uint32_t mine, const uint32_t* s_pack, const uint32_t* s_info) {
+    uint32_t* words = &d.fx_inside[e.ao(valid ? ai : 0) * d.FW + (f0 >> 5)];
     const int nw = (n + 31) >> 5;  // 1 or 2 words of this agent's bitmap
-    uint32_t in0 = words[0], in1 = nw > 1 ? words[1] : 0u;
+    uint32_t in0 = valid ? words[0] : 0u, in1 = (valid && nw > 1) ? words[1] : 0u;
     const uint32_t old0 = in0, old1 = in1;
     unsigned long long todo = 0;
     for (int q = 0; q < n; q++) {
+#ifdef MGX_CPU_EMU
+      (void)mine;
       const uint32_t p = s_pack[q];
+#else
+      (void)s_pack;
+      const uint32_t p = (uint32_t)__builtin_amdgcn_readlane((int)mine, q);
+#endif
       const bool covers = mgx_pack_covers(p, r, c);
       const bool was = (((q < 32 ? in0 : in1) >> (q & 31)) & 1u) != 0;
       const bool pick = pass == 0 ? (((p >> 24) & 1u) && was && !covers) : covers;
       if (pick) todo |= 1ull << q;
     }
+    if (!valid) return;
     while (todo) {
       const int q = __ffsll((unsigned long long)todo) - 1;
       todo &= todo - 1;
@@ -459,19 +468,26 @@ struct MgxLocalAgent {
   }
   // AOETracker::apply_mobile (core/aoe_tracker.cpp:364-415): this agent against the mobile sources [m0, m0 + n), in
   // registration order; only sources in range (or left since the last tick) take the full path.
-  __device__ __forceinline__ void mobile_chunk(int m0, int n, const uint32_t* s_pack, const uint32_t* s_info) {
-    uint32_t* words = &d.mb_inside[e.ao(ai) * d.MW + (m0 >> 5)];
+  __device__ __forceinline__ void mobile_chunk(bool valid, int m0, int n, uint32_t mine, const uint32_t* s_pack, const uint32_t* s_info) {
+    uint32_t* words = &d.mb_inside[e.ao(valid ? ai : 0) * d.MW + (m0 >> 5)];
     const int nw = (n + 31) >> 5;
-    uint32_t in0 = words[0], in1 = nw > 1 ? words[1] : 0u;
+    uint32_t in0 = valid ? words[0] : 0u, in1 = (valid && nw > 1) ? words[1] : 0u;
     const uint32_t old0 = in0, old1 = in1;
     unsigned long long todo = 0, inr = 0;
     for (int q = 0; q < n; q++) {
+#ifdef MGX_CPU_EMU
+      (void)mine;
       const uint32_t p = s_pack[q];
+#else
+      (void)s_pack;
+      const uint32_t p = (uint32_t)__builtin_amdgcn_readlane((int)mine, q);
+#endif
       const bool in_range = mgx_pack_covers(p, r, c);
       const bool was = (((q < 32 ? in0 : in1) >> (q & 31)) & 1u) != 0;
       if (((p >> 24) & 1u) && (in_range || was)) todo |= 1ull << q;
       if (in_range) inr |= 1ull << q;
     }
+    if (!valid) return;
     while (todo) {
       const int q = __ffsll((unsigned long long)todo) - 1;
       todo &= todo - 1;
