@@ -51,45 +51,91 @@ __device__ __forceinline__ void mgx_act_apply_gsets(const ENV& e, const MgxDev& 
   }
 }
 
-// std::shuffle of the env's agent order (bits/stl_algo.h:3729-3795; same draws as mgx_shuffle_order) with the order held one
-// element per lane — lane p of the env's run holds order[p] — so that a swap is one cross-lane read instead of four
-// dependent LDS accesses.  The generator's outputs are drawn by the run's first lane, eight at a time, and broadcast.
-// Every lane of the wavefront executes the same sequence (runs that are done, or not in use, swap nothing).
+// std::shuffle of the env's agent order (bits/stl_algo.h:3729-3795; same draws as mgx_shuffle_order), spread over the lanes
+// of the env's run.  The serial form costs a 64-agent env 32 draws one after another — each an integer multiply and three
+// integer divisions, ≈ 80 instructions — which every lane of a one-env wavefront would execute redundantly: it was 38 % of
+// the kernel.  Here lane q < A / 2 produces generator output q itself (incremental twist of state word i0 + q: it needs
+// the old words i0 + q + 1 and i0 + q + 397, none of which another lane of the block rewrites) and turns it into draw q's
+// pair of swaps; the swaps — the only serial part — are then applied in draw order, the order held one element per lane
+// (lane p holds order[p]; a swap is one cross-lane read).  A Lemire rejection (probability ≈ range / 2^32 per draw) shifts
+// every later draw by one output: an env that sees one replays the draws serially from the outputs already made, pulling
+// the extra output(s) with rng_next.  Every lane of the wavefront executes the same instruction sequence.
 template <class ENV>
-__device__ __forceinline__ int mgx_act_shuffle(const ENV& e, int A, int p, int segbase, bool env_valid) {
+__device__ __forceinline__ int mgx_act_shuffle(const ENV& e, const MgxDev& d, int A, int p, int segbase, unsigned long long seg, bool env_valid) {
   int ord = p;
   const uint32_t nd = (env_valid && A >= 2) ? (uint32_t)A / 2 : 0u;  // A even: 1 + (A - 2) / 2 draws, A odd: (A - 1) / 2
-  uint32_t j = 0;                                                      // draws done (the same in every lane of the run)
-  auto swap = [&](int a, int b) {   // a < 0: nothing
-    const int src = a < 0 ? p : p == a ? b : p == b ? a : p;
+  auto swap = [&](int a, int b) {   // a == 0xFF: nothing
+    const int src = a == 0xFF ? p : p == a ? b : p == b ? a : p;
     ord = __shfl(ord, segbase + src);
   };
-  while (__any(j < nd)) {
-    uint32_t r[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
-    const uint32_t cnt = j < nd ? min(8u, nd - j) : 0u;
-    if (p == 0 && cnt > 0) e.rng_block(r, cnt);
-#pragma unroll
-    for (int q = 0; q < 8; q++) {
-      const uint32_t rq = (uint32_t)__shfl((int)r[q], segbase);
-      int a1 = -1, b1 = 0, a2 = -1, b2 = 0;
-      if ((uint32_t)q < cnt) {
-        const bool first_even = (A & 1) == 0 && j == 0;
-        const uint32_t i = (A & 1) == 0 ? 2 * j : 2 * j + 1;  // index of the pair's first element (paired draws)
-        const uint32_t sft = i + 1;
-        const uint32_t range = first_even ? 2u : sft * (sft + 1);
-        const unsigned long long pr = (unsigned long long)rq * range;
-        const uint32_t low = (uint32_t)pr;
-        const bool accept = low >= range || low >= (0u - range) % range;   // (Lemire: a rejection consumes one more output)
-        if (accept) {
-          const uint32_t x = (uint32_t)(pr >> 32);
-          if (first_even) { a1 = 1; b1 = (int)x; }
-          else { a1 = (int)i; b1 = (int)(x / (sft + 1)); a2 = (int)i + 1; b2 = (int)(x % (sft + 1)); }
-          j++;
-        }
-      }
-      swap(a1, b1);
-      swap(a2, b2);
+  // the two swaps of draw j from generator output r: a1 | b1 << 8 | a2 << 16 | b2 << 24; accept = no Lemire rejection
+  auto draw = [&](uint32_t j, uint32_t r, bool& accept) -> uint32_t {
+    const bool first_even = (A & 1) == 0 && j == 0;
+    const uint32_t i = (A & 1) == 0 ? 2 * j : 2 * j + 1;  // index of the pair's first element (paired draws)
+    const uint32_t sft = i + 1;
+    const uint32_t range = first_even ? 2u : sft * (sft + 1);
+    const unsigned long long pr = (unsigned long long)r * range;
+    const uint32_t low = (uint32_t)pr;
+    accept = low >= range || low >= (0u - range) % range;
+    const uint32_t x = (uint32_t)(pr >> 32);
+    if (first_even) return 1u | (x << 8) | (0xFFu << 16);
+    return i | ((x / (sft + 1)) << 8) | ((i + 1) << 16) | ((x % (sft + 1)) << 24);
+  };
+  const int ev = e.envi();
+  uint32_t rq = 0, packed = 0xFFu | (0xFFu << 16);
+  bool rejected = false;
+  if ((uint32_t)p < nd) {
+    const size_t E = (size_t)d.E;
+    const uint32_t i0 = d.mt_idx[ev];
+    uint32_t i = i0 + (uint32_t)p; i = i >= 624 ? i - 624 : i;
+    uint32_t i1 = i + 1; i1 = i1 >= 624 ? i1 - 624 : i1;
+    uint32_t im = i + 397; im = im >= 624 ? im - 624 : im;
+    const uint32_t w0 = d.mt[i * E + ev], w1 = d.mt[i1 * E + ev], wm = d.mt[im * E + ev];
+    const uint32_t y = (w0 & 0x80000000u) | (w1 & 0x7fffffffu);
+    uint32_t x = wm ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    d.mt[i * E + ev] = x;   // (data dependence on the loads of every lane: all old words are read before any is rewritten)
+    x ^= x >> 11;
+    x ^= (x << 7) & 0x9d2c5680u;
+    x ^= (x << 15) & 0xefc60000u;
+    x ^= x >> 18;
+    rq = x;
+    if (p == 0) { const uint32_t n1 = i0 + nd; d.mt_idx[ev] = n1 >= 624 ? n1 - 624 : n1; }
+    bool accept;
+    packed = draw((uint32_t)p, rq, accept);
+    rejected = !accept;
+  }
+#ifdef MGX_ACT_SHUFFLE_REPLAY   // (developer build: every step takes the replay path below)
+  rejected = true;
+#endif
+  const bool env_rejected = (__ballot(rejected) & seg) != 0ull;
+  if (!__any(env_rejected)) {
+    const uint32_t ndmax = (uint32_t)A / 2;   // (the same for every env of the launch)
+    for (uint32_t j = 0; j < ndmax; j++) {
+      const uint32_t pk = (uint32_t)__shfl((int)packed, segbase + (int)j);
+      swap((int)(pk & 0xFF), (int)((pk >> 8) & 0xFF));
+      swap((int)((pk >> 16) & 0xFF), (int)(pk >> 24));
     }
+    return ord;
+  }
+  // a rejection somewhere in the wavefront: every env replays its draws serially over the outputs (same result for the
+  // envs without one)
+  mgx_act_fence();   // the parallel twist's stores are visible to rng_next below
+  uint32_t j = 0, k = 0;   // draws done, outputs consumed (the same in every lane of the run)
+  while (__any(j < nd)) {
+    uint32_t extra = 0;
+    if (j < nd && k >= nd && p == 0) extra = e.rng_next();
+    const uint32_t from_block = (uint32_t)__shfl((int)rq, segbase + (int)min(k, nd > 0 ? nd - 1 : 0u));
+    const uint32_t from_extra = (uint32_t)__shfl((int)extra, segbase);
+    const uint32_t r = k < nd ? from_block : from_extra;
+    bool accept = false;
+    uint32_t pk = 0xFFu | (0xFFu << 16);
+    if (j < nd) {
+      const uint32_t v = draw(j, r, accept);
+      if (accept) { pk = v; j++; }
+      k++;
+    }
+    swap((int)(pk & 0xFF), (int)((pk >> 8) & 0xFF));
+    swap((int)((pk >> 16) & 0xFF), (int)(pk >> 24));
   }
   return ord;
 }
@@ -131,7 +177,7 @@ __device__ __forceinline__ void mgx_act_body(const MgxDev& d, PP P, uint8_t* ord
   mgx_act_fence();
   MGX_TICK(0);
   const int segbase = wl - p;
-  const int ai = mgx_act_shuffle(e, A, p, segbase, env < d.E);
+  const int ai = mgx_act_shuffle(e, d, A, p, segbase, seg, env < d.E);
   MGX_TICK(1);
   // footprints u32[A'][EPG] (by order position) and, when the map is small enough, cell -> order position of the pending
   // agent standing there u8[EPG][H * W] (entries are validated against the footprints, so stale ones are harmless)

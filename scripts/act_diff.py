@@ -27,9 +27,10 @@ seeds = np.arange(E, dtype=np.uint32)
 A, n_act = prog.num_agents, len(prog.action_names)
 par = BatchedMettaGrid(prog, cms, seeds, buffers="device")
 os.environ["MGX_ACT_SERIAL"] = "1"
+os.environ["MGX_NO_GEN"] = "1"          # the baseline: lane per env, handler interpreter
 ser = BatchedMettaGrid(prog, cms, seeds, buffers="device")
-del os.environ["MGX_ACT_SERIAL"]
-print("variants:", par.L.mgx_act_variant(par.h), ser.L.mgx_act_variant(ser.h))
+del os.environ["MGX_ACT_SERIAL"], os.environ["MGX_NO_GEN"]
+print("dispatch variants:", par.act_variant, ser.act_variant, "handler variants:", par.handler_variant, ser.handler_variant)
 gen = torch.Generator(device="cuda").manual_seed(99 + rung)
 DBG_ENV = int(os.environ.get("ACT_DBG_ENV", "-1"))
 DBG_STEP = int(os.environ.get("ACT_DBG_STEP", "-1"))
@@ -50,6 +51,8 @@ for t in range(steps):
         for p_ in range(64):
             print(f"pos {p_:2d} agent {buf[p_] & 0xFF:2d} round {buf[p_] >> 8} own ({buf[64 + p_] >> 24},{(buf[64 + p_] >> 16) & 0xFF}) tgt ({(buf[64 + p_] >> 8) & 0xFF},{buf[64 + p_] & 0xFF}) act {buf[128 + p_]}")
         par.L.mgx_debug_act_env(-1)
+    if (t + 1) % int(os.environ.get("ACT_DIFF_EVERY", "1")) and t + 1 < steps:
+        continue
     dp, ds = par.state_digests(), ser.state_digests()
     bad = np.nonzero(dp != ds)[0]
     if len(bad):
