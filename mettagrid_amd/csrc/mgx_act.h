@@ -104,9 +104,7 @@ __device__ __forceinline__ int mgx_act_shuffle(const ENV& e, const MgxDev& d, in
     packed = draw((uint32_t)p, rq, accept);
     rejected = !accept;
   }
-#ifdef MGX_ACT_SHUFFLE_REPLAY   // (developer build: every step takes the replay path below)
-  rejected = true;
-#endif
+  if (d.act_replay) rejected = true;   // (MGX_ACT_SHUFFLE_REPLAY: every step takes the replay path below — how the tests reach it)
   const bool env_rejected = (__ballot(rejected) & seg) != 0ull;
   if (!__any(env_rejected)) {
     const uint32_t ndmax = (uint32_t)A / 2;   // (the same for every env of the launch)

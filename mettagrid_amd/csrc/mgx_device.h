@@ -44,6 +44,7 @@ struct MgxDev {
   int act_ngset;          // game-scope stats the action-phase handlers SET (StatsMutation): applied in agent order at the end
   int act_gset_ids[4];
   int act_lds_extra;      // bytes per workgroup behind the game-stat cells: footprints u32[A'][EPG] | cell map u8[EPG][H*W] (0: no cell map)
+  int act_replay;         // 1 (env MGX_ACT_SHUFFLE_REPLAY): the shuffle always takes its serial replay path (tests)
   int act_map;            // 1: conflicts are looked up through the cell map (H*W <= 4096); 0: all-pairs walk over the pending lanes
   int feat[16];
   int wk[32];             // well-known stat ids (MGX_S_*)

@@ -1017,6 +1017,7 @@ int mgx_create(const int32_t* program, size_t program_words, const uint16_t* cla
     par = false;   // wavefront-cooperative (ballot / readlane): not part of the sanitizer build
 #endif
     d.act_par = par ? 1 : 0;
+    d.act_replay = getenv("MGX_ACT_SHUFFLE_REPLAY") ? 1 : 0;
     d.act_tick = (par && tick) ? 1 : 0;
     d.act_ngset = par ? (int)gset.size() : 0;
     for (int k = 0; k < 4; k++) d.act_gset_ids[k] = (par && k < (int)gset.size()) ? gset[k] : -1;

@@ -82,18 +82,25 @@ def test_crowded_extended_arena():
 
 
 @pytest.mark.parametrize("rung", [3, 4])
-def test_agent_kernel_equals_env_kernel_by_digest(rung, monkeypatch):
+def test_shuffle_replay_path(rung, monkeypatch):
+    """The lanes of an env draw the shuffle's swaps in parallel; a Lemire rejection (about one draw in a million) makes the
+    env replay them serially.  MGX_ACT_SHUFFLE_REPLAY sends every step down that path: same digests as the env kernel."""
+    monkeypatch.setenv("MGX_ACT_SHUFFLE_REPLAY", "1")
+    test_agent_kernel_equals_env_kernel_by_digest(rung, monkeypatch, E=2048, steps=30)
+
+
+@pytest.mark.parametrize("rung", [3, 4])
+def test_agent_kernel_equals_env_kernel_by_digest(rung, monkeypatch, E=8192, steps=None):
     """Same maps, seeds and action traces through both kernels: equal state digests after every tenth step, 8 192 envs."""
     import torch
-    E = 8192
     if rung == 3:
         prog = compile_spec(presets.rung3_spec(), 32, 32, max_objects=192)
-        maps = random_class_maps(prog, 32, 32, {"wall": 40, "extractor": 8, "chest": 4}, {"red": 8, "blue": 8}, range(1024))
-        steps = 120
+        maps = random_class_maps(prog, 32, 32, {"wall": 40, "extractor": 8, "chest": 4}, {"red": 8, "blue": 8}, range(min(E, 1024)))
+        steps = steps or 120
     else:
         prog = compile_spec(presets.rung4_spec(), 64, 64, max_objects=presets.RUNG4_MAX_OBJECTS)
-        maps = random_class_maps(prog, 64, 64, presets.RUNG4_OBJECTS, presets.RUNG4_AGENTS, range(512))
-        steps = 60
+        maps = random_class_maps(prog, 64, 64, presets.RUNG4_OBJECTS, presets.RUNG4_AGENTS, range(min(E, 512)))
+        steps = steps or 60
     cms = maps[np.arange(E) % len(maps)]
     seeds = np.arange(E, dtype=np.uint32)
     monkeypatch.setenv("MGX_ACT_LEAN", "1")
