@@ -237,22 +237,35 @@ __device__ __forceinline__ void mgx_act_body(const MgxDev& d, PP P, uint8_t* ord
         }
         mgx_act_fence();
         if (pending) {
-          auto at = [&](int r, int c, uint32_t& Fj) -> bool {   // an earlier pending agent standing on (r, c)?
-            if (r < 0 || c < 0 || r >= d.H || c >= d.W) return false;
-            const int j = cmap[r * d.W + c];
-            if (j >= p || !((pend >> (segbase + j)) & 1ull)) return false;
-            Fj = fps[j * MGX_WORLD_EPG + envl];
-            return (Fj >> 16) == (uint32_t)((r << 8) | c);
-          };
-          uint32_t Fj;
+          // 17 cells: [0] my target, [1..8] the neighbours of my cell, [9..16] the neighbours of my target.  All map reads
+          // first, then all footprint reads, then the decisions: two LDS latencies instead of thirty-four in a row.
           const int orow = (int)(own >> 8), ocol = (int)(own & 0xFF), trow = (int)(tgt >> 8), tcol = (int)(tgt & 0xFF);
-          if (tgt != own && at(trow, tcol, Fj)) clear = false;                      // tgt == oj
+          const bool has_tgt = tgt != own;
+          int jj[17];
+          uint32_t rc17[17];
+          bool ok[17];
 #pragma unroll
-          for (int k = 0; k < 9; k++) {
-            if (k == 4) continue;
-            const int dr = k / 3 - 1, dc = k % 3 - 1;
-            if (at(orow + dr, ocol + dc, Fj) && (Fj & 0xFFFFu) == own) { clear = false; hit = true; }   // own == tj
-            if (tgt != own && at(trow + dr, tcol + dc, Fj) && (Fj & 0xFFFFu) == tgt) clear = false;     // tgt == tj
+          for (int k = 0; k < 17; k++) {
+            const int n = k == 0 ? 4 : (k - 1) & 7;          // neighbour number 0..7 -> (dr, dc) without the centre
+            const int m = n < 4 ? n : n + 1;
+            const int dr = k == 0 ? 0 : m / 3 - 1, dc = k == 0 ? 0 : m % 3 - 1;
+            const int r = (k >= 1 && k <= 8 ? orow : trow) + dr, c = (k >= 1 && k <= 8 ? ocol : tcol) + dc;
+            ok[k] = r >= 0 && c >= 0 && r < d.H && c < d.W && (k >= 1 && k <= 8 ? true : has_tgt);
+            rc17[k] = (uint32_t)((r << 8) | c);
+            jj[k] = cmap[ok[k] ? r * d.W + c : 0];
+          }
+          uint32_t fj[17];
+#pragma unroll
+          for (int k = 0; k < 17; k++) {
+            ok[k] = ok[k] && jj[k] < p && ((pend >> (segbase + (jj[k] & 63))) & 1ull);
+            fj[k] = fps[(ok[k] ? jj[k] : 0) * MGX_WORLD_EPG + envl];
+          }
+#pragma unroll
+          for (int k = 0; k < 17; k++) {
+            const bool there = ok[k] && (fj[k] >> 16) == rc17[k];   // an earlier pending agent stands on that cell
+            if (k == 0) { if (there) clear = false; }                                            // tgt == oj
+            else if (k <= 8) { if (there && (fj[k] & 0xFFFFu) == own) { clear = false; hit = true; } }   // own == tj
+            else { if (there && (fj[k] & 0xFFFFu) == tgt) clear = false; }                      // tgt == tj
           }
         }
       } else
