@@ -749,6 +749,12 @@ __global__ void __launch_bounds__(NTH) mgx_obs_kernel(MgxDev d, int pool_tokens,
   // DPP steps), row-wide values travel by ds_bpermute, long token lists are copied by the 16 lanes of their row. ----
   if (WITH_REWARDS && rewards_mid && wave == (NTH / MGX_WAVE) - 1)
     for (int a = lane; a < A; a += MGX_WAVE) agent_rewards(a);
+  // GridObject::visited stamps (:789-796): first observers are final since the window lists, and the encode only reads the
+  // LDS copies — with wavefronts to spare (EW < NTH / 64) they write the stamps now instead of everybody behind the encode
+  constexpr bool stamps_mid = EW < NTH / MGX_WAVE;
+  if (stamps_mid && step > 0 && wave >= EW)
+    for (int s = (wave - EW) * MGX_WAVE + lane; s < S; s += (NTH / MGX_WAVE - EW) * MGX_WAVE)
+      if (s_minobs[s] != 0xFFFFFFFFu && s_visited[s] < step) d.obj_visited[e.so(s)] = step;
   for (int a0 = wave < EW ? wave * 4 : A; a0 < A; a0 += EW * 4) {
     const int a = a0 + row;
     const bool av = a < A;          // this row has an agent
@@ -909,7 +915,7 @@ __global__ void __launch_bounds__(NTH) mgx_obs_kernel(MgxDev d, int pool_tokens,
   MGX_PHASE_END(4);
 
   // ---- visited stamps, token statistics, rewards, termination ----
-  if (step > 0)
+  if (!stamps_mid && step > 0)
     for (int s = tid; s < S; s += NTH)
       if (s_minobs[s] != 0xFFFFFFFFu && s_visited[s] < step) d.obj_visited[e.so(s)] = step;
   if (wave == 0) {  // tokens_written / tokens_free_space (:659-661, 821-823): the reference adds agent by agent in f32
