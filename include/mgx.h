@@ -199,7 +199,8 @@ int mgx_get_step_timing(mgx_engine* e, float* ms_out /* [MGX_T_COUNT] */);
 
 /* Shape queries. */
 /* Which instance of the observation kernel the engine launches: 0 = the generic one (shape read at run time), 3 = the
- * instance compiled for the shape of BASELINE.json configs[2] (mettagrid_amd/gen_presets.py). Diagnostic. */
+ * instance compiled for the shape of BASELINE.json configs[2] (mettagrid_amd/gen_presets.py), 5 = the same shape with an
+ * episode length set (max_steps read at run time). Diagnostic. */
 int32_t mgx_obs_variant(const mgx_engine* e);
 /* How the action dispatch of MettaGrid::_step (mettagrid_c.cpp:966-999) is executed: 0 = one lane per env, agents one
  * after another; 1 = one lane per agent, in rounds ordered by the agents' cell footprints (mgx_act.h) — chosen at

@@ -357,6 +357,7 @@ static int size_obs_lds(mgx_engine* e) {
   e->obs_variant = 0;
   if (!getenv("MGX_OBS_GENERIC")) {
     if (!d.X && e->obs_blk_lds && mgx_obs_shape_matches<MgxObsShapeR3>(d, e->obs_blk_words, (e->rewards_early ? 1 : e->rewards_mid ? 2 : 0))) e->obs_variant = 3;
+    else if (!d.X && e->obs_blk_lds && mgx_obs_shape_matches<MgxObsShapeR3AnyLength>(d, e->obs_blk_words, (e->rewards_early ? 1 : e->rewards_mid ? 2 : 0))) e->obs_variant = 5;   // same shape, max_steps set
     // (an instance for the shape of configs[3], MgxObsShapeR4, was measured too: 5.07 ms against the generic kernel's 5.01 —
     // the extended kernel's time is barrier and LDS latency, not scalar arithmetic; it is not built)
   }
@@ -375,6 +376,8 @@ static int size_obs_lds(mgx_engine* e) {
   if (e->lds_obs > cur_max) {
     const void* fns[] = {(const void*)mgx_obs_kernel<true, false, true, MGX_OBS_THREADS, MGX_OBS_THREADS / MGX_WAVE, MgxObsShapeR3>,
                          (const void*)mgx_obs_kernel<false, false, true, MGX_OBS_THREADS, MGX_OBS_THREADS / MGX_WAVE, MgxObsShapeR3>,
+                         (const void*)mgx_obs_kernel<true, false, true, MGX_OBS_THREADS, MGX_OBS_THREADS / MGX_WAVE, MgxObsShapeR3AnyLength>,
+                         (const void*)mgx_obs_kernel<false, false, true, MGX_OBS_THREADS, MGX_OBS_THREADS / MGX_WAVE, MgxObsShapeR3AnyLength>,
                          (const void*)mgx_obs_kernel<true, false, false>, (const void*)mgx_obs_kernel<false, false, false>,
                          (const void*)mgx_obs_kernel<true, false, true>,  (const void*)mgx_obs_kernel<false, false, true>,
                          (const void*)mgx_obs_kernel<true, true, false>,  (const void*)mgx_obs_kernel<false, true, false>,
@@ -467,6 +470,7 @@ static int launch_obs(mgx_engine* e, bool with_rewards, const uint8_t* mask = nu
   }
   // a program whose shape equals a preset's runs that preset's instance of the kernel (shape = compile-time constants)
   if (e->obs_variant == 3) launch_obs_t<false, true, MGX_OBS_THREADS, MGX_OBS_THREADS / MGX_WAVE, MgxObsShapeR3>(e, with_rewards, mask);
+  else if (e->obs_variant == 5) launch_obs_t<false, true, MGX_OBS_THREADS, MGX_OBS_THREADS / MGX_WAVE, MgxObsShapeR3AnyLength>(e, with_rewards, mask);
   else if (e->d.X && e->obs_threads == 512 && e->obs_ew == 4) launch_obs_t<true, false, 512, 4>(e, with_rewards, mask);
   else if (e->d.X && e->obs_threads == 512 && e->obs_ew == 3) launch_obs_t<true, false, 512, 3>(e, with_rewards, mask);
   else if (e->d.X && e->obs_threads == 512) launch_obs_t<true, false, 512, 2>(e, with_rewards, mask);

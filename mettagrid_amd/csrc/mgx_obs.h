@@ -231,7 +231,7 @@ struct MgxObsShape {
 template <class K>
 inline bool mgx_obs_shape_matches(const MgxDev& d, int blk_words, int rewards_early) {
   return K::fixed && d.H == K::H && d.W == K::W && d.A == K::A && d.S == K::S && d.T == K::T && d.NOFF == K::NOFF && d.base == K::BASE &&
-         d.n_obs_values == K::NOV && d.NT == K::NT && d.NRW == K::NRW && d.flags == K::FLAGS && d.max_steps == K::MAX_STEPS &&
+         d.n_obs_values == K::NOV && d.NT == K::NT && d.NRW == K::NRW && d.flags == K::FLAGS && (K::MAX_STEPS < 0 || d.max_steps == K::MAX_STEPS) &&   // (MAX_STEPS = -1: any episode length, read at run time)
          blk_words == K::BLKW && d.aoe_mask_feat == K::MASK_FEAT && rewards_early == K::REWARDS_EARLY;
 }
 
@@ -264,7 +264,7 @@ __global__ void __launch_bounds__(NTH) mgx_obs_kernel(MgxDev d, int pool_tokens,
   const int dH = FX ? K::H : d.H, dW = FX ? K::W : d.W, A = FX ? K::A : d.A, S = FX ? K::S : d.S, T = FX ? K::T : d.T,
             NOFF = FX ? K::NOFF : d.NOFF, HW = dH * dW;
   const int dBase = FX ? K::BASE : d.base, NOV = FX ? K::NOV : d.n_obs_values, dNT = FX ? K::NT : d.NT, dNRW = FX ? K::NRW : d.NRW,
-            dFlags = FX ? K::FLAGS : d.flags, dMaxSteps = FX ? K::MAX_STEPS : d.max_steps, dMaskFeat = FX ? K::MASK_FEAT : d.aoe_mask_feat;
+            dFlags = FX ? K::FLAGS : d.flags, dMaxSteps = (FX && K::MAX_STEPS >= 0) ? K::MAX_STEPS : d.max_steps, dMaskFeat = FX ? K::MASK_FEAT : d.aoe_mask_feat;
   const int blk_words = FX ? K::BLKW : blk_words_arg, rewards_mode = FX ? K::REWARDS_EARLY : rewards_early_arg;
   // when the reward expressions read nothing this kernel writes (host: mgx_create), they need not wait for its end:
   //   1 = evaluated early, beside the token-list phase (lean games);

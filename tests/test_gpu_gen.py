@@ -67,3 +67,18 @@ def test_selection_by_fingerprint():
     spec_f, map_f, _, _ = hp.SCENARIOS["torture"]
     m = map_f(0)
     assert variant(spec_f(), *m.shape, m) == 0
+
+
+def test_preset_shape_with_an_episode_length_runs_its_own_instance():
+    """The env wrappers run the presets with max_steps set: same shape, so the observation kernel instance compiled for it
+    (max_steps read at run time, obs_variant 5) — against the oracle across a truncation."""
+    from test_gpu_act import _against_oracle
+    spec = presets.rung3_spec()
+    spec.max_steps = 9
+    prog = compile_spec(spec, 32, 32, max_objects=192)
+    E = 6
+    cms = random_class_maps(prog, 32, 32, {"wall": 40, "extractor": 8, "chest": 4}, {"red": 8, "blue": 8}, range(E))
+    eng = BatchedMettaGrid(prog, cms, np.arange(E, dtype=np.uint32), buffers="host")
+    assert eng.obs_variant == 5 and eng.handler_variant == 3
+    eng.close()
+    _against_oracle(prog, cms, np.arange(E, dtype=np.uint32) + 2, 12, 4, "rung 3 with max_steps", 0)
