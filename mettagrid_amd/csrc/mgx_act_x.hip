@@ -49,8 +49,7 @@ bool mgx_act_x_set_lds(size_t lds) {
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
   size_t& g_lds_max = g_lds_max_dev[dev];
   if (lds <= g_lds_max) return true;
-  if (hipFuncSetAttribute((const void*)mgx_act_kernel_x<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-      hipFuncSetAttribute((const void*)mgx_act_kernel_x<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+  if (hipFuncSetAttribute((const void*)mgx_act_kernel_x<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return false;
   g_lds_max = lds;
   return true;
@@ -62,8 +61,10 @@ void mgx_launch_act_x(bool prog_lds, size_t lds, hipStream_t stream, const MgxDe
   int ap = 1;
   while (ap < d.A) ap <<= 1;
   dim3 grid((d.E + MGX_WORLD_EPG - 1) / MGX_WORLD_EPG), block(MGX_WORLD_EPG * ap);
-  if (prog_lds) hipLaunchKernelGGL((mgx_act_kernel_x<true>), grid, block, lds, stream, dp, prog_words);
-  else hipLaunchKernelGGL((mgx_act_kernel_x<false>), grid, block, lds, stream, dp, prog_words);
+  // (only the variant with the hot program range in LDS is built — the fully inlined kernel takes minutes to compile;
+  // programs whose hot range does not fit keep the lane-per-env kernel: mgx_create)
+  (void)prog_lds;
+  hipLaunchKernelGGL((mgx_act_kernel_x<true>), grid, block, lds, stream, dp, prog_words);
 }
 
 #ifdef MGX_ACT_DEBUG

@@ -924,6 +924,7 @@ int mgx_create(const int32_t* program, size_t program_words, const uint16_t* cla
     // a wavefront there and a round costs what 2.4 serial steps cost, so lean games stay lane per env unless asked.
     if (!d.X && !getenv("MGX_ACT_LEAN")) par = false;
     if (d.X && !d.flat_top) par = false;      // tag mutations, query recomputation / filters: lane-per-env VM
+    if (d.X && !e->prog_in_lds) par = false;  // mgx_act_x.hip is built for the hot program range in LDS only
     const int32_t* mh = P + d.sec[MGX_SEC_MOVE_HANDLERS];
     for (int k = 0; k < d.n_move_handlers; k++)
       if (mh[k * MGX_MH_WORDS + MGX_MH_MAX_RANGE] != 1) par = false;   // footprint = own cell + the cell ahead
@@ -1107,7 +1108,7 @@ int mgx_create(const int32_t* program, size_t program_words, const uint16_t* cla
     }
     e->lds_act = (d.X ? mgx_act_x_lds_bytes(d.A, d.x_aoe_lds != 0, d.act_lds_extra) : mgx_act_fast_lds_bytes(d.A, d.act_lds_extra)) +
                  (e->prog_in_lds ? (size_t)e->prog_lds_words * 4 : 0);
-    if (!(d.X ? mgx_act_x_set_lds(e->lds_act) : (e->slot == 0 ? mgx_act_fast_set_lds_s0(e->lds_act) : mgx_act_fast_set_lds_s1(e->lds_act)))) {
+    if (!(d.X ? mgx_act_x_set_lds(e->lds_act) : mgx_act_fast_set_lds_s0(e->lds_act))) {
       mgx_destroy(e);
       return fail(MGX_ERR_HIP, "mgx_create: cannot raise the action kernel's dynamic LDS limit");
     }
@@ -1480,8 +1481,7 @@ int mgx_step(mgx_engine* e) {
     const bool x_events = d.n_schedule > 0 || (d.any_on_tick && !d.tick_in_aoe);   // what is left of the action launch behind mgx_act_kernel
     if (!d.X) {
       if (d.act_par) {
-        if (e->slot == 0) mgx_launch_act_fast_s0(e->prog_in_lds, e->lds_act, e->stream, e->d, pw);
-        else mgx_launch_act_fast_s1(e->prog_in_lds, e->lds_act, e->stream, e->d, pw);
+        mgx_launch_act_fast_s0(e->prog_in_lds, e->lds_act, e->stream, e->d, pw);   // (one constant-memory copy: an opt-in path)
       } else {
         if (e->slot == 0) mgx_launch_world_fast_s0(e->prog_in_lds, e->lds_world, e->stream, e->d, pw);
         else mgx_launch_world_fast_s1(e->prog_in_lds, e->lds_world, e->stream, e->d, pw);

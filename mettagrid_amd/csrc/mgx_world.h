@@ -2250,9 +2250,7 @@ bool mgx_world_fast_set_lds_s1(size_t lds);
 size_t mgx_act_fast_lds_bytes(int A, int extra);
 int mgx_act_fast_epg();   // envs per workgroup of the unit
 void mgx_launch_act_fast_s0(bool prog_lds, size_t lds, hipStream_t stream, const MgxDev& d, int prog_words);
-void mgx_launch_act_fast_s1(bool prog_lds, size_t lds, hipStream_t stream, const MgxDev& d, int prog_words);
 bool mgx_act_fast_set_lds_s0(size_t lds);
-bool mgx_act_fast_set_lds_s1(size_t lds);
 void mgx_launch_act_x(bool prog_lds, size_t lds, hipStream_t stream, const MgxDev& d, const MgxDev* dev_copy, int prog_words);
 bool mgx_act_x_set_lds(size_t lds);
 size_t mgx_act_x_lds_bytes(int A, bool aoe_lds, int extra);

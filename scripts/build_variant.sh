@@ -17,7 +17,6 @@ hipcc $F $(x aoe) -c $C/mgx_aoe.hip -o $O/a.o &
 hipcc $F $(x decode) -c $C/mgx_decode.hip -o $O/d.o &
 hipcc $F $(x box) -c $C/mgx_obs_box.hip -o $O/b.o &
 hipcc $F $(x actf) -DMGX_SLOT=0 -c $C/mgx_act_fast.hip -o $O/af0.o &
-hipcc $F $(x actf) -DMGX_SLOT=1 -c $C/mgx_act_fast.hip -o $O/af1.o &
 hipcc $F $(x actx) -c $C/mgx_act_x.hip -o $O/ax.o &
 for job in $(jobs -p); do wait $job; done
 mkdir -p $ROOT/build

@@ -15,9 +15,7 @@ size_t mgx_act_fast_lds_bytes(int, int) { return 0; }
 int mgx_act_fast_epg() { return 1; }
 int mgx_act_x_epg() { return 1; }
 void mgx_launch_act_fast_s0(bool, size_t, hipStream_t, const MgxDev&, int) {}
-void mgx_launch_act_fast_s1(bool, size_t, hipStream_t, const MgxDev&, int) {}
 bool mgx_act_fast_set_lds_s0(size_t) { return true; }
-bool mgx_act_fast_set_lds_s1(size_t) { return true; }
 void mgx_launch_act_x(bool, size_t, hipStream_t, const MgxDev&, const MgxDev*, int) {}
 bool mgx_act_x_set_lds(size_t) { return true; }
 size_t mgx_act_x_lds_bytes(int, bool, int) { return 0; }
