@@ -390,6 +390,66 @@ def env_wrapper_throughput(envs: int, steps: int, local_rank: int) -> dict:
     return out
 
 
+def launch_ranks(n: int) -> int:
+    """One child process per GPU with the environment torch.distributed.run would give it (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_ADDR / MASTER_PORT), same argv.  Children are fresh interpreters started BEFORE anything here touches the GPU.
+    Returns the exit code: 0 only if every rank exited 0."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    code = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                rc = p.poll()
+                if rc is None:
+                    continue
+                pending.remove(p)
+                if rc != 0 and code == 0:   # one rank failed: the others would wait for it in the next barrier forever
+                    code = rc if rc > 0 else 1
+                    for q in pending:
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return code
+
+
+def stub_rank(args, rank: int, world: int) -> int:
+    """--stub: the multi-rank plumbing without a GPU — rendezvous over gloo, the env shard of every rank, one all-reduce in
+    place of the timing reduction; rank 0 prints the line."""
+    import torch
+    from mettagrid_amd.dist import env_shard
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("gloo")
+        if dist.get_world_size() != args.gpus:
+            return 3
+        n = torch.tensor([len(env_shard(rank, world, args.envs))], dtype=torch.int64)
+        dist.all_reduce(n)
+        dist.barrier()
+        total, size = int(n.item()), dist.get_world_size()
+        dist.destroy_process_group()
+    else:
+        total, size = len(env_shard(0, 1, args.envs)), 1
+    if rank == 0:
+        print(json.dumps({"metric": "agent-steps/sec (whole node) at 65 536 envs, 32x32x16-agent; HBM GB/s vs peak", "value": None,
+                          "stub": True, "n_gpus": size, "steps": args.steps, "warmup": args.warmup, "envs_total": total,
+                          "scaling": "weak"}))
+    return 0
+
+
 def main() -> None:
     if len(sys.argv) > 1 and sys.argv[1] == "--cpu-worker":
         cpu_worker(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), float(sys.argv[5]))
@@ -412,11 +472,22 @@ def main() -> None:
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="headline only: skip the rung-4 object and the env-wrapper throughput")
     ap.add_argument("--rung4-steps", type=int, default=100)
+    ap.add_argument("--stub", action="store_true",
+                    help="launcher self-test (tests/test_bench_launcher.py): the ranks rendezvous over gloo and do no GPU work; "
+                         "rank 0 prints a line whose n_gpus is the communicator's size and whose value is null")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` by hand: start the N ranks ourselves (what torch.distributed.run does for the driver).
+        # This parent never touches the GPU; rank 0's line is the output.
+        raise SystemExit(launch_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if args.stub:
+        raise SystemExit(stub_rank(args, rank, world))
     extras = world == 1 and args.rung == 3 and not args.no_extras
     from mettagrid_amd.dist import env_shard
 
@@ -439,6 +510,8 @@ def main() -> None:
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but the RCCL communicator has {dist.get_world_size()} ranks")
 
     common = dict(envs=args.envs, groups=args.groups, gather_kind=args.gather, rank=rank, local_rank=local_rank, world=world, dist=dist)
     head = measure(args.rung, cms, steps=args.steps, warmup=args.warmup, rounds=args.rounds, **common)

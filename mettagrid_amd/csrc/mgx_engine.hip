@@ -17,6 +17,7 @@
 #include "mgx_handlers_fp.h"   // fingerprints of the presets' handler tables (mettagrid_amd/gen_handlers.py, written at build())
 #include "mgx_world.h"
 #include "mgx_aoe_local.h"
+#include "mgx_episode.h"
 
 
 // Territory ownership map (TerritoryTracker::compute_cell_ownership, core/territory_tracker.cpp:215-252) of every cell,
@@ -186,7 +187,7 @@ __global__ void __launch_bounds__(256) mgx_objects_kernel(const MgxDev* __restri
 // dense-output instances of the observation kernel (mgx_obs_box.hip)
 bool mgx_launch_obs_box(hipStream_t stream, const MgxDev& dd, size_t lds, int pool_tokens, int pool_prefix, const uint8_t* mask, int blk_start,
                         int blk_words, int rewards_early, bool with_rewards, bool X, bool PL, int threads, int ew, void* box, const float* scale,
-                        int C, int dtype);
+                        int C, int dtype, const int32_t* env_list, const uint32_t* env_list_n, int list_grid, int stat_passes);
 bool mgx_obs_box_set_lds(size_t lds);
 // token decode kernel (mgx_decode.hip)
 int mgx_launch_decode(hipStream_t stream, const uint8_t* tokens, float* box, const float* scale_dev, long long rows, int T, int C, int H, int W);
@@ -291,6 +292,23 @@ struct mgx_engine {
   bool auto_reset = false;
   int pool_stride = 1;
   uint32_t step_seq = 0;
+  int32_t* d_done_list = nullptr;   // [E] the envs of d_next_mask in ascending order (mgx_episode_end_kernel) ...
+  uint32_t* d_done_n = nullptr;     // [1] ... and how many: what the restart and episode-statistics kernels walk
+  // episode-end statistics (mgx_set_episode_stats; csrc/mgx_episode.h)
+  bool ep_stats = false;
+  MgxEpLayout ep{};
+  uint32_t* d_ep_rec = nullptr;     // [E][ep.rec_words] records of the envs that finished in the last step
+  double* d_ep_partial = nullptr;   // [ceil(E / 256)][TW] chunk sums
+  double* d_ep_totals = nullptr;    // [TW] batch totals since the last snapshot
+  double* d_ep_snap = nullptr;      // [TW] snapshot taken by mgx_request_episode_stats
+  double* h_ep_snap = nullptr;      // pinned host copy of the snapshot
+  uint32_t* d_ep_ticket = nullptr;  // [1]
+  uint32_t* d_ep_log = nullptr;     // [ep_log_cap][ep.log_words] per-episode records kept for mgx_drain_episode_log
+  uint32_t* d_ep_log_state = nullptr;  // [2] records in the log, records dropped
+  int ep_log_cap = 0;
+  hipEvent_t ep_ev = nullptr;       // recorded behind the snapshot copy
+  bool ep_pending = false;          // a snapshot has been requested and not fetched yet
+  int ep_tw() const { return MGX_EP_TOT_HDR + 2 * (ep.NG + ep.NS); }
   unsigned long long* d_digest = nullptr;   // [E] mgx_state_digests
   int32_t* d_objs = nullptr;        // mgx_get_objects_batch: env list | counts | packed records
   size_t objs_cap = 0;              // envs the buffer holds
@@ -391,16 +409,26 @@ static int size_obs_lds(mgx_engine* e) {
   return MGX_OK;
 }
 
+// Grid of a restart kernel that walks a device list whose length only the device knows: enough workgroups to fill the chip,
+// each taking every grid-th entry.  n_host >= 0: the host knows the length (host-driven restarts) and launches exactly that.
+struct MgxList { const int32_t* list = nullptr; const uint32_t* n = nullptr; int n_host = -1; int passes = 1; };   // passes: see mgx_obs.h (token statistics of a restart)
+static unsigned list_grid(const mgx_engine* e, const MgxList& l, int cap) {
+  return (unsigned)std::max(1, l.n_host >= 0 ? std::min(l.n_host, e->d.E) : std::min(e->d.E, cap));
+}
 template <bool X, bool PL, int NTH = MGX_OBS_THREADS, int EW = NTH / MGX_WAVE, class K = MgxObsShapeDyn>
-static void launch_obs_t(mgx_engine* e, bool with_rewards, const uint8_t* mask) {
-  dim3 grid(e->d.E), block(NTH);
+static void launch_obs_t(mgx_engine* e, bool with_rewards, const uint8_t* mask, const MgxList& l) {
+  const bool listed = !with_rewards && l.list;
+  dim3 grid(listed ? list_grid(e, l, 2048) : (unsigned)e->d.E), block(NTH);
+  const int32_t* ll = listed ? l.list : nullptr;
+  const uint32_t* ln = listed ? l.n : nullptr;
+  if (listed) mask = nullptr;
   MgxDev dd = e->d;
   if (PL)  // the interpreted sections are addressed relative to their LDS copy
     for (int k = MGX_SEC_INV_FEATURES; k < MGX_SEC_WORDLIST; k++) dd.sec[k] -= e->obs_blk_start;
   if (with_rewards)
-    hipLaunchKernelGGL((mgx_obs_kernel<true, X, PL, NTH, EW, K>), grid, block, e->lds_obs, e->stream, dd, e->pool_tokens, e->pool_prefix, mask, e->obs_blk_start, e->obs_blk_words, (e->rewards_early ? 1 : e->rewards_mid ? 2 : 0), (void*)nullptr, (const float*)nullptr, 0, 0);
+    hipLaunchKernelGGL((mgx_obs_kernel<true, X, PL, NTH, EW, K>), grid, block, e->lds_obs, e->stream, dd, e->pool_tokens, e->pool_prefix, mask, e->obs_blk_start, e->obs_blk_words, (e->rewards_early ? 1 : e->rewards_mid ? 2 : 0), (void*)nullptr, (const float*)nullptr, 0, 0, ll, ln, l.passes);
   else
-    hipLaunchKernelGGL((mgx_obs_kernel<false, X, PL, NTH, EW, K>), grid, block, e->lds_obs, e->stream, dd, e->pool_tokens, e->pool_prefix, mask, e->obs_blk_start, e->obs_blk_words, (e->rewards_early ? 1 : e->rewards_mid ? 2 : 0), (void*)nullptr, (const float*)nullptr, 0, 0);
+    hipLaunchKernelGGL((mgx_obs_kernel<false, X, PL, NTH, EW, K>), grid, block, e->lds_obs, e->stream, dd, e->pool_tokens, e->pool_prefix, mask, e->obs_blk_start, e->obs_blk_words, (e->rewards_early ? 1 : e->rewards_mid ? 2 : 0), (void*)nullptr, (const float*)nullptr, 0, 0, ll, ln, l.passes);
 }
 // Device-memory copy of e->d, brought up to date (stream-ordered) whenever the host table changed.
 static const MgxDev* dev_copy(mgx_engine* e) {
@@ -442,9 +470,9 @@ static int launch_terr(mgx_engine* e) {  // refresh the ownership maps of the en
   }
   return MGX_OK;
 }
-static int launch_obs(mgx_engine* e, bool with_rewards, const uint8_t* mask = nullptr) {
+static int launch_obs(mgx_engine* e, bool with_rewards, const uint8_t* mask = nullptr, const MgxList& l = MgxList()) {
 #ifdef MGX_CPU_EMU
-  (void)with_rewards; (void)mask;
+  (void)with_rewards; (void)mask; (void)l;
   return launch_terr(e);  // sanitizer build: the wavefront-cooperative observation kernel is not emulated
 #endif
   int trc = consume_out_fence(e);
@@ -463,20 +491,20 @@ static int launch_obs(mgx_engine* e, bool with_rewards, const uint8_t* mask = nu
       for (int k = MGX_SEC_INV_FEATURES; k < MGX_SEC_WORDLIST; k++) dd.sec[k] -= e->obs_blk_start;
     if (!mgx_launch_obs_box(e->stream, dd, e->lds_obs, e->pool_tokens, e->pool_prefix, mask, e->obs_blk_start, e->obs_blk_words,
                             (e->rewards_early ? 1 : e->rewards_mid ? 2 : 0), with_rewards, e->d.X != 0, pl, e->obs_threads, e->obs_ew, e->box_out, e->d_scale,
-                            e->box_C, e->box_dtype))
+                            e->box_C, e->box_dtype, with_rewards ? nullptr : l.list, l.n, (int)list_grid(e, l, 2048), l.passes))
       return fail(MGX_ERR_PROGRAM, "mgx_step: no dense-output instance of the observation kernel for this configuration");
     HIP_TRY(hipGetLastError());
     return MGX_OK;
   }
   // a program whose shape equals a preset's runs that preset's instance of the kernel (shape = compile-time constants)
-  if (e->obs_variant == 3) launch_obs_t<false, true, MGX_OBS_THREADS, MGX_OBS_THREADS / MGX_WAVE, MgxObsShapeR3>(e, with_rewards, mask);
-  else if (e->obs_variant == 5) launch_obs_t<false, true, MGX_OBS_THREADS, MGX_OBS_THREADS / MGX_WAVE, MgxObsShapeR3AnyLength>(e, with_rewards, mask);
-  else if (e->d.X && e->obs_threads == 512 && e->obs_ew == 4) launch_obs_t<true, false, 512, 4>(e, with_rewards, mask);
-  else if (e->d.X && e->obs_threads == 512 && e->obs_ew == 3) launch_obs_t<true, false, 512, 3>(e, with_rewards, mask);
-  else if (e->d.X && e->obs_threads == 512) launch_obs_t<true, false, 512, 2>(e, with_rewards, mask);
-  else if (e->d.X) launch_obs_t<true, false>(e, with_rewards, mask);
-  else if (e->obs_blk_lds) launch_obs_t<false, true>(e, with_rewards, mask);
-  else launch_obs_t<false, false>(e, with_rewards, mask);
+  if (e->obs_variant == 3) launch_obs_t<false, true, MGX_OBS_THREADS, MGX_OBS_THREADS / MGX_WAVE, MgxObsShapeR3>(e, with_rewards, mask, l);
+  else if (e->obs_variant == 5) launch_obs_t<false, true, MGX_OBS_THREADS, MGX_OBS_THREADS / MGX_WAVE, MgxObsShapeR3AnyLength>(e, with_rewards, mask, l);
+  else if (e->d.X && e->obs_threads == 512 && e->obs_ew == 4) launch_obs_t<true, false, 512, 4>(e, with_rewards, mask, l);
+  else if (e->d.X && e->obs_threads == 512 && e->obs_ew == 3) launch_obs_t<true, false, 512, 3>(e, with_rewards, mask, l);
+  else if (e->d.X && e->obs_threads == 512) launch_obs_t<true, false, 512, 2>(e, with_rewards, mask, l);
+  else if (e->d.X) launch_obs_t<true, false>(e, with_rewards, mask, l);
+  else if (e->obs_blk_lds) launch_obs_t<false, true>(e, with_rewards, mask, l);
+  else launch_obs_t<false, false>(e, with_rewards, mask, l);
   HIP_TRY(hipGetLastError());
   return MGX_OK;
 }
@@ -503,15 +531,48 @@ static int init_buffers(mgx_engine* e) {
   return MGX_OK;
 }
 
+static void free_episode_stats(mgx_engine* e) {
+  for (void* p : {(void*)e->d_ep_rec, (void*)e->d_ep_partial, (void*)e->d_ep_totals, (void*)e->d_ep_snap, (void*)e->d_ep_ticket,
+                  (void*)e->d_ep_log, (void*)e->d_ep_log_state})
+    if (p) (void)hipFree(p);
+  if (e->h_ep_snap) (void)hipHostFree(e->h_ep_snap);
+  if (e->ep_ev) (void)hipEventDestroy(e->ep_ev);
+  e->d_ep_rec = nullptr; e->d_ep_partial = nullptr; e->d_ep_totals = nullptr; e->d_ep_snap = nullptr; e->d_ep_ticket = nullptr;
+  e->d_ep_log = nullptr; e->d_ep_log_state = nullptr; e->h_ep_snap = nullptr; e->ep_ev = nullptr;
+  e->ep_stats = false; e->ep_pending = false; e->ep_log_cap = 0;
+}
+// Episode-end statistics of the envs in the done list (csrc/mgx_episode.h): records, then batch totals (+ log).
+static int launch_episode_stats(mgx_engine* e) {
+#ifndef MGX_CPU_EMU
+  const MgxDev& d = e->d;
+  hipLaunchKernelGGL(mgx_episode_record_kernel, dim3((unsigned)std::min(std::max(1, d.E / 4), 512)), dim3(256), 0, e->stream, dev_copy(e), e->ep,
+                     (const int32_t*)e->d_done_list, (const uint32_t*)e->d_done_n, e->d_ep_rec, e->d_ep_log, (const uint32_t*)e->d_ep_log_state,
+                     e->ep_log_cap, (const uint32_t*)e->d_early, (const uint32_t*)e->d_episodes, (const int32_t*)e->d_map_index,
+                     (const uint32_t*)e->dseeds);
+  HIP_TRY(hipGetLastError());
+  const int nchunks_max = (d.E + MGX_EP_CHUNK - 1) / MGX_EP_CHUNK;
+  hipLaunchKernelGGL(mgx_episode_accum_kernel, dim3((unsigned)std::min(nchunks_max, 64)), dim3(256), 0, e->stream, e->ep,
+                     (const uint32_t*)e->d_done_n, (const uint32_t*)e->d_ep_rec, e->d_ep_partial, e->d_ep_totals, e->d_ep_ticket,
+                     e->d_ep_log_state, e->ep_log_cap, e->d_ep_log ? 1 : 0);
+  HIP_TRY(hipGetLastError());
+#else
+  (void)e;
+#endif
+  return MGX_OK;
+}
+
 extern "C" {
 
 const char* mgx_last_error(void) { return g_err.c_str(); }
 
 // construction / episode restart: one wavefront per env on the GPU, the lane-per-env statement in the CPU sanitizer build
+// (dc, maps, map_index, seeds, mask, list): `list` is an MgxList; the sanitizer build only knows masks
 #ifdef MGX_CPU_EMU
-#define MGX_LAUNCH_INIT(stream, ...) hipLaunchKernelGGL(mgx_init_kernel, dim3((d.E + MGX_WAVE - 1) / MGX_WAVE), dim3(MGX_WAVE), 0, stream, __VA_ARGS__)
+#define MGX_LAUNCH_INIT(stream, dc, maps, mi, sd, mask, l) hipLaunchKernelGGL(mgx_init_kernel, dim3((d.E + MGX_WAVE - 1) / MGX_WAVE), dim3(MGX_WAVE), 0, stream, dc, maps, mi, sd, mask)
 #else
-#define MGX_LAUNCH_INIT(stream, ...) hipLaunchKernelGGL(mgx_init_wave_kernel, dim3(d.E), dim3(MGX_WAVE), 0, stream, __VA_ARGS__)
+#define MGX_LAUNCH_INIT(stream, dc, maps, mi, sd, mask, l)                                                                          \
+  hipLaunchKernelGGL(mgx_init_wave_kernel, dim3((l).list ? list_grid(e, (l), 4096) : (unsigned)d.E), dim3(MGX_WAVE), 0, stream, dc, maps, mi, sd, \
+                     (l).list ? (const uint8_t*)nullptr : (mask), (l).list, (l).n)
 #endif
 static std::mutex g_live_mu;
 static std::vector<mgx_engine*> g_live;  // engines between mgx_create and mgx_destroy
@@ -1125,7 +1186,7 @@ int mgx_create(const int32_t* program, size_t program_words, const uint16_t* cla
   e->dmaps = dmaps;
   e->dseeds = dseeds;
   MGX_LAUNCH_INIT(e->stream, dev_copy(e), (const uint16_t*)dmaps,
-                     (const int32_t*)nullptr, (const uint32_t*)dseeds, (const uint8_t*)nullptr);
+                     (const int32_t*)nullptr, (const uint32_t*)dseeds, (const uint8_t*)nullptr, MgxList());
   he = hipGetLastError();
   if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
   if (he != hipSuccess) { mgx_destroy(e); return fail(MGX_ERR_HIP, std::string("mgx_init_kernel: ") + hipGetErrorString(he)); }
@@ -1153,6 +1214,7 @@ void mgx_destroy(mgx_engine* e) {
   if (e->d_stage) (void)hipFree(e->d_stage);
   if (e->d_objs) (void)hipFree(e->d_objs);
   if (e->h_flags) (void)hipHostFree(e->h_flags);
+  free_episode_stats(e);
   for (int i = 0; i <= MGX_T_COUNT; i++) if (e->ev[i]) (void)hipEventDestroy(e->ev[i]);
   if (e->world_done) (void)hipEventDestroy(e->world_done);
   if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -1226,20 +1288,28 @@ static int stage(mgx_engine* e, size_t bytes) {
 }
 // Restart the envs of a DEVICE mask: clear their state rows, rebuild them (construction kernel), initial observations.
 // from_pool: maps come from the pool through d_map_index; bump: auto-reset bookkeeping (episode counter, next pool map).
-static int restart_masked(mgx_engine* e, const uint8_t* dmask, bool from_pool, bool bump) {
+// l: the same envs as an ascending device list (the kernels then walk the list with a small grid instead of testing E mask bytes).
+static int restart_masked(mgx_engine* e, const uint8_t* dmask, bool from_pool, bool bump, const MgxList& l = MgxList()) {
   const MgxDev& d = e->d;
   int rc = consume_out_fence(e);   // the cleared rows include terminals / truncations / rewards
   if (rc) return rc;
   rc = upload_rows(e);
   if (rc) return rc;
-  hipLaunchKernelGGL(mgx_clear_rows_kernel, dim3((unsigned)d.E), dim3(256), 0, e->stream, (const MgxRow*)e->d_rows, e->n_rows, dmask, d.E,
-                     bump ? e->d_episodes : (uint32_t*)nullptr, bump ? e->d_map_index : (int32_t*)nullptr, e->n_pool, e->pool_stride);
+#ifdef MGX_CPU_EMU
+  MgxList ll;   // the sanitizer build runs the mask forms
+#else
+  MgxList ll = l;
+#endif
+  ll.passes = 2;   // new MettaGrid + set_buffers = two initial observation passes in the reference (token statistics)
+  hipLaunchKernelGGL(mgx_clear_rows_kernel, dim3(ll.list ? list_grid(e, ll, 1024) : (unsigned)d.E), dim3(256), 0, e->stream, (const MgxRow*)e->d_rows,
+                     e->n_rows, dmask, d.E, bump ? e->d_episodes : (uint32_t*)nullptr, bump ? e->d_map_index : (int32_t*)nullptr, e->n_pool,
+                     e->pool_stride, ll.list, ll.n);
   HIP_TRY(hipGetLastError());
   MGX_LAUNCH_INIT(e->stream, dev_copy(e),
                      (const uint16_t*)(from_pool ? e->d_pool : e->dmaps), (const int32_t*)(from_pool ? e->d_map_index : nullptr),
-                     (const uint32_t*)e->dseeds, dmask);
+                     (const uint32_t*)e->dseeds, dmask, ll);
   HIP_TRY(hipGetLastError());
-  return launch_obs(e, false, dmask);
+  return launch_obs(e, false, dmask, ll);
 }
 // Class ids of maps handed over by the caller: 0 = empty, else class index + 1.
 static int validate_maps(const mgx_engine* e, const uint16_t* maps, size_t n_maps, const uint8_t* mask, const char* who) {
@@ -1313,9 +1383,11 @@ int mgx_reset_envs(mgx_engine* e, const uint8_t* env_mask, const uint16_t* class
   }
   // ONE contiguous upload: [indices | packed seeds | packed maps] of the masked envs, scattered on the device
   const size_t off_seeds = n * 4, off_maps = (off_seeds + (seeds ? n * 4 : 0) + 15) & ~(size_t)15;
-  const size_t total = off_maps + (class_maps ? n * HW * 2 : 0);
+  const size_t off_n = (off_maps + (class_maps ? n * HW * 2 : 0) + 15) & ~(size_t)15;   // the list length, for the list-walking kernels
+  const size_t total = off_n + 16;
   std::vector<uint8_t> host(total);
   memcpy(host.data(), idx.data(), n * 4);
+  { const uint32_t n32 = (uint32_t)n; memcpy(host.data() + off_n, &n32, 4); }
   for (size_t k = 0; k < n; k++) {
     if (seeds) memcpy(host.data() + off_seeds + k * 4, seeds + idx[k], 4);
     if (class_maps) memcpy(host.data() + off_maps + k * HW * 2, class_maps + (size_t)idx[k] * HW, HW * 2);
@@ -1330,7 +1402,9 @@ int mgx_reset_envs(mgx_engine* e, const uint8_t* env_mask, const uint16_t* class
   if (class_maps) hipLaunchKernelGGL(mgx_scatter_maps_kernel, dim3(4, (unsigned)n), dim3(256), 0, e->stream, e->dmaps,
                                      (const uint16_t*)(st + off_maps), (const int32_t*)st, (int)n, (int)HW);
   HIP_TRY(hipGetLastError());
-  rc = restart_masked(e, e->dmask, false, false);
+  MgxList l;
+  l.list = (const int32_t*)st; l.n = (const uint32_t*)(st + off_n); l.n_host = (int)n;
+  rc = restart_masked(e, e->dmask, false, false, l);
   if (rc) return rc;
   if (e->mem_kind == MGX_MEM_HOST) {  // host buffers: the restarted rows, one copy per contiguous run of envs
     for (size_t k = 0; k < n;) {
@@ -1385,8 +1459,9 @@ int mgx_reset_envs_from_pool(mgx_engine* e, const uint8_t* env_mask, const int32
   }
   if (idx.empty()) return MGX_OK;
   const size_t n = idx.size();
-  std::vector<uint8_t> host(n * 12);
+  std::vector<uint8_t> host(n * 12 + 16);
   memcpy(host.data(), idx.data(), n * 4);
+  { const uint32_t n32 = (uint32_t)n; memcpy(host.data() + n * 12, &n32, 4); }
   for (size_t k = 0; k < n; k++) {
     memcpy(host.data() + n * 4 + k * 4, pool_index + idx[k], 4);
     if (seeds) memcpy(host.data() + n * 8 + k * 4, seeds + idx[k], 4);
@@ -1400,7 +1475,9 @@ int mgx_reset_envs_from_pool(mgx_engine* e, const uint8_t* env_mask, const int32
   hipLaunchKernelGGL(mgx_scatter_words_kernel, g, b, 0, e->stream, (uint32_t*)e->d_map_index, (const uint32_t*)(st + n * 4), (const int32_t*)st, (int)n);
   if (seeds) hipLaunchKernelGGL(mgx_scatter_words_kernel, g, b, 0, e->stream, e->dseeds, (const uint32_t*)(st + n * 8), (const int32_t*)st, (int)n);
   HIP_TRY(hipGetLastError());
-  rc = restart_masked(e, e->dmask, true, false);
+  MgxList l;
+  l.list = (const int32_t*)st; l.n = (const uint32_t*)(st + n * 12); l.n_host = (int)n;
+  rc = restart_masked(e, e->dmask, true, false, l);
   if (rc) return rc;
   if (e->mem_kind == MGX_MEM_HOST) {
     const size_t rows = E * d.A;
@@ -1421,8 +1498,10 @@ int mgx_set_auto_reset(mgx_engine* e, int32_t enabled, int32_t pool_stride, cons
   const MgxDev& d = e->d;
   int rc = MGX_OK;
   if (!e->d_next_mask) {
-    rc = e->alloc(&e->d_next_mask, (size_t)d.E);
+    rc = e->alloc(&e->d_next_mask, ((size_t)d.E + 3) & ~(size_t)3);
     if (!rc) rc = e->alloc(&e->d_counters, 2);
+    if (!rc && !e->d_done_list) rc = e->alloc(&e->d_done_list, (size_t)d.E);
+    if (!rc && !e->d_done_n) rc = e->alloc(&e->d_done_n, 4);
     if (rc) return rc;
     HIP_TRY(hipHostMalloc((void**)&e->h_flags, 8, hipHostMallocMapped));
     e->h_flags[0] = 0xFFFFFFFFu; e->h_flags[1] = 0;
@@ -1435,6 +1514,7 @@ int mgx_set_auto_reset(mgx_engine* e, int32_t enabled, int32_t pool_stride, cons
     HIP_TRY(hipMemsetAsync(e->d_early, 0, (size_t)d.E * 4, e->stream));
   }
   HIP_TRY(hipMemsetAsync(e->d_next_mask, 0, (size_t)d.E, e->stream));
+  HIP_TRY(hipMemsetAsync(e->d_done_n, 0, 4, e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));
   e->pool_stride = pool_stride > 0 ? pool_stride : 1;
   e->auto_reset = true;
@@ -1449,6 +1529,124 @@ int mgx_get_episodes(mgx_engine* e, uint32_t* episodes, int32_t* map_index) {
   if (episodes) HIP_TRY(hipMemcpyAsync(episodes, e->d_episodes, (size_t)e->d.E * 4, hipMemcpyDeviceToHost, e->stream));
   if (map_index) HIP_TRY(hipMemcpyAsync(map_index, e->d_map_index, (size_t)e->d.E * 4, hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));
+  return MGX_OK;
+}
+
+int mgx_set_episode_stats(mgx_engine* e, int32_t enabled, int32_t log_capacity, int32_t log_per_agent) {
+  if (!e) return fail(MGX_ERR_BAD_ARG, "mgx_set_episode_stats: null engine");
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  free_episode_stats(e);
+  if (!enabled) return MGX_OK;
+#ifdef MGX_CPU_EMU
+  return fail(MGX_ERR_BAD_ARG, "mgx_set_episode_stats: not part of the sanitizer build");
+#else
+  static_assert(MGX_EPT_HEADER == MGX_EP_TOT_HDR, "totals header");
+  if (log_capacity < 0) return fail(MGX_ERR_BAD_ARG, "mgx_set_episode_stats: negative log capacity");
+  const MgxDev& d = e->d;
+  e->ep = mgx_ep_layout(d.NG, d.NS, d.A, d.NSP, log_per_agent ? 1 : 0);
+  const size_t TW = (size_t)e->ep_tw(), nch = ((size_t)d.E + MGX_EP_CHUNK - 1) / MGX_EP_CHUNK;
+  HIP_TRY(hipMalloc((void**)&e->d_ep_rec, (size_t)d.E * e->ep.rec_words * 4));
+  HIP_TRY(hipMalloc((void**)&e->d_ep_partial, nch * TW * 8));
+  HIP_TRY(hipMalloc((void**)&e->d_ep_totals, TW * 8));
+  HIP_TRY(hipMalloc((void**)&e->d_ep_snap, TW * 8));
+  HIP_TRY(hipMalloc((void**)&e->d_ep_ticket, 4));
+  HIP_TRY(hipMalloc((void**)&e->d_ep_log_state, 8));
+  HIP_TRY(hipHostMalloc((void**)&e->h_ep_snap, TW * 8, hipHostMallocDefault));
+  HIP_TRY(hipEventCreateWithFlags(&e->ep_ev, hipEventDisableTiming));
+  HIP_TRY(hipMemsetAsync(e->d_ep_ticket, 0, 4, e->stream));
+  HIP_TRY(hipMemsetAsync(e->d_ep_log_state, 0, 8, e->stream));
+  if (log_capacity > 0) {
+    HIP_TRY(hipMalloc((void**)&e->d_ep_log, (size_t)log_capacity * e->ep.log_words * 4));
+    e->ep_log_cap = log_capacity;
+  }
+  if (!e->d_done_list) { int rc = e->alloc(&e->d_done_list, (size_t)d.E); if (rc) return rc; }
+  if (!e->d_done_n) { int rc = e->alloc(&e->d_done_n, 4); if (rc) return rc; }
+  // totals start as a cleared snapshot would leave them
+  hipLaunchKernelGGL(mgx_episode_snapshot_kernel, dim3(1), dim3(256), 0, e->stream, e->d_ep_totals, e->d_ep_snap, (int)TW);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  e->ep_stats = true;
+  return MGX_OK;
+#endif
+}
+
+int mgx_episode_stats_layout(mgx_engine* e, int32_t* out) {
+  if (!e || !out) return fail(MGX_ERR_BAD_ARG, "mgx_episode_stats_layout: null argument");
+  if (!e->ep_stats) return fail(MGX_ERR_BAD_ARG, "mgx_episode_stats_layout: episode statistics are off (mgx_set_episode_stats)");
+  const MgxEpLayout& L = e->ep;
+  const int32_t v[MGX_EPL_COUNT] = {L.NG, L.NS, L.A, e->ep_tw(), L.rec_words, L.log_words, L.off_game, L.off_gbits, L.off_agent, L.off_abits,
+                                    L.off_rew, L.off_pa, L.off_pabits, L.off_invk, L.off_invn, L.per_agent, e->ep_log_cap};
+  memcpy(out, v, sizeof(v));
+  return MGX_OK;
+}
+
+int mgx_record_episodes(mgx_engine* e, const uint8_t* env_mask) {
+  if (!e || !env_mask) return fail(MGX_ERR_BAD_ARG, "mgx_record_episodes: null argument");
+  if (!e->ep_stats) return fail(MGX_ERR_BAD_ARG, "mgx_record_episodes: episode statistics are off (mgx_set_episode_stats)");
+  if (e->auto_reset) return fail(MGX_ERR_BAD_ARG, "mgx_record_episodes: the engine is in auto-reset mode and records finished envs itself");
+  HIP_TRY(hipSetDevice(e->device));
+  std::vector<int32_t> idx;
+  for (int i = 0; i < e->d.E; i++) if (env_mask[i]) idx.push_back(i);
+  if (idx.empty()) return MGX_OK;
+  const uint32_t n = (uint32_t)idx.size();
+  HIP_TRY(hipMemcpyAsync(e->d_done_list, idx.data(), (size_t)n * 4, hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(hipMemcpyAsync(e->d_done_n, &n, 4, hipMemcpyHostToDevice, e->stream));
+  int rc = launch_episode_stats(e);
+  if (rc) return rc;
+  HIP_TRY(hipMemsetAsync(e->d_done_n, 0, 4, e->stream));   // the list belongs to this call only
+  HIP_TRY(hipStreamSynchronize(e->stream));  // `idx` and `n` are locals
+  return MGX_OK;
+}
+
+int mgx_request_episode_stats(mgx_engine* e) {
+  if (!e) return fail(MGX_ERR_BAD_ARG, "mgx_request_episode_stats: null engine");
+  if (!e->ep_stats) return fail(MGX_ERR_BAD_ARG, "mgx_request_episode_stats: episode statistics are off (mgx_set_episode_stats)");
+  if (e->ep_pending) return MGX_OK;   // the snapshot already under way is fetched first; the totals keep accumulating
+#ifndef MGX_CPU_EMU
+  HIP_TRY(hipSetDevice(e->device));
+  const int TW = e->ep_tw();
+  hipLaunchKernelGGL(mgx_episode_snapshot_kernel, dim3(1), dim3(256), 0, e->stream, e->d_ep_totals, e->d_ep_snap, TW);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(e->h_ep_snap, e->d_ep_snap, (size_t)TW * 8, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipEventRecord(e->ep_ev, e->stream));
+  e->ep_pending = true;
+#endif
+  return MGX_OK;
+}
+
+int mgx_fetch_episode_stats(mgx_engine* e, int32_t wait, double* totals, int32_t* ready) {
+  if (!e || !totals || !ready) return fail(MGX_ERR_BAD_ARG, "mgx_fetch_episode_stats: null argument");
+  *ready = 0;
+  if (!e->ep_stats) return fail(MGX_ERR_BAD_ARG, "mgx_fetch_episode_stats: episode statistics are off (mgx_set_episode_stats)");
+  if (!e->ep_pending) return MGX_OK;
+  HIP_TRY(hipSetDevice(e->device));
+  if (wait) {
+    HIP_TRY(hipEventSynchronize(e->ep_ev));
+  } else {
+    const hipError_t q = hipEventQuery(e->ep_ev);
+    if (q == hipErrorNotReady) return MGX_OK;
+    if (q != hipSuccess) return fail(MGX_ERR_HIP, std::string("hipEventQuery: ") + hipGetErrorString(q));
+  }
+  memcpy(totals, e->h_ep_snap, (size_t)e->ep_tw() * 8);
+  e->ep_pending = false;
+  *ready = 1;
+  return MGX_OK;
+}
+
+int mgx_drain_episode_log(mgx_engine* e, uint32_t* records, int32_t max_records, int32_t* n_records, int32_t* n_dropped) {
+  if (!e || !records || !n_records) return fail(MGX_ERR_BAD_ARG, "mgx_drain_episode_log: null argument");
+  if (!e->ep_stats || !e->d_ep_log) return fail(MGX_ERR_BAD_ARG, "mgx_drain_episode_log: no episode log (mgx_set_episode_stats)");
+  if (max_records < e->ep_log_cap) return fail(MGX_ERR_BAD_ARG, "mgx_drain_episode_log: the buffer must hold the whole log (log_capacity records)");
+  HIP_TRY(hipSetDevice(e->device));
+  uint32_t st[2] = {0, 0};
+  HIP_TRY(hipMemcpyAsync(st, e->d_ep_log_state, 8, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  if (st[0]) HIP_TRY(hipMemcpyAsync(records, e->d_ep_log, (size_t)st[0] * e->ep.log_words * 4, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipMemsetAsync(e->d_ep_log_state, 0, 8, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  *n_records = (int32_t)st[0];
+  if (n_dropped) *n_dropped = (int32_t)st[1];
   return MGX_OK;
 }
 
@@ -1467,7 +1665,9 @@ int mgx_step(mgx_engine* e) {
     // already synchronised with it and nothing was done, the restart launches are skipped altogether.
     const bool known_none = e->h_flags[0] == e->step_seq && e->h_flags[1] == 0;
     if (!known_none) {
-      int rrc = restart_masked(e, e->d_next_mask, true, true);
+      MgxList l;
+      l.list = e->d_done_list; l.n = e->d_done_n;
+      int rrc = restart_masked(e, e->d_next_mask, true, true, l);
       if (rrc) return rrc;
     }
   }
@@ -1534,8 +1734,9 @@ int mgx_step(mgx_engine* e) {
 #endif
     hipLaunchKernelGGL(mgx_episode_end_kernel, dim3((d.E + bt - 1) / bt), dim3(bt), 0, e->stream, dev_copy(e), (const uint32_t*)e->d_early,
                        (const uint32_t*)e->d_episodes, e->d_next_mask, e->d_counters, (volatile uint32_t*)e->h_flags_dev, e->step_seq,
-                       e->d_counters + 1);
+                       e->d_counters + 1, e->d_done_list, e->d_done_n);
     HIP_TRY(hipGetLastError());
+    if (e->ep_stats) { int erc = launch_episode_stats(e); if (erc) return erc; }
   }
   if (e->mem_kind == MGX_MEM_HOST) {
     HIP_TRY(hipMemcpyAsync(e->h_obs, d.obs, rows * d.T * 3, hipMemcpyDeviceToHost, e->stream));

@@ -250,13 +250,34 @@ inline bool mgx_obs_shape_matches(const MgxDev& d, int blk_words, int rewards_ea
 // value / scale[feature] added into cell (feature, y, x) in token order, global tokens on the centre cell) as float32
 // (box_dtype MGX_BOX_F32) or bfloat16 (MGX_BOX_BF16: the float32 sum rounded to nearest even once) — written straight from
 // the LDS staging row; the token buffer is neither written nor read back.
+// Which envs: all of them (one workgroup per env, grid = E) — the step; the masked ones (env_mask) or, WITHOUT rewards only,
+// the entries of a device list of unknown length walked by a small fixed grid (env_list / env_list_n) — the initial
+// observations of restarted envs.
+template <bool WITH_REWARDS, bool X, bool PL, int NTH, int EW, class K, bool BOX>
+static __device__ __forceinline__ void mgx_obs_env(const MgxDev& d, const int env, uint8_t* smem, int pool_tokens, int pool_prefix,
+                                                   const uint8_t* env_mask, int blk_start, int blk_words_arg, int rewards_early_arg,
+                                                   void* box_out, const float* box_scale, int box_C, int box_dtype, int stat_passes);
 template <bool WITH_REWARDS, bool X, bool PL, int NTH = MGX_OBS_THREADS, int EW = NTH / MGX_WAVE, class K = MgxObsShapeDyn, bool BOX = false>
 __global__ void __launch_bounds__(NTH) mgx_obs_kernel(MgxDev d, int pool_tokens, int pool_prefix, const uint8_t* env_mask,
                                                                   int blk_start, int blk_words_arg, int rewards_early_arg,
-                                                                  void* box_out, const float* box_scale, int box_C, int box_dtype) {
+                                                                  void* box_out, const float* box_scale, int box_C, int box_dtype,
+                                                                  const int32_t* env_list, const uint32_t* env_list_n, int stat_passes) {
   MGX_KERNARG_ENTRY(d);
   extern __shared__ __align__(16) uint8_t smem[];
-  const int env = blockIdx.x;
+  const bool listed = !WITH_REWARDS && env_list != nullptr;   // (constant false in the instances the step launches)
+  const int n_listed = listed ? (int)*env_list_n : 0;
+  for (int k = blockIdx.x;; k += gridDim.x) {
+    if (listed && k >= n_listed) break;
+    mgx_obs_env<WITH_REWARDS, X, PL, NTH, EW, K, BOX>(d, listed ? env_list[k] : (int)blockIdx.x, smem, pool_tokens, pool_prefix, env_mask, blk_start,
+                                                      blk_words_arg, rewards_early_arg, box_out, box_scale, box_C, box_dtype, stat_passes);
+    if (!listed) break;
+    __syncthreads();   // the next env's staging overwrites this one's LDS
+  }
+}
+template <bool WITH_REWARDS, bool X, bool PL, int NTH, int EW, class K, bool BOX>
+static __device__ __forceinline__ void mgx_obs_env(const MgxDev& d, const int env, uint8_t* smem, int pool_tokens, int pool_prefix,
+                                                   const uint8_t* env_mask, int blk_start, int blk_words_arg, int rewards_early_arg,
+                                                   void* box_out, const float* box_scale, int box_C, int box_dtype, int stat_passes) {
   if (env_mask && !env_mask[env]) return;  // episode restart: only the restarted envs get initial observations
   const int tid = threadIdx.x, lane = tid & (MGX_WAVE - 1);
   const int wave = __builtin_amdgcn_readfirstlane(tid / MGX_WAVE);  // wave-uniform: per-agent values and branches go scalar
@@ -927,20 +948,25 @@ __global__ void __launch_bounds__(NTH) mgx_obs_kernel(MgxDev d, int pool_tokens,
     const bool over = __ballot(lane < A && nw > T) != 0;
     const uint32_t sum_w = mgx_wave_sum((uint32_t)nw);
     if (lane == 0) {
+      // passes: an episode restart stands for the reference's new MettaGrid + set_buffers, which computes the initial
+      // observations TWICE (ctor -> _make_buffers -> set_buffers, then the caller's set_buffers: mettagrid_c.cpp:190, 271-292,
+      // 1165-1184) and so counts their tokens twice; a step counts once.
+      const uint32_t passes = WITH_REWARDS ? 1u : (uint32_t)stat_passes;
       const uint32_t sum_f = (uint32_t)A * (uint32_t)T - sum_w;
       const bool exact = A <= MGX_WAVE && !over && tw == truncf(tw) && tf == truncf(tf) && tw >= 0.f && tf >= 0.f &&
-                         tw + (float)sum_w <= 16777216.f && tf + (float)sum_f <= 16777216.f;
+                         tw + (float)(sum_w * passes) <= 16777216.f && tf + (float)(sum_f * passes) <= 16777216.f;
       bool overflow = false;
       if (exact) {
-        tw += (float)sum_w;
-        tf += (float)sum_f;
+        tw += (float)(sum_w * passes);
+        tf += (float)(sum_f * passes);
       } else {
-        for (int a = 0; a < A && !overflow; a++) {
-          int n = s_written[a];
-          if (n > T) { overflow = true; break; }  // reference: std::runtime_error (:813-819)
-          tw = __fadd_rn(tw, (float)n);
-          tf = __fadd_rn(tf, (float)(T - n));
-        }
+        for (uint32_t p = 0; p < passes && !overflow; p++)
+          for (int a = 0; a < A && !overflow; a++) {
+            int n = s_written[a];
+            if (n > T) { overflow = true; break; }  // reference: std::runtime_error (:813-819)
+            tw = __fadd_rn(tw, (float)n);
+            tf = __fadd_rn(tf, (float)(T - n));
+          }
       }
       gs[d.wk[MGX_S_GAME_TOKENS_WRITTEN]] = tw;
       gs[d.wk[MGX_S_GAME_TOKENS_FREE]] = tf;

@@ -12,22 +12,23 @@
 
 template <bool X, bool PL, int NTH, int EW>
 static void launch_box(hipStream_t stream, const MgxDev& dd, size_t lds, int pool_tokens, int pool_prefix, const uint8_t* mask, int blk_start,
-                       int blk_words, int rewards_early, bool with_rewards, void* box, const float* scale, int C, int dtype) {
-  dim3 grid(dd.E), block(NTH);
+                       int blk_words, int rewards_early, bool with_rewards, void* box, const float* scale, int C, int dtype, const int32_t* env_list,
+                       const uint32_t* env_list_n, int list_grid, int stat_passes) {
+  dim3 grid(env_list && !with_rewards ? list_grid : dd.E), block(NTH);
   if (with_rewards)
     hipLaunchKernelGGL((mgx_obs_kernel<true, X, PL, NTH, EW, MgxObsShapeDyn, true>), grid, block, lds, stream, dd, pool_tokens, pool_prefix, mask,
-                       blk_start, blk_words, rewards_early, box, scale, C, dtype);
+                       blk_start, blk_words, rewards_early, box, scale, C, dtype, env_list, env_list_n, stat_passes);
   else
     hipLaunchKernelGGL((mgx_obs_kernel<false, X, PL, NTH, EW, MgxObsShapeDyn, true>), grid, block, lds, stream, dd, pool_tokens, pool_prefix, mask,
-                       blk_start, blk_words, rewards_early, box, scale, C, dtype);
+                       blk_start, blk_words, rewards_early, box, scale, C, dtype, env_list, env_list_n, stat_passes);
 }
 
 // The variant the token path would launch for the same engine (mgx_engine.hip launch_obs): lean with / without the program
 // block in LDS, extended with 256 threads or 512 threads and 4 / 3 / 2 encode wavefronts.
 bool mgx_launch_obs_box(hipStream_t stream, const MgxDev& dd, size_t lds, int pool_tokens, int pool_prefix, const uint8_t* mask, int blk_start,
                         int blk_words, int rewards_early, bool with_rewards, bool X, bool PL, int threads, int ew, void* box, const float* scale,
-                        int C, int dtype) {
-#define MGX_BOX_ARGS stream, dd, lds, pool_tokens, pool_prefix, mask, blk_start, blk_words, rewards_early, with_rewards, box, scale, C, dtype
+                        int C, int dtype, const int32_t* env_list, const uint32_t* env_list_n, int list_grid, int stat_passes) {
+#define MGX_BOX_ARGS stream, dd, lds, pool_tokens, pool_prefix, mask, blk_start, blk_words, rewards_early, with_rewards, box, scale, C, dtype, env_list, env_list_n, list_grid, stat_passes
   if (!X && PL) launch_box<false, true, MGX_OBS_THREADS, MGX_OBS_THREADS / MGX_WAVE>(MGX_BOX_ARGS);
   else if (!X) launch_box<false, false, MGX_OBS_THREADS, MGX_OBS_THREADS / MGX_WAVE>(MGX_BOX_ARGS);
   else if (threads == 512 && ew == 4) launch_box<true, false, 512, 4>(MGX_BOX_ARGS);

@@ -2407,13 +2407,31 @@ __global__ void __launch_bounds__(MGX_WAVE) mgx_init_kernel(const MgxDev* __rest
 // each lane initialises its own object.  What is order dependent — the registration lists of the extended variant
 // (tag index, AoE sources, territory sources, in object order) and the materialized queries — is done by lane 0 afterwards
 // over the objects, not the cells.  Object counts per class are whole numbers: atomic float adds are exact in any order.
+// The envs to build are all (env_mask == env_list == nullptr: grid = E), the masked ones (grid = E), or — episode restarts —
+// the entries of a device LIST whose length the host need not know: a small fixed grid walks it (`*env_list_n` entries).
+static __device__ void mgx_init_wave_env(const MgxDev& d, const int env, const int lane, const uint16_t* class_maps,
+                                         const int32_t* map_index, const uint32_t* seeds);
 __global__ void __launch_bounds__(MGX_WAVE) mgx_init_wave_kernel(const MgxDev* __restrict__ dp, const uint16_t* class_maps,
                                                                  const int32_t* map_index, const uint32_t* seeds,
-                                                                 const uint8_t* env_mask) {
+                                                                 const uint8_t* env_mask, const int32_t* env_list,
+                                                                 const uint32_t* env_list_n) {
   const MgxDev& d = *dp;
-  const int env = blockIdx.x, lane = threadIdx.x;
+  const int lane = threadIdx.x;
+  if (env_list) {
+    const int n = (int)*env_list_n;
+    for (int k = blockIdx.x; k < n; k += gridDim.x) {
+      mgx_init_wave_env(d, env_list[k], lane, class_maps, map_index, seeds);
+      __builtin_amdgcn_wave_barrier();
+    }
+    return;
+  }
+  const int env = blockIdx.x;
   if (env >= d.E) return;
   if (env_mask && !env_mask[env]) return;
+  mgx_init_wave_env(d, env, lane, class_maps, map_index, seeds);
+}
+static __device__ void mgx_init_wave_env(const MgxDev& d, const int env, const int lane, const uint16_t* class_maps,
+                                         const int32_t* map_index, const uint32_t* seeds) {
   MgxEnvX e(d, d.P, env);
   const size_t E = (size_t)d.E;
   if (lane == 0) {
@@ -2556,11 +2574,23 @@ struct MgxRow { uint8_t* base; unsigned long long row_bytes; int fill; int pad; 
 // One workgroup per env: for a masked env, fill its row of every state array in the table (what a fresh construction
 // would find there) and — auto-reset mode — start its next episode: bump the episode counter and pick the next map of
 // the pool, (env + episode * stride) mod pool size.
+// Envs: the masked ones (grid = E) or the entries of a device list walked by a small fixed grid (see mgx_init_wave_kernel).
+static __device__ void mgx_clear_rows_env(const MgxRow* rows, int n_rows, int env, uint32_t* episodes, int32_t* map_index,
+                                          int pool_size, int pool_stride);
 __global__ void __launch_bounds__(256) mgx_clear_rows_kernel(const MgxRow* rows, int n_rows, const uint8_t* env_mask, int E,
                                                              uint32_t* episodes, int32_t* map_index, int pool_size,
-                                                             int pool_stride) {
+                                                             int pool_stride, const int32_t* env_list, const uint32_t* env_list_n) {
+  if (env_list) {
+    const int n = (int)*env_list_n;
+    for (int k = blockIdx.x; k < n; k += gridDim.x) mgx_clear_rows_env(rows, n_rows, env_list[k], episodes, map_index, pool_size, pool_stride);
+    return;
+  }
   const int env = blockIdx.x;
   if (env >= E || !env_mask[env]) return;
+  mgx_clear_rows_env(rows, n_rows, env, episodes, map_index, pool_size, pool_stride);
+}
+static __device__ void mgx_clear_rows_env(const MgxRow* rows, int n_rows, int env, uint32_t* episodes, int32_t* map_index,
+                                          int pool_size, int pool_stride) {
   for (int k = 0; k < n_rows; k++) {
     uint8_t* row = rows[k].base + (size_t)env * rows[k].row_bytes;
     const size_t n = (size_t)rows[k].row_bytes;
@@ -2601,32 +2631,78 @@ __global__ void mgx_scatter_words_kernel(uint32_t* dst, const uint32_t* packed, 
 __global__ void __launch_bounds__(256) mgx_episode_end_kernel(const MgxDev* __restrict__ dp, const uint32_t* early_steps,
                                                               const uint32_t* episodes, uint8_t* next_mask,
                                                               uint32_t* done_count, volatile uint32_t* host_flags, uint32_t seq,
-                                                              uint32_t* blocks_done) {
+                                                              uint32_t* blocks_done, int32_t* done_list, uint32_t* done_n) {
   const MgxDev& d = *dp;
   const int env = blockIdx.x * blockDim.x + threadIdx.x;
   if (env < d.E) {
     const size_t r0 = (size_t)env * d.A;
-    if (early_steps && episodes[env] == 0 && early_steps[env] > 0 && d.step[env] >= early_steps[env])
-      for (int a = 0; a < d.A; a++) d.truncations[r0 + a] = 1;
+    const bool early = early_steps && episodes[env] == 0 && early_steps[env] > 0 && d.step[env] >= early_steps[env];
     bool all_term = true, all_trunc = true;
-    for (int a = 0; a < d.A; a++) { all_term = all_term && d.terminals[r0 + a]; all_trunc = all_trunc && d.truncations[r0 + a]; }
+    if ((d.A & 3) == 0 && ((((uintptr_t)d.truncations) | ((uintptr_t)d.terminals)) & 3) == 0) {   // rows of A flag bytes as 32-bit words
+      uint32_t* tr = (uint32_t*)(d.truncations + r0);
+      const uint32_t* te = (const uint32_t*)(d.terminals + r0);
+      for (int a = 0; a < d.A / 4; a++) {
+        if (early) tr[a] = 0x01010101u;
+        const uint32_t t = te[a], u = early ? 0x01010101u : tr[a];
+        all_term = all_term && (t & 0xFF) && (t & 0xFF00) && (t & 0xFF0000) && (t & 0xFF000000u);
+        all_trunc = all_trunc && (u & 0xFF) && (u & 0xFF00) && (u & 0xFF0000) && (u & 0xFF000000u);
+      }
+    } else {
+      if (early) for (int a = 0; a < d.A; a++) d.truncations[r0 + a] = 1;
+      for (int a = 0; a < d.A; a++) { all_term = all_term && d.terminals[r0 + a]; all_trunc = all_trunc && d.truncations[r0 + a]; }
+    }
     const bool done = all_term || all_trunc;
     next_mask[env] = done ? 1 : 0;
     if (done) atomicAdd(done_count, 1u);
   }
   __threadfence();
   __syncthreads();
+  __shared__ uint32_t s_last, s_wsum[4];
   if (threadIdx.x == 0) {
     const uint32_t ticket = atomicAdd(blocks_done, 1u);
-    if (ticket == gridDim.x - 1) {  // the last workgroup publishes the totals
+    s_last = ticket == gridDim.x - 1 ? 1u : 0u;
+    if (s_last) {  // the last workgroup publishes the totals
       __threadfence();
-      host_flags[1] = atomicAdd(done_count, 0u);
+      const uint32_t n = atomicAdd(done_count, 0u);
+      host_flags[1] = n;
       __threadfence_system();
       host_flags[0] = seq;
       *done_count = 0;
       *blocks_done = 0;
+      if (done_n) *done_n = n;
     }
   }
+  __syncthreads();
+  // ... and lists the done envs in ascending order (what the restart kernels and the episode-statistics kernels walk:
+  // a few dozen entries per step instead of a mask of E bytes tested by E workgroups).
+  if (!s_last || !done_list) return;
+#ifdef MGX_CPU_EMU
+  {
+    int n = 0;
+    for (int k = 0; k < d.E; k++) if (next_mask[k]) done_list[n++] = k;
+  }
+#else
+  const int tid = threadIdx.x, lane = tid & (MGX_WAVE - 1), wave = tid / MGX_WAVE;
+  uint32_t base = 0;
+  for (int e0 = 0; e0 < d.E; e0 += 256 * 4) {   // four envs (one word of the mask) per thread and pass
+    const int first = e0 + tid * 4;
+    uint32_t w = 0;
+    if (first < d.E)   // written by other workgroups of this launch: read at the coherence point, not from this CU's L1
+      w = __hip_atomic_load((const uint32_t*)(next_mask + first), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t bits = 0;
+    for (int q = 0; q < 4; q++) bits |= (first + q < d.E && ((w >> (8 * q)) & 0xFF)) ? 1u << q : 0u;
+    const uint32_t cnt = __popc(bits);
+    uint32_t incl = cnt;
+    for (int o = 1; o < MGX_WAVE; o <<= 1) { const uint32_t v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+    if (lane == MGX_WAVE - 1) s_wsum[wave] = incl;
+    __syncthreads();
+    uint32_t off = base + incl - cnt;
+    for (int q = 0; q < wave; q++) off += s_wsum[q];
+    for (int q = 0; q < 4; q++) if (bits & (1u << q)) done_list[off++] = first + q;
+    base += s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+    __syncthreads();
+  }
+#endif
 }
 
 #endif  // !MGX_WORLD_FAST_TU

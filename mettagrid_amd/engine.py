@@ -79,6 +79,12 @@ def load_lib():
     L.mgx_reset_envs_from_pool.argtypes = [vp, vp, vp, vp]
     L.mgx_set_auto_reset.argtypes = [vp, i32, i32, vp]
     L.mgx_get_episodes.argtypes = [vp, vp, vp]
+    L.mgx_set_episode_stats.argtypes = [vp, i32, i32, i32]
+    L.mgx_episode_stats_layout.argtypes = [vp, vp]
+    L.mgx_record_episodes.argtypes = [vp, vp]
+    L.mgx_request_episode_stats.argtypes = [vp]
+    L.mgx_fetch_episode_stats.argtypes = [vp, i32, vp, C.POINTER(i32)]
+    L.mgx_drain_episode_log.argtypes = [vp, vp, i32, C.POINTER(i32), C.POINTER(i32)]
     L.mgx_count_objects_with_tag.argtypes = [vp, i32, i32, C.POINTER(i32)]
     L.mgx_set_profiling.argtypes = [vp, i32]
     L.mgx_get_step_timing.argtypes = [vp, vp]
@@ -262,6 +268,121 @@ class BatchedMettaGrid:
         ep, mi = np.empty(self.E, np.uint32), np.empty(self.E, np.int32)
         _check(self.L.mgx_get_episodes(self.h, ep.ctypes.data, mi.ctypes.data))
         return ep, mi
+
+    # ---- episode-end statistics (include/mgx.h "Episode-end statistics"; the reference's StatsTracker.on_episode_end) ----
+    EPL = ("NG", "NS", "A", "TOTALS_WORDS", "REC_WORDS", "LOG_WORDS", "OFF_GAME", "OFF_GAME_BITS", "OFF_AGENT", "OFF_AGENT_BITS",
+           "OFF_REWARDS", "OFF_PA", "OFF_PA_BITS", "OFF_INVK", "OFF_INVN", "PER_AGENT", "LOG_CAPACITY")
+    EPT = ("episodes", "return_sum", "return_min", "return_max", "length_sum", "length_min", "length_max", "terminated")
+
+    def set_episode_stats(self, enabled: bool = True, log_capacity: int = 0, log_per_agent: bool = False) -> None:
+        """Reduce the stats of every finished env into batch totals on the device (and keep up to ``log_capacity`` per-episode
+        records, with the per-agent rows if asked) before the auto-reset wipes them."""
+        _check(self.L.mgx_set_episode_stats(self.h, 1 if enabled else 0, int(log_capacity), 1 if log_per_agent else 0))
+        self._epl = None
+        if enabled:
+            out = np.zeros(len(self.EPL), np.int32)
+            _check(self.L.mgx_episode_stats_layout(self.h, out.ctypes.data))
+            self._epl = {k: int(v) for k, v in zip(self.EPL, out)}
+
+    def record_episodes(self, env_mask) -> None:
+        """Host-driven restarts: record the masked envs' episodes as finished now (call before ``reset_envs``)."""
+        mask = np.ascontiguousarray(np.asarray(env_mask, dtype=np.uint8).reshape(self.E))
+        _check(self.L.mgx_record_episodes(self.h, mask.ctypes.data))
+
+    def request_episode_stats(self) -> None:
+        _check(self.L.mgx_request_episode_stats(self.h))
+
+    def _fetch_raw(self, wait: bool):
+        out = np.zeros(self._epl["TOTALS_WORDS"], np.float64)
+        ready = C.c_int32(0)
+        _check(self.L.mgx_fetch_episode_stats(self.h, 1 if wait else 0, out.ctypes.data, C.byref(ready)))
+        return out if ready.value else None
+
+    def fetch_episode_stats(self, wait: bool = False):
+        """The snapshot requested last as a dict (see ``episode_totals_dict``), or None while its copy is still in flight."""
+        raw = self._fetch_raw(wait)
+        return None if raw is None else self.episode_totals_dict(raw)
+
+    def drain_episode_stats(self):
+        """Everything recorded up to now, synchronously: a snapshot still in flight (requested earlier, not fetched) is merged
+        with a fresh one (sums and counts add, minima / maxima combine)."""
+        first = self._fetch_raw(True)          # None unless a request was pending
+        self.request_episode_stats()
+        tot = self._fetch_raw(True)
+        if first is not None:
+            lo, hi = [2, 5], [3, 6]            # MGX_EPT_RETURN_MIN / LENGTH_MIN, ..._MAX
+            merged = first + tot
+            merged[lo] = np.minimum(first[lo], tot[lo])
+            merged[hi] = np.maximum(first[hi], tot[hi])
+            tot = merged
+        return self.episode_totals_dict(tot)
+
+    def episode_totals_dict(self, totals: np.ndarray) -> dict:
+        """Raw totals -> {"episodes", "return_sum", ..., "game_sum": {name: f64}, "game_count": {name: int}, "agent_sum", "agent_count"}
+        (only keys some finished episode held)."""
+        NG, NS, H = self._epl["NG"], self._epl["NS"], len(self.EPT)
+        out = {k: float(totals[i]) for i, k in enumerate(self.EPT)}
+        out["episodes"] = int(out["episodes"])
+        gs, gc = totals[H:H + NG], totals[H + NG:H + 2 * NG]
+        as_, ac = totals[H + 2 * NG:H + 2 * NG + NS], totals[H + 2 * NG + NS:H + 2 * NG + 2 * NS]
+        out["game_sum"] = {self.prog.game_stat_names[i]: float(gs[i]) for i in range(NG) if gc[i]}
+        out["game_count"] = {self.prog.game_stat_names[i]: int(gc[i]) for i in range(NG) if gc[i]}
+        out["agent_sum"] = {self.prog.agent_stat_names[i]: float(as_[i]) for i in range(NS) if ac[i]}
+        out["agent_count"] = {self.prog.agent_stat_names[i]: int(ac[i]) for i in range(NS) if ac[i]}
+        return out
+
+    def drain_episode_log(self):
+        """(list of per-episode dicts, dropped count).  Each dict: env, episode, map_index, seed, steps, flags, episode_rewards
+        (f32 [A]), game {name: value}, agent {name: f64 mean over agents} — the reference's infos["game"] / infos["agent"] —
+        and, with log_per_agent, per_agent [A] dicts (incl. the "action.invalid_index.<k>" keys without a stat column)."""
+        Lw = self._epl
+        cap, W = Lw["LOG_CAPACITY"], Lw["LOG_WORDS"]
+        if cap <= 0:
+            raise ValueError("no episode log: set_episode_stats(log_capacity=...)")
+        raw = np.zeros((cap, W), np.uint32)
+        n, dropped = C.c_int32(0), C.c_int32(0)
+        _check(self.L.mgx_drain_episode_log(self.h, raw.ctypes.data, cap, C.byref(n), C.byref(dropped)))
+        return [self.episode_record_dict(raw[i]) for i in range(n.value)], dropped.value
+
+    def episode_record_dict(self, rec: np.ndarray) -> dict:
+        Lw = self._epl
+        NG, NS, A = Lw["NG"], Lw["NS"], Lw["A"]
+        gnames, anames = self.prog.game_stat_names, self.prog.agent_stat_names
+
+        def bits(off, n):
+            w = rec[off:off + (n + 31) // 32]
+            return [(int(w[i >> 5]) >> (i & 31)) & 1 for i in range(n)]
+        gv = rec[Lw["OFF_GAME"]:Lw["OFF_GAME"] + NG].view(np.float32)
+        gb = bits(Lw["OFF_GAME_BITS"], NG)
+        av = np.ascontiguousarray(rec[Lw["OFF_AGENT"]:Lw["OFF_AGENT"] + 2 * NS]).view(np.float64)
+        ab = bits(Lw["OFF_AGENT_BITS"], NS)
+        out = {"env": int(rec[0]), "episode": int(rec[1]), "map_index": int(np.int32(rec[2])), "seed": int(rec[3]), "steps": int(rec[4]),
+               "flags": int(rec[5]), "return_sum": float(np.ascontiguousarray(rec[6:8]).view(np.float64)[0]),
+               "episode_rewards": rec[Lw["OFF_REWARDS"]:Lw["OFF_REWARDS"] + A].view(np.float32).copy(),
+               "game": {gnames[i]: float(gv[i]) for i in range(NG) if gb[i]},
+               "agent": {anames[i]: float(av[i]) for i in range(NS) if ab[i]}}
+        if Lw["PER_AGENT"]:
+            pa = rec[Lw["OFF_PA"]:Lw["OFF_PA"] + A * NS].view(np.float32).reshape(A, NS)
+            nsw = (NS + 31) // 32
+            ik = rec[Lw["OFF_INVK"]:Lw["OFF_INVK"] + A * K.INVALID_EXTRA].view(np.int32).reshape(A, K.INVALID_EXTRA)
+            inn = rec[Lw["OFF_INVN"]:Lw["OFF_INVN"] + A * K.INVALID_EXTRA].view(np.float32).reshape(A, K.INVALID_EXTRA)
+            per = []
+            for a in range(A):
+                pb = bits(Lw["OFF_PA_BITS"] + a * nsw, NS)
+                dct = {anames[i]: float(pa[a, i]) for i in range(NS) if pb[i]}
+                for q in range(K.INVALID_EXTRA):
+                    if inn[a, q] != 0:
+                        dct[f"action.invalid_index.{int(ik[a, q])}"] = float(inn[a, q])
+                per.append(dct)
+            out["per_agent"] = per
+            extra = {}   # keys without a stat column take part in infos["agent"] like any other (stats_tracker.py:41-46)
+            for dct in per:
+                for k, v in dct.items():
+                    if k.startswith("action.invalid_index.") and k not in anames:
+                        extra[k] = extra.get(k, 0) + v
+            for k, v in extra.items():
+                out["agent"][k] = v / A
+        return out
 
     @property
     def stream(self) -> int:

@@ -133,12 +133,25 @@ class MettaGridBatchedEnv:
 
     With device buffers the returned tensors are ordered on the caller's current torch stream (no host synchronisation);
     ``validate_actions=False`` also skips the reference's range checks on the action tensor, which need a host read.
+
+    ``infos`` (the last element of what ``step`` returns): the reference's wrapper returns, from the step that ends an episode
+    on, the dict StatsTracker.on_episode_end built (stats_tracker.py:26-76: ``game``, ``agent``, ``per_agent``, ``attributes``
+    ...).  Here dozens of the E envs finish in any one step; their stats are reduced on the device before the restart wipes
+    them (``episode_stats=True``: include/mgx.h "Episode-end statistics") and ``step`` returns the batch aggregate of the
+    episodes that finished since the last non-empty ``infos``: ``{"episodes": n, "game": {key: mean over the episodes that
+    hold the key}, "agent": {key: mean of the per-episode infos["agent"] values}, "game_count" / "agent_count",
+    "episode_return": {mean, min, max}, "episode_length": {...}, "terminated": n, "attributes": {...}}`` — every
+    ``stats_interval`` steps a snapshot is requested and the one requested before is returned if its copy has landed (no
+    host synchronisation: the aggregate trails the step that produced it by ``stats_interval`` steps), ``{}`` otherwise.
+    ``episode_infos()`` returns the finished episodes one by one in the reference's shape from a bounded device log
+    (``episode_log`` records; ``log_per_agent`` adds ``per_agent``).
     """
 
     def __init__(self, prog: Program, num_envs: int, map_fn: Optional[Callable[[int, int], np.ndarray]] = None,
                  seed_fn: Optional[Callable[[int, int, int], int]] = None, device: int = 0, seed: int = 0,
                  buffers: str = "device", map_pool: Optional[np.ndarray] = None, pool_stride: int = 1,
-                 desync: bool = False, validate_actions: bool = True) -> None:
+                 desync: bool = False, validate_actions: bool = True, episode_stats: bool = True, stats_interval: int = 1,
+                 episode_log: int = 0, log_per_agent: bool = False) -> None:
         if (map_fn is None) == (map_pool is None):
             raise ValueError("give exactly one of map_fn and map_pool")
         self.prog = prog
@@ -160,6 +173,11 @@ class MettaGridBatchedEnv:
         self._vibe_ids = None
         self.supervisor = None          # object with step_batch(raw_observations, teacher_actions), see set_supervisor
         self.teacher_actions = None
+        self.episode_stats = episode_stats
+        self.stats_interval = max(1, int(stats_interval))
+        self.episode_log = int(episode_log)
+        self.log_per_agent = log_per_agent
+        self._steps = 0
 
     def set_supervisor(self, supervisor) -> None:
         """Supervisor-policy path of MettaGridPufferEnv (mettagrid_puffer_env.py:399-426): after every step
@@ -231,6 +249,9 @@ class MettaGridBatchedEnv:
         else:
             self._eng = BatchedMettaGrid(self.prog, self._maps(range(self.E)), self._seeds(), device=self._device,
                                          buffers=self._kind)
+        if self.episode_stats:
+            self._eng.set_episode_stats(True, self.episode_log, self.log_per_agent)
+        self._steps = 0
         ids = [self.prog.action_names.index(n) for n in self.vibe_action_names]
         self._vibe_ids_host = np.asarray(ids, dtype=np.int32)
         if self._kind == "device":
@@ -256,12 +277,61 @@ class MettaGridBatchedEnv:
             return term.cpu().numpy()
         return eng.terminals.reshape(self.E, A).all(1) | eng.truncations.reshape(self.E, A).all(1)
 
+    # ---- infos ----
+    def _infos_from_totals(self, tot: Optional[dict]) -> dict:
+        """Batch aggregate of the finished episodes in the vocabulary of StatsTracker.on_episode_end (stats_tracker.py:26-76)."""
+        if not tot or tot["episodes"] == 0:
+            return {}
+        n = tot["episodes"]
+        words = self.prog.words
+        return {"episodes": n,
+                "game": {k: v / tot["game_count"][k] for k, v in tot["game_sum"].items()},
+                "agent": {k: v / tot["agent_count"][k] for k, v in tot["agent_sum"].items()},
+                "game_count": tot["game_count"], "agent_count": tot["agent_count"],
+                "episode_return": {"mean": tot["return_sum"] / n, "min": tot["return_min"], "max": tot["return_max"]},
+                "episode_length": {"mean": tot["length_sum"] / n, "min": tot["length_min"], "max": tot["length_max"]},
+                "terminated": int(tot["terminated"]),
+                "attributes": {"map_w": int(words[4]), "map_h": int(words[3]), "max_steps": int(words[11]), "seed": self._seed}}
+
+    def _step_infos(self) -> dict:
+        if not self.episode_stats:
+            return {}
+        eng = self.engine
+        self._steps += 1
+        if self.map_pool is None or self._kind != "device":   # these paths synchronise with the device every step anyway
+            return self._infos_from_totals(eng.drain_episode_stats()) if self._steps % self.stats_interval == 0 else {}
+        out = {}
+        if self._steps % self.stats_interval == 0:
+            out = self._infos_from_totals(eng.fetch_episode_stats(wait=False))   # the snapshot requested one interval ago
+            eng.request_episode_stats()
+        return out
+
+    def episode_infos(self) -> list:
+        """The episodes that finished since the last call, one dict each in the reference's shape (stats_tracker.py:26-76):
+        ``game``, ``agent``, ``per_agent`` (with ``log_per_agent``), ``episode_rewards``, ``attributes`` (seed, map_w, map_h,
+        steps, max_steps) + ``env`` / ``episode`` / ``map_index``.  Needs ``episode_log`` > 0; synchronises with the device."""
+        recs, dropped = self.engine.drain_episode_log()
+        words = self.prog.words
+        out = []
+        for r in recs:
+            info = {"game": r["game"], "agent": r["agent"], "episode_rewards": r["episode_rewards"],
+                    "attributes": {"seed": r["seed"], "map_w": int(words[4]), "map_h": int(words[3]), "steps": r["steps"],
+                                   "max_steps": int(words[11])},
+                    "env": r["env"], "episode": r["episode"], "map_index": r["map_index"]}
+            if "per_agent" in r:
+                info["per_agent"] = {str(i): dct for i, dct in enumerate(r["per_agent"])}
+            out.append(info)
+        self.episodes_dropped = dropped
+        return out
+
     def step(self, actions):
         eng = self.engine
         if self.map_pool is None:  # host map source: the done test needs the flags on the host
             done = self._done_envs()
             if done.any():  # lazy auto-reset at the start of the next step (mettagrid_puffer_env.py:299-302)
                 idx = np.nonzero(done)[0]
+                if self.episode_stats:
+                    eng.record_episodes(done)
                 self.episode[idx] += 1
                 eng.reset_envs(done, self._maps(idx), self._seeds())
         if self._kind == "device":
@@ -307,7 +377,7 @@ class MettaGridBatchedEnv:
             eng.step()
             if self.supervisor is not None:
                 self._compute_supervisor_actions()
-        return eng.obs, eng.rewards, eng.terminals, eng.truncations, {}
+        return eng.obs, eng.rewards, eng.terminals, eng.truncations, self._step_infos()
 
     def close(self) -> None:
         if self._eng is not None:

@@ -23,8 +23,12 @@ spec.max_steps = 1000
 prog = compile_spec(spec, 32, 32, max_objects=192)
 pool = random_class_maps(prog, 32, 32, {"wall": 40, "extractor": 8, "chest": 4}, {"red": 8, "blue": 8}, range(256))
 out = {}
-for validate in (False, True):
-    env = MettaGridBatchedEnv(prog, E, map_pool=pool, pool_stride=7, desync=True, validate_actions=validate, seed=1)
+only = sys.argv[3].split(",") if len(sys.argv) > 3 else None   # e.g. "unchecked_actions" (profiling runs)
+for validate, stats in ((False, True), (False, False), (True, True)):
+    key = ("validate_actions" if validate else "unchecked_actions") + ("" if stats else "_no_episode_stats")
+    if only and key not in only:
+        continue
+    env = MettaGridBatchedEnv(prog, E, map_pool=pool, pool_stride=7, desync=True, validate_actions=validate, seed=1, episode_stats=stats)
     obs, _ = env.reset()
     n = env.transport_action_n   # joint ids: core actions, then (core, vibe) pairs
     gen = torch.Generator(device="cuda").manual_seed(3)
@@ -33,15 +37,18 @@ for validate in (False, True):
         env.step(acts[t % 8])
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    n_infos = n_eps = 0
     for t in range(steps):
-        obs, rew, term, trunc, _ = env.step(acts[t % 8])
+        obs, rew, term, trunc, infos = env.step(acts[t % 8])
+        if infos:
+            n_infos += 1
+            n_eps += infos["episodes"]
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     ep, _ = env.engine.episodes()
     bits, first = env.engine.poll_errors()
-    out["validate_actions" if validate else "unchecked_actions"] = {
-        "agent_steps_per_s": env.num_agents * steps / dt, "ms_per_step": dt * 1e3 / steps,
-        "episodes_finished": int(ep.sum()), "env_error_bits": int(bits)}
+    out[key] = {"agent_steps_per_s": env.num_agents * steps / dt, "ms_per_step": dt * 1e3 / steps,
+                "episodes_finished": int(ep.sum()), "env_error_bits": int(bits), "infos_returned": n_infos, "episodes_in_infos": n_eps}
     env.close()
 print(json.dumps({"workload": f"rung3 rules through MettaGridBatchedEnv, {E} envs x 16 agents, max_steps=1000, pool of 256 maps, "
                               f"desync, {steps} timed steps", **out}))
