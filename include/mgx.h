@@ -64,10 +64,17 @@ void* mgx_stream(mgx_engine* e);
 /* The action decoding of MettaGridPufferEnv.step (python/src/mettagrid/envs/mettagrid_puffer_env.py:331-381) for one joint
  * discrete id per agent, on the device: id < num_primary is a primary action (no vibe action); otherwise
  * off = id - num_primary, primary = off / num_vibe, vibe action = vibe_ids[off % num_vibe].  Writes the engine's bound
- * action buffers (device buffers only), ordered on the engine's stream.  No range checks (the reference's raise
- * ValueError on the host): ids outside [0, num_primary * (num_vibe + 1)) become invalid action indices of the step.
+ * action buffers (device buffers only), ordered on the engine's stream.  Ids outside [0, num_primary * (num_vibe + 1)) become
+ * invalid action indices of the step and are reported by mgx_poll_action_errors.
  * joint: int32 [E*A] device memory; vibe_ids: int32 [num_vibe] host memory (action index of each vibe action). */
 int mgx_set_joint_actions(mgx_engine* e, const int32_t* joint, int32_t num_primary, const int32_t* vibe_ids, int32_t num_vibe);
+/* The reference's range checks on that tensor (mettagrid_puffer_env.py:336-360: "Actions must be non-negative", "Action
+ * indices out of range") are made by the same kernel; a bad id raises a flag in host-visible memory instead of an exception
+ * in the middle of the step.  *flags: 0 = every id decoded so far by mgx_set_joint_actions was in range, bit 0 = a negative id,
+ * bit 1 = an id >= num_primary * (num_vibe + 1); *row / *value: the lowest offending row and its id.  wait = 0 reads the flag
+ * as it stands (no device synchronisation while it is clear: an error of the call just enqueued may show only at a later
+ * poll), wait = 1 first waits for the engine's stream.  A reported error is cleared. */
+int mgx_poll_action_errors(mgx_engine* e, int32_t wait, uint32_t* flags, int64_t* row, int32_t* value);
 
 /* Two env groups on one GPU (two engines, each on its own stream): from now on every mgx_step of `e` holds its
  * world-update kernels back until the world-update kernels of `after`'s most recent mgx_step have finished; its

@@ -264,6 +264,9 @@ struct mgx_engine {
   bool terr_fresh = false;     // the territory ownership maps were refreshed in this step and nothing behind that can change them
   bool rewards_mid = false;    // extended games: ... read nothing the observation kernel writes: evaluated during its encode phase
   int slot = 0;                // constant-memory slot of the lean world kernel (mgx_world_fast.hip, MGX_SLOT)
+  uint32_t* h_act_err = nullptr;      // pinned + mapped [4]: mgx_set_joint_actions' range check: flags, lowest bad row, its value
+  uint32_t* h_act_err_dev = nullptr;
+  unsigned long long* d_first_bad = nullptr;   // (row << 32 | value) of the lowest bad row so far, ~0 = none
   int32_t* d_vibe_ids = nullptr;  // mgx_set_joint_actions: action index of each vibe action
   int32_t vibe_ids_host[256] = {};
   int n_vibe_ids = 0;
@@ -412,13 +415,18 @@ static int size_obs_lds(mgx_engine* e) {
 // Grid of a restart kernel that walks a device list whose length only the device knows: enough workgroups to fill the chip,
 // each taking every grid-th entry.  n_host >= 0: the host knows the length (host-driven restarts) and launches exactly that.
 struct MgxList { const int32_t* list = nullptr; const uint32_t* n = nullptr; int n_host = -1; int passes = 1; };   // passes: see mgx_obs.h (token statistics of a restart)
-static unsigned list_grid(const mgx_engine* e, const MgxList& l, int cap) {
-  return (unsigned)std::max(1, l.n_host >= 0 ? std::min(l.n_host, e->d.E) : std::min(e->d.E, cap));
+// Launching and retiring idle workgroups is not free (measured: ~3 us per 1 000 wavefronts), so the grid follows the number
+// of envs that finished in the most recent step the host has heard of (h_flags, written by mgx_episode_end_kernel): twice
+// that, at least `lo` workgroups — a wrong guess only changes how many entries each workgroup walks.
+static unsigned list_grid(const mgx_engine* e, const MgxList& l, int lo, int hi) {
+  if (l.n_host >= 0) return (unsigned)std::max(1, std::min(l.n_host, e->d.E));
+  const int hint = e->h_flags ? (int)std::min<uint32_t>(e->h_flags[1], 1u << 20) : 0;
+  return (unsigned)std::max(1, std::min(e->d.E, std::min(hi, std::max(lo, 2 * hint))));
 }
 template <bool X, bool PL, int NTH = MGX_OBS_THREADS, int EW = NTH / MGX_WAVE, class K = MgxObsShapeDyn>
 static void launch_obs_t(mgx_engine* e, bool with_rewards, const uint8_t* mask, const MgxList& l) {
   const bool listed = !with_rewards && l.list;
-  dim3 grid(listed ? list_grid(e, l, 2048) : (unsigned)e->d.E), block(NTH);
+  dim3 grid(listed ? list_grid(e, l, 128, 2048) : (unsigned)e->d.E), block(NTH);
   const int32_t* ll = listed ? l.list : nullptr;
   const uint32_t* ln = listed ? l.n : nullptr;
   if (listed) mask = nullptr;
@@ -491,7 +499,7 @@ static int launch_obs(mgx_engine* e, bool with_rewards, const uint8_t* mask = nu
       for (int k = MGX_SEC_INV_FEATURES; k < MGX_SEC_WORDLIST; k++) dd.sec[k] -= e->obs_blk_start;
     if (!mgx_launch_obs_box(e->stream, dd, e->lds_obs, e->pool_tokens, e->pool_prefix, mask, e->obs_blk_start, e->obs_blk_words,
                             (e->rewards_early ? 1 : e->rewards_mid ? 2 : 0), with_rewards, e->d.X != 0, pl, e->obs_threads, e->obs_ew, e->box_out, e->d_scale,
-                            e->box_C, e->box_dtype, with_rewards ? nullptr : l.list, l.n, (int)list_grid(e, l, 2048), l.passes))
+                            e->box_C, e->box_dtype, with_rewards ? nullptr : l.list, l.n, (int)list_grid(e, l, 128, 2048), l.passes))
       return fail(MGX_ERR_PROGRAM, "mgx_step: no dense-output instance of the observation kernel for this configuration");
     HIP_TRY(hipGetLastError());
     return MGX_OK;
@@ -545,13 +553,15 @@ static void free_episode_stats(mgx_engine* e) {
 static int launch_episode_stats(mgx_engine* e) {
 #ifndef MGX_CPU_EMU
   const MgxDev& d = e->d;
-  hipLaunchKernelGGL(mgx_episode_record_kernel, dim3((unsigned)std::min(std::max(1, d.E / 4), 512)), dim3(256), 0, e->stream, dev_copy(e), e->ep,
+  MgxList dl;
+  dl.n_host = -1;
+  hipLaunchKernelGGL(mgx_episode_record_kernel, dim3((list_grid(e, dl, 128, 2048) + 3) / 4), dim3(256), 0, e->stream, dev_copy(e), e->ep,
                      (const int32_t*)e->d_done_list, (const uint32_t*)e->d_done_n, e->d_ep_rec, e->d_ep_log, (const uint32_t*)e->d_ep_log_state,
                      e->ep_log_cap, (const uint32_t*)e->d_early, (const uint32_t*)e->d_episodes, (const int32_t*)e->d_map_index,
                      (const uint32_t*)e->dseeds);
   HIP_TRY(hipGetLastError());
   const int nchunks_max = (d.E + MGX_EP_CHUNK - 1) / MGX_EP_CHUNK;
-  hipLaunchKernelGGL(mgx_episode_accum_kernel, dim3((unsigned)std::min(nchunks_max, 64)), dim3(256), 0, e->stream, e->ep,
+  hipLaunchKernelGGL(mgx_episode_accum_kernel, dim3((unsigned)std::min(nchunks_max, 16)), dim3(256), 0, e->stream, e->ep,
                      (const uint32_t*)e->d_done_n, (const uint32_t*)e->d_ep_rec, e->d_ep_partial, e->d_ep_totals, e->d_ep_ticket,
                      e->d_ep_log_state, e->ep_log_cap, e->d_ep_log ? 1 : 0);
   HIP_TRY(hipGetLastError());
@@ -571,7 +581,8 @@ const char* mgx_last_error(void) { return g_err.c_str(); }
 #define MGX_LAUNCH_INIT(stream, dc, maps, mi, sd, mask, l) hipLaunchKernelGGL(mgx_init_kernel, dim3((d.E + MGX_WAVE - 1) / MGX_WAVE), dim3(MGX_WAVE), 0, stream, dc, maps, mi, sd, mask)
 #else
 #define MGX_LAUNCH_INIT(stream, dc, maps, mi, sd, mask, l)                                                                          \
-  hipLaunchKernelGGL(mgx_init_wave_kernel, dim3((l).list ? list_grid(e, (l), 4096) : (unsigned)d.E), dim3(MGX_WAVE), 0, stream, dc, maps, mi, sd, \
+  hipLaunchKernelGGL(mgx_init_wave_kernel, dim3((l).list ? list_grid(e, (l), 128, 2048) : (unsigned)d.E),                                  \
+                     dim3((unsigned)std::min(MGX_INIT_THREADS, std::max(MGX_WAVE, (d.H * d.W + MGX_WAVE - 1) / MGX_WAVE * MGX_WAVE))), 0, stream, dc, maps, mi, sd, \
                      (l).list ? (const uint8_t*)nullptr : (mask), (l).list, (l).n)
 #endif
 static std::mutex g_live_mu;
@@ -1214,6 +1225,7 @@ void mgx_destroy(mgx_engine* e) {
   if (e->d_stage) (void)hipFree(e->d_stage);
   if (e->d_objs) (void)hipFree(e->d_objs);
   if (e->h_flags) (void)hipHostFree(e->h_flags);
+  if (e->h_act_err) (void)hipHostFree(e->h_act_err);
   free_episode_stats(e);
   for (int i = 0; i <= MGX_T_COUNT; i++) if (e->ev[i]) (void)hipEventDestroy(e->ev[i]);
   if (e->world_done) (void)hipEventDestroy(e->world_done);
@@ -1301,7 +1313,7 @@ static int restart_masked(mgx_engine* e, const uint8_t* dmask, bool from_pool, b
   MgxList ll = l;
 #endif
   ll.passes = 2;   // new MettaGrid + set_buffers = two initial observation passes in the reference (token statistics)
-  hipLaunchKernelGGL(mgx_clear_rows_kernel, dim3(ll.list ? list_grid(e, ll, 1024) : (unsigned)d.E), dim3(256), 0, e->stream, (const MgxRow*)e->d_rows,
+  hipLaunchKernelGGL(mgx_clear_rows_kernel, dim3(ll.list ? list_grid(e, ll, 128, 1024) : (unsigned)d.E), dim3(256), 0, e->stream, (const MgxRow*)e->d_rows,
                      e->n_rows, dmask, d.E, bump ? e->d_episodes : (uint32_t*)nullptr, bump ? e->d_map_index : (int32_t*)nullptr, e->n_pool,
                      e->pool_stride, ll.list, ll.n);
   HIP_TRY(hipGetLastError());
@@ -1730,7 +1742,7 @@ int mgx_step(mgx_engine* e) {
 #ifdef MGX_CPU_EMU
     const unsigned bt = 1;  // the sanitizer build runs work-items one after another: one env per workgroup
 #else
-    const unsigned bt = 256;
+    const unsigned bt = MGX_EPEND_THREADS;
 #endif
     hipLaunchKernelGGL(mgx_episode_end_kernel, dim3((d.E + bt - 1) / bt), dim3(bt), 0, e->stream, dev_copy(e), (const uint32_t*)e->d_early,
                        (const uint32_t*)e->d_episodes, e->d_next_mask, e->d_counters, (volatile uint32_t*)e->h_flags_dev, e->step_seq,
@@ -1983,12 +1995,22 @@ int mgx_state_digests(mgx_engine* e, uint64_t* out) {
 }
 
 // joint action id -> (primary, vibe) action indices (mettagrid_puffer_env.py:331-381), one thread per agent row
+// ... and the range checks MettaGridPufferEnv.step makes on the host (:336-360: negative ids, ids >= num_primary * (num_vibe + 1)):
+// a bad id sets a flag word in host-visible memory (bit 0 negative, bit 1 too large) — read by mgx_poll_action_errors without
+// waiting for the device — and keeps the lowest offending (row, value) in device memory.
 __global__ void __launch_bounds__(256) mgx_joint_actions_kernel(const int32_t* __restrict__ joint, int32_t* __restrict__ actions,
                                                                 int32_t* __restrict__ vibe_actions, const int32_t* __restrict__ vibe_ids,
-                                                                long long rows, int num_primary, int num_vibe) {
+                                                                long long rows, int num_primary, int num_vibe,
+                                                                unsigned long long* __restrict__ first_bad, uint32_t* __restrict__ host_err) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= rows) return;
   const int a = joint[i];
+  const int max_valid = num_vibe > 0 ? num_primary + num_primary * num_vibe : num_primary;
+  if (a < 0 || a >= max_valid) {
+    const unsigned long long key = ((unsigned long long)i << 32) | (uint32_t)a;
+    atomicMin(first_bad, key);   // the lowest bad row (fetched by the host once it has seen the flag)
+    atomicOr(host_err, a < 0 ? 1u : 2u);
+  }
   int core = a, vibe = 0;
   if (num_vibe > 0 && a >= num_primary) {
     const int off = a - num_primary;
@@ -2012,9 +2034,36 @@ int mgx_set_joint_actions(mgx_engine* e, const int32_t* joint, int32_t num_prima
     HIP_TRY(hipMemcpyAsync(e->d_vibe_ids, e->vibe_ids_host, (size_t)num_vibe * 4, hipMemcpyHostToDevice, e->stream));
   }
   const long long rows = (long long)d.E * d.A;
+  if (!e->h_act_err) {
+    HIP_TRY(hipHostMalloc((void**)&e->h_act_err, 16, hipHostMallocMapped));
+    memset(e->h_act_err, 0, 16);
+    HIP_TRY(hipHostGetDevicePointer((void**)&e->h_act_err_dev, e->h_act_err, 0));
+    int rc = e->alloc(&e->d_first_bad, 1, 0xFF);
+    if (rc) return rc;
+  }
   hipLaunchKernelGGL(mgx_joint_actions_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, e->stream, joint, (int32_t*)d.actions, (int32_t*)d.vibe_actions,
-                     (const int32_t*)e->d_vibe_ids, rows, num_primary, num_vibe);
+                     (const int32_t*)e->d_vibe_ids, rows, num_primary, num_vibe, e->d_first_bad, e->h_act_err_dev);
   HIP_TRY(hipGetLastError());
+  return MGX_OK;
+}
+
+int mgx_poll_action_errors(mgx_engine* e, int32_t wait, uint32_t* flags, int64_t* row, int32_t* value) {
+  if (!e || !flags) return fail(MGX_ERR_BAD_ARG, "mgx_poll_action_errors: null argument");
+  *flags = 0;
+  if (!e->h_act_err) return MGX_OK;   // mgx_set_joint_actions has not run
+  if (wait) { HIP_TRY(hipSetDevice(e->device)); HIP_TRY(hipStreamSynchronize(e->stream)); }
+  const uint32_t f = ((volatile uint32_t*)e->h_act_err)[0];
+  if (!f) return MGX_OK;
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipStreamSynchronize(e->stream));   // (an error is the slow path: report the lowest bad row of everything enqueued)
+  *flags = ((volatile uint32_t*)e->h_act_err)[0];
+  unsigned long long key = 0;
+  HIP_TRY(hipMemcpy(&key, e->d_first_bad, 8, hipMemcpyDeviceToHost));
+  if (row) *row = (int64_t)(key >> 32);
+  if (value) *value = (int32_t)(uint32_t)key;
+  memset(e->h_act_err, 0, 16);
+  HIP_TRY(hipMemsetAsync(e->d_first_bad, 0xFF, 8, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
   return MGX_OK;
 }
 

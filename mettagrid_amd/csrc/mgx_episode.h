@@ -100,21 +100,33 @@ __global__ void __launch_bounds__(256) mgx_episode_record_kernel(const MgxDev* _
       const int c = c0 + lane;
       double s = 0.0;
       bool any = false;
-      for (int a = 0; a < L.A; a++) {
-        float v = 0.f;
-        bool t = false;
-        if (c < L.NS) {
-          v = d.ag_stats[(a0 + a) * L.NSP + c];
-          t = ((d.ag_touched[(a0 + a) * L.NSW + (c >> 5)] >> (c & 31)) & 1u) || v != 0.f;
-          s += (double)v;   // (an agent without the key holds 0: adding it changes nothing, as skipping it does in the reference)
-          any = any || t;
-          if (G && L.per_agent) G[L.off_pa + a * L.NS + c] = __float_as_uint(v);
+      const float* as = d.ag_stats + a0 * L.NSP + (c < L.NS ? c : 0);
+      const uint32_t* at = d.ag_touched + a0 * L.NSW + (c < L.NS ? (c >> 5) : 0);
+      for (int ab = 0; ab < L.A; ab += 8) {   // eight agents' loads in flight at a time, added in agent order
+        float v[8];
+        uint32_t tw[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+          const int a = min(ab + q, L.A - 1);
+          v[q] = as[(size_t)a * L.NSP];
+          tw[q] = at[(size_t)a * L.NSW];
         }
-        if (G && L.per_agent) {
-          const unsigned long long m = __ballot(t);
-          if (lane == 0) {
-            G[L.off_pabits + a * L.NSW + (c0 >> 5)] = (uint32_t)m;
-            if ((c0 >> 5) + 1 < L.NSW) G[L.off_pabits + a * L.NSW + (c0 >> 5) + 1] = (uint32_t)(m >> 32);
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+          const int a = ab + q;
+          if (a >= L.A) break;
+          const bool t = c < L.NS && (((tw[q] >> (c & 31)) & 1u) || v[q] != 0.f);
+          if (c < L.NS) {
+            s += (double)v[q];   // (an agent without the key holds 0: adding it changes nothing, as skipping it does in the reference)
+            any = any || t;
+            if (G && L.per_agent) G[L.off_pa + a * L.NS + c] = __float_as_uint(v[q]);
+          }
+          if (G && L.per_agent) {
+            const unsigned long long m = __ballot(t);
+            if (lane == 0) {
+              G[L.off_pabits + a * L.NSW + (c0 >> 5)] = (uint32_t)m;
+              if ((c0 >> 5) + 1 < L.NSW) G[L.off_pabits + a * L.NSW + (c0 >> 5) + 1] = (uint32_t)(m >> 32);
+            }
           }
         }
       }
@@ -181,33 +193,59 @@ __global__ void __launch_bounds__(256) mgx_episode_accum_kernel(const MgxEpLayou
     double* P = partial + (size_t)ch * TW;
     for (int c = threadIdx.x; c < cols; c += blockDim.x) {
       double s = 0.0, cnt = 0.0;
+      // sixteen records' loads in flight at a time, added in list order
       if (c < L.NG) {
-        for (int k = k0; k < k1; k++) {
-          const uint32_t* R = rec + (size_t)k * L.rec_words;
-          const bool t = (R[L.off_gbits + (c >> 5)] >> (c & 31)) & 1u;
-          s += (double)__uint_as_float(R[L.off_game + c]);   // (a missing key holds 0)
-          cnt += t ? 1.0 : 0.0;
+        for (int kb = k0; kb < k1; kb += 16) {
+          uint32_t vb[16], tb[16];
+#pragma unroll
+          for (int q = 0; q < 16; q++) {
+            const uint32_t* R = rec + (size_t)min(kb + q, k1 - 1) * L.rec_words;
+            vb[q] = R[L.off_game + c]; tb[q] = R[L.off_gbits + (c >> 5)];
+          }
+#pragma unroll
+          for (int q = 0; q < 16; q++) {
+            if (kb + q >= k1) break;
+            s += (double)__uint_as_float(vb[q]);   // (a missing key holds 0)
+            cnt += ((tb[q] >> (c & 31)) & 1u) ? 1.0 : 0.0;
+          }
         }
         P[MGX_EP_TOT_HDR + c] = s; P[MGX_EP_TOT_HDR + L.NG + c] = cnt;
       } else {
         const int a = c - L.NG;
-        for (int k = k0; k < k1; k++) {
-          const uint32_t* R = rec + (size_t)k * L.rec_words;
-          const bool t = (R[L.off_abits + (a >> 5)] >> (a & 31)) & 1u;
-          s += mgx_ep_f64(R + L.off_agent + 2 * a);
-          cnt += t ? 1.0 : 0.0;
+        for (int kb = k0; kb < k1; kb += 16) {
+          uint32_t lo[16], hi[16], tb[16];
+#pragma unroll
+          for (int q = 0; q < 16; q++) {
+            const uint32_t* R = rec + (size_t)min(kb + q, k1 - 1) * L.rec_words;
+            lo[q] = R[L.off_agent + 2 * a]; hi[q] = R[L.off_agent + 2 * a + 1]; tb[q] = R[L.off_abits + (a >> 5)];
+          }
+#pragma unroll
+          for (int q = 0; q < 16; q++) {
+            if (kb + q >= k1) break;
+            s += __longlong_as_double((long long)((unsigned long long)lo[q] | ((unsigned long long)hi[q] << 32)));
+            cnt += ((tb[q] >> (a & 31)) & 1u) ? 1.0 : 0.0;
+          }
         }
         P[MGX_EP_TOT_HDR + 2 * L.NG + a] = s; P[MGX_EP_TOT_HDR + 2 * L.NG + L.NS + a] = cnt;
       }
     }
     if (threadIdx.x == blockDim.x - 1) {   // header: returns and lengths of the chunk, in list order
       double rs = 0.0, rmin = INF, rmax = -INF, ls = 0.0, lmin = INF, lmax = -INF, nterm = 0.0;
-      for (int k = k0; k < k1; k++) {
-        const uint32_t* R = rec + (size_t)k * L.rec_words;
-        const double r = mgx_ep_f64(R + 6) / (double)L.A, len = (double)R[4];
-        rs += r; rmin = fmin(rmin, r); rmax = fmax(rmax, r);
-        ls += len; lmin = fmin(lmin, len); lmax = fmax(lmax, len);
-        nterm += (R[5] & 1u) ? 1.0 : 0.0;
+      for (int kb = k0; kb < k1; kb += 8) {
+        uint32_t hw[8][4];
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+          const uint4 x = *(const uint4*)(rec + (size_t)min(kb + q, k1 - 1) * L.rec_words + 4);   // steps, flags, f64 return sum
+          hw[q][0] = x.x; hw[q][1] = x.y; hw[q][2] = x.z; hw[q][3] = x.w;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+          if (kb + q >= k1) break;
+          const double r = mgx_ep_f64(&hw[q][2]) / (double)L.A, len = (double)hw[q][0];
+          rs += r; rmin = fmin(rmin, r); rmax = fmax(rmax, r);
+          ls += len; lmin = fmin(lmin, len); lmax = fmax(lmax, len);
+          nterm += (hw[q][1] & 1u) ? 1.0 : 0.0;
+        }
       }
       P[0] = (double)(k1 - k0); P[1] = rs; P[2] = rmin; P[3] = rmax; P[4] = ls; P[5] = lmin; P[6] = lmax; P[7] = nterm;
     }
@@ -223,7 +261,8 @@ __global__ void __launch_bounds__(256) mgx_episode_accum_kernel(const MgxEpLayou
     double t = totals[c];
     const bool is_min = c == 2 || c == 5, is_max = c == 3 || c == 6;
     for (int ch = 0; ch < nchunks; ch++) {
-      const double p = __hip_atomic_load(partial + (size_t)ch * TW + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const double p = __longlong_as_double((long long)__hip_atomic_load((const unsigned long long*)(partial + (size_t)ch * TW + c),
+                                                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
       t = is_min ? fmin(t, p) : is_max ? fmax(t, p) : t + p;
     }
     totals[c] = t;

@@ -2399,48 +2399,53 @@ __global__ void __launch_bounds__(MGX_WAVE) mgx_init_kernel(const MgxDev* __rest
 }
 
 #ifndef MGX_CPU_EMU
-// The same construction with one WAVEFRONT per env (the kernel the engine launches; the lane-per-env kernel above is its
-// serial statement and what the CPU sanitizer build runs).  An episode restart rebuilds a few dozen envs per step; with
-// one lane per env that was a 0.6 ms chain of 1 024 dependent cell reads per restarted env, on the critical path of
-// every step of an auto-resetting batch.  Here 64 cells are read per pass; ballots give every occupied cell its object
-// slot (= number of occupied cells before it, the reference's object id - 1) and every agent cell its agent index, and
-// each lane initialises its own object.  What is order dependent — the registration lists of the extended variant
-// (tag index, AoE sources, territory sources, in object order) and the materialized queries — is done by lane 0 afterwards
-// over the objects, not the cells.  Object counts per class are whole numbers: atomic float adds are exact in any order.
+// The same construction with one WORKGROUP per env (the kernel the engine launches; the lane-per-env kernel above is its
+// serial statement and what the CPU sanitizer build runs).  An episode restart rebuilds a few dozen envs per step, and its
+// time is the latency of ONE env's construction: with one lane per env that was a 0.6 ms chain of 1 024 dependent cell
+// reads, with one wavefront per env (round 2) 16 passes of 64 cells, each a chain of ~8 dependent accesses (class ->
+// initial inventory -> limits -> stats), launched as E single-wavefront workgroups of which a few dozen had work: 0.11 ms
+// on the critical path of every step of an auto-resetting batch (measured round 4: 0.05 ms of it was launching and
+// retiring the idle wavefronts — about 3 us per 1 000 of them —, 0.02 ms the object pass, the rest the first step's
+// full-batch launch in the average).  Now the wavefronts of a 256-thread workgroup take the 64-cell passes
+// p = wave, wave + NW, ...: (A) ballots
+// count the occupied / agent cells of each pass into LDS, (B) a scan over the passes gives every pass its first object slot
+// (= number of occupied cells before it, the reference's object id - 1) and agent index, (C) each lane initialises its own
+// object — one chain per lane, four passes of a 32 x 32 map at a time.  What is order dependent — the registration lists of
+// the extended variant (tag index, AoE sources, territory sources, in object order) and the materialized queries — is done
+// by lane 0 of wavefront 0 afterwards over the objects, while the last lane of the workgroup seeds the Mersenne Twister
+// (a serial recurrence of 623 steps).  Object counts per class are whole numbers: atomic float adds are exact in any order.
 // The envs to build are all (env_mask == env_list == nullptr: grid = E), the masked ones (grid = E), or — episode restarts —
 // the entries of a device LIST whose length the host need not know: a small fixed grid walks it (`*env_list_n` entries).
-static __device__ void mgx_init_wave_env(const MgxDev& d, const int env, const int lane, const uint16_t* class_maps,
-                                         const int32_t* map_index, const uint32_t* seeds);
-__global__ void __launch_bounds__(MGX_WAVE) mgx_init_wave_kernel(const MgxDev* __restrict__ dp, const uint16_t* class_maps,
-                                                                 const int32_t* map_index, const uint32_t* seeds,
-                                                                 const uint8_t* env_mask, const int32_t* env_list,
-                                                                 const uint32_t* env_list_n) {
+#define MGX_INIT_THREADS 256
+#define MGX_INIT_MAX_PASSES 1024   // maps up to 255 x 255 = 1 017 passes of 64 cells
+static __device__ void mgx_init_wave_env(const MgxDev& d, const int env, const uint16_t* class_maps, const int32_t* map_index,
+                                         const uint32_t* seeds, uint16_t* s_occ, uint16_t* s_ag, int* s_tot);
+__global__ void __launch_bounds__(MGX_INIT_THREADS) mgx_init_wave_kernel(const MgxDev* __restrict__ dp, const uint16_t* class_maps,
+                                                                         const int32_t* map_index, const uint32_t* seeds,
+                                                                         const uint8_t* env_mask, const int32_t* env_list,
+                                                                         const uint32_t* env_list_n) {
   const MgxDev& d = *dp;
-  const int lane = threadIdx.x;
+  __shared__ uint16_t s_occ[MGX_INIT_MAX_PASSES], s_ag[MGX_INIT_MAX_PASSES];
+  __shared__ int s_tot[2];
   if (env_list) {
     const int n = (int)*env_list_n;
     for (int k = blockIdx.x; k < n; k += gridDim.x) {
-      mgx_init_wave_env(d, env_list[k], lane, class_maps, map_index, seeds);
-      __builtin_amdgcn_wave_barrier();
+      mgx_init_wave_env(d, env_list[k], class_maps, map_index, seeds, s_occ, s_ag, s_tot);
+      __syncthreads();
     }
     return;
   }
   const int env = blockIdx.x;
   if (env >= d.E) return;
   if (env_mask && !env_mask[env]) return;
-  mgx_init_wave_env(d, env, lane, class_maps, map_index, seeds);
+  mgx_init_wave_env(d, env, class_maps, map_index, seeds, s_occ, s_ag, s_tot);
 }
-static __device__ void mgx_init_wave_env(const MgxDev& d, const int env, const int lane, const uint16_t* class_maps,
-                                         const int32_t* map_index, const uint32_t* seeds) {
+static __device__ void mgx_init_wave_env(const MgxDev& d, const int env, const uint16_t* class_maps, const int32_t* map_index,
+                                         const uint32_t* seeds, uint16_t* s_occ, uint16_t* s_ag, int* s_tot) {
   MgxEnvX e(d, d.P, env);
   const size_t E = (size_t)d.E;
-  if (lane == 0) {
-    uint32_t x = seeds[env];  // std::mt19937(seed): bits/random.tcc seed()
-    d.mt[env] = x;
-    for (uint32_t i = 1; i < 624; i++) {
-      x = 1812433253u * (x ^ (x >> 30)) + i;
-      d.mt[i * E + env] = x;
-    }
+  const int tid = threadIdx.x, lane = tid & (MGX_WAVE - 1), wave = tid / MGX_WAVE, NW = (int)blockDim.x / MGX_WAVE;
+  if (tid == 0) {
     d.mt_idx[env] = 0;
     d.step[env] = 0;
     d.err[env] = 0;
@@ -2448,24 +2453,48 @@ static __device__ void mgx_init_wave_env(const MgxDev& d, const int env, const i
     e.gstat_touch(d.wk[MGX_S_GAME_TOKENS_DROPPED]);
     e.gstat_touch(d.wk[MGX_S_GAME_TOKENS_FREE]);
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // err = 0 / touched bits before any lane's atomicOr below
-  __builtin_amdgcn_wave_barrier();
-  const int HW = d.H * d.W;
+  const int HW = d.H * d.W, npass = (HW + MGX_WAVE - 1) / MGX_WAVE;
   const uint16_t* cm = class_maps + (size_t)(map_index ? map_index[env] : env) * HW;
   const unsigned long long lt = (1ull << lane) - 1ull;
-  int nobj = 0, nag = 0;
+  // (A) occupied / agent cells per pass
+  for (int p = wave; p < npass; p += NW) {
+    const int cellidx = p * MGX_WAVE + lane;
+    const int k = cellidx < HW ? (int)cm[cellidx] : 0;
+    const unsigned long long occ = __ballot(k != 0);
+    const unsigned long long agm = __ballot(k != 0 && mgx_cls(d, k ? k - 1 : 0)[MGX_C_KIND] == MGX_KIND_AGENT);
+    if (lane == 0) { s_occ[p] = (uint16_t)__popcll(occ); s_ag[p] = (uint16_t)__popcll(agm); }
+  }
+  __threadfence_block();   // err = 0 / touched bits (thread 0) before any lane's atomicOr below
+  __syncthreads();
+  // (B) exclusive scan over the passes (wavefront 0, 64 passes at a time)
+  if (wave == 0) {
+    int co = 0, ca = 0;
+    for (int p0 = 0; p0 < npass; p0 += MGX_WAVE) {
+      const int p = p0 + lane;
+      const int vo = p < npass ? (int)s_occ[p] : 0, va = p < npass ? (int)s_ag[p] : 0;
+      int io = vo, ia = va;
+      for (int o = 1; o < MGX_WAVE; o <<= 1) {
+        const int to = __shfl_up(io, o), ta = __shfl_up(ia, o);
+        if (lane >= o) { io += to; ia += ta; }
+      }
+      if (p < npass) { s_occ[p] = (uint16_t)min(co + io - vo, 0xFFFF); s_ag[p] = (uint16_t)min(ca + ia - va, 0xFFFF); }
+      co += __shfl(io, MGX_WAVE - 1);
+      ca += __shfl(ia, MGX_WAVE - 1);
+    }
+    if (lane == 0) { s_tot[0] = co; s_tot[1] = ca; }
+  }
+  __syncthreads();
+  // (C) every lane builds the object of its cell
   bool overflow = false;
-  for (int base = 0; base < HW; base += MGX_WAVE) {
-    const int cellidx = base + lane;
+  for (int p = wave; p < npass; p += NW) {
+    const int cellidx = p * MGX_WAVE + lane;
     const int k = cellidx < HW ? (int)cm[cellidx] : 0;
     const unsigned long long occ = __ballot(k != 0);
     const int32_t* C = mgx_cls(d, k ? k - 1 : 0);
     const bool agent_cell = k != 0 && C[MGX_C_KIND] == MGX_KIND_AGENT;
     const unsigned long long agm = __ballot(agent_cell);
-    const int slot = nobj + __popcll(occ & lt);
-    const int ai_raw = nag + __popcll(agm & lt);
-    nobj += __popcll(occ);
-    nag += __popcll(agm);
+    const int slot = (int)s_occ[p] + __popcll(occ & lt);
+    const int ai_raw = (int)s_ag[p] + __popcll(agm & lt);
     if (k == 0) continue;
     if (slot >= d.S) { overflow = true; continue; }   // (the serial kernel stops at the first object that does not fit)
     const int cls = k - 1;
@@ -2499,10 +2528,19 @@ static __device__ void mgx_init_wave_env(const MgxDev& d, const int env, const i
     if (d.X && d.obj_tags)
       for (int w = 0; w < MGX_TAG_WORDS; w++) d.obj_tags[e.so(slot) * MGX_TAG_WORDS + w] = (uint32_t)C[MGX_C_TAGS + w];
   }
-  if (__ballot(overflow)) { if (lane == 0) atomicOr(&d.err[env], 8u); nobj = min(nobj, d.S); }
-  nag = min(nag, d.A);
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // the objects written by other lanes are read below
-  __builtin_amdgcn_wave_barrier();
+  if (__ballot(overflow) && lane == 0) atomicOr(&d.err[env], 8u);
+  __threadfence_block();   // the objects written by other wavefronts are read below
+  __syncthreads();
+  const int nobj = min(s_tot[0], d.S), nag = min(s_tot[1], d.A);
+  if (tid == (int)blockDim.x - 1) {   // std::mt19937(seed): bits/random.tcc seed() — beside the registration pass below
+    uint32_t x = seeds[env];
+    d.mt[env] = x;
+    for (uint32_t i = 1; i < 624; i++) {
+      x = 1812433253u * (x ^ (x >> 30)) + i;
+      d.mt[i * E + env] = x;
+    }
+  }
+  if (wave != 0) return;
   if (lane == 0) {
     d.num_objs[env] = (uint32_t)nobj;
     if (d.X) {
@@ -2622,18 +2660,22 @@ __global__ void mgx_scatter_words_kernel(uint32_t* dst, const uint32_t* packed, 
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k < n) dst[idx[k]] = packed[k];
 }
+// bit 8q of the result is set iff byte q of w is non-zero
+__device__ __forceinline__ uint32_t mgx_nonzero_bytes(uint32_t w) { return ((w & 0x7F7F7F7Fu) + 0x7F7F7F7Fu | w) & 0x80808080u; }
 // End of a step in auto-reset mode: the one-off early end of every env's first episode (EarlyResetHandler,
 // python/src/mettagrid/envs/early_reset_handler.py:6-22: truncations set once current_step >= the drawn step), then the
 // env-is-done test of Simulation.is_done (simulator.py:145-146) -> mask of the envs to restart at the start of the next
 // step (lazy auto-reset, mettagrid_puffer_env.py:299-302).  The number of done envs and the step's sequence number go to
 // host-visible memory, so a host that has already synchronised with this step knows without a copy whether the restart
 // launches are needed at all.
-__global__ void __launch_bounds__(256) mgx_episode_end_kernel(const MgxDev* __restrict__ dp, const uint32_t* early_steps,
+#define MGX_EPEND_THREADS 1024   // (few workgroups: every one of them takes a ticket on one address)
+__global__ void __launch_bounds__(MGX_EPEND_THREADS) mgx_episode_end_kernel(const MgxDev* __restrict__ dp, const uint32_t* early_steps,
                                                               const uint32_t* episodes, uint8_t* next_mask,
                                                               uint32_t* done_count, volatile uint32_t* host_flags, uint32_t seq,
                                                               uint32_t* blocks_done, int32_t* done_list, uint32_t* done_n) {
   const MgxDev& d = *dp;
   const int env = blockIdx.x * blockDim.x + threadIdx.x;
+  bool done = false;
   if (env < d.E) {
     const size_t r0 = (size_t)env * d.A;
     const bool early = early_steps && episodes[env] == 0 && early_steps[env] > 0 && d.step[env] >= early_steps[env];
@@ -2651,13 +2693,20 @@ __global__ void __launch_bounds__(256) mgx_episode_end_kernel(const MgxDev* __re
       if (early) for (int a = 0; a < d.A; a++) d.truncations[r0 + a] = 1;
       for (int a = 0; a < d.A; a++) { all_term = all_term && d.terminals[r0 + a]; all_trunc = all_trunc && d.truncations[r0 + a]; }
     }
-    const bool done = all_term || all_trunc;
+    done = all_term || all_trunc;
     next_mask[env] = done ? 1 : 0;
-    if (done) atomicAdd(done_count, 1u);
   }
+#ifdef MGX_CPU_EMU
+  if (done) atomicAdd(done_count, 1u);
+#else
+  {
+    const unsigned long long m = __ballot(done);   // one add per wavefront
+    if (m && (threadIdx.x & (MGX_WAVE - 1)) == 0) atomicAdd(done_count, (uint32_t)__popcll(m));
+  }
+#endif
   __threadfence();
   __syncthreads();
-  __shared__ uint32_t s_last, s_wsum[4];
+  __shared__ uint32_t s_last, s_wsum[MGX_EPEND_THREADS / MGX_WAVE];
   if (threadIdx.x == 0) {
     const uint32_t ticket = atomicAdd(blocks_done, 1u);
     s_last = ticket == gridDim.x - 1 ? 1u : 0u;
@@ -2682,26 +2731,46 @@ __global__ void __launch_bounds__(256) mgx_episode_end_kernel(const MgxDev* __re
     for (int k = 0; k < d.E; k++) if (next_mask[k]) done_list[n++] = k;
   }
 #else
+  // Thread t owns the contiguous envs [t * per, (t + 1) * per): it loads its mask bytes in one go (independent 16-byte
+  // loads; the mask was written by the other workgroups of this launch, made visible by their fences and the acquire
+  // fence behind the ticket), counts, and one scan over the workgroup gives it its place in the list.
   const int tid = threadIdx.x, lane = tid & (MGX_WAVE - 1), wave = tid / MGX_WAVE;
-  uint32_t base = 0;
-  for (int e0 = 0; e0 < d.E; e0 += 256 * 4) {   // four envs (one word of the mask) per thread and pass
-    const int first = e0 + tid * 4;
-    uint32_t w = 0;
-    if (first < d.E)   // written by other workgroups of this launch: read at the coherence point, not from this CU's L1
-      w = __hip_atomic_load((const uint32_t*)(next_mask + first), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    uint32_t bits = 0;
-    for (int q = 0; q < 4; q++) bits |= (first + q < d.E && ((w >> (8 * q)) & 0xFF)) ? 1u << q : 0u;
-    const uint32_t cnt = __popc(bits);
-    uint32_t incl = cnt;
-    for (int o = 1; o < MGX_WAVE; o <<= 1) { const uint32_t v = __shfl_up(incl, o); if (lane >= o) incl += v; }
-    if (lane == MGX_WAVE - 1) s_wsum[wave] = incl;
-    __syncthreads();
-    uint32_t off = base + incl - cnt;
-    for (int q = 0; q < wave; q++) off += s_wsum[q];
-    for (int q = 0; q < 4; q++) if (bits & (1u << q)) done_list[off++] = first + q;
-    base += s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
-    __syncthreads();
+  const int NT = (int)blockDim.x, NWV = NT / MGX_WAVE;
+  const int per = (((d.E + NT - 1) / NT) + 15) & ~15;   // envs per thread, a multiple of 16
+  const int first = tid * per;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  uint32_t cnt = 0;
+  for (int q0 = 0; q0 < per; q0 += 16) {
+    const int e0 = first + q0;
+    if (e0 >= d.E) break;
+    if (e0 + 16 <= d.E) {
+      const uint4 w = *(const uint4*)(next_mask + e0);
+      cnt += __popc(mgx_nonzero_bytes(w.x)) + __popc(mgx_nonzero_bytes(w.y)) + __popc(mgx_nonzero_bytes(w.z)) + __popc(mgx_nonzero_bytes(w.w));
+    } else {
+      for (int q = 0; q < 16 && e0 + q < d.E; q++) cnt += next_mask[e0 + q] ? 1u : 0u;
+    }
   }
+  uint32_t incl = cnt;
+  for (int o = 1; o < MGX_WAVE; o <<= 1) { const uint32_t v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+  if (lane == MGX_WAVE - 1) s_wsum[wave] = incl;
+  __syncthreads();
+  uint32_t off = incl - cnt;
+  for (int q = 0; q < wave && q < NWV; q++) off += s_wsum[q];
+  if (cnt)   // (a few dozen threads per step: second pass over the own bytes, 64 envs per trip)
+    for (int q0 = 0; q0 < per && first + q0 < d.E; q0 += 64) {
+      const int e0 = first + q0;
+      if (e0 + 64 <= d.E) {
+        uint32_t w[16];
+        for (int v = 0; v < 4; v++) {
+          const uint4 x = *(const uint4*)(next_mask + e0 + 16 * v);
+          w[4 * v] = x.x; w[4 * v + 1] = x.y; w[4 * v + 2] = x.z; w[4 * v + 3] = x.w;
+        }
+        for (int v = 0; v < 16; v++)
+          for (uint32_t m = mgx_nonzero_bytes(w[v]); m; m &= m - 1) done_list[off++] = e0 + 4 * v + ((__ffs(m) - 1) >> 3);
+      } else {
+        for (int q = 0; q < 64 && e0 + q < d.E; q++) if (next_mask[e0 + q]) done_list[off++] = e0 + q;
+      }
+    }
 #endif
 }
 

@@ -61,6 +61,7 @@ def load_lib():
     L.mgx_chain_world.argtypes = [vp, vp]
     L.mgx_wait_before_outputs.argtypes = [vp, vp]
     L.mgx_set_joint_actions.argtypes = [vp, vp, i32, vp, i32]
+    L.mgx_poll_action_errors.argtypes = [vp, i32, C.POINTER(C.c_uint32), C.POINTER(i64), C.POINTER(i32)]
     L.mgx_get_buffers.argtypes = [vp] + [C.POINTER(vp)] * 6 + [C.POINTER(i32)]
     L.mgx_get_episode_rewards.argtypes = [vp, vp]
     L.mgx_get_action_success.argtypes = [vp, vp]
@@ -206,6 +207,13 @@ class BatchedMettaGrid:
         ``joint``: contiguous int32 CUDA tensor [E*A]; call ``wait_for_caller()`` first if it was written on another stream."""
         ids = np.ascontiguousarray(np.asarray(vibe_ids, dtype=np.int32))
         _check(self.L.mgx_set_joint_actions(self.h, joint.data_ptr(), int(num_primary), ids.ctypes.data if ids.size else None, int(ids.size)))
+
+    def poll_action_errors(self, wait: bool = False):
+        """(flags, row, value) of the range check ``set_joint_actions`` makes on the device (include/mgx.h
+        mgx_poll_action_errors): flags 0 = all ids seen so far were in range.  ``wait=False`` does not synchronise."""
+        flags, row, value = C.c_uint32(0), C.c_int64(-1), C.c_int32(0)
+        _check(self.L.mgx_poll_action_errors(self.h, 1 if wait else 0, C.byref(flags), C.byref(row), C.byref(value)))
+        return flags.value, row.value, value.value
 
     def chain_world_after(self, other: "BatchedMettaGrid | None") -> None:
         """From now on this engine's world-update kernels start only when ``other``'s most recent ones have finished

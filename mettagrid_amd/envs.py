@@ -131,8 +131,11 @@ class MettaGridBatchedEnv:
     Engine seeds: ``seed_fn(base, env, episode)`` (default: the seed given to ``reset`` plus the env index, constant
     across auto-resets like the reference's ``_current_seed``).
 
-    With device buffers the returned tensors are ordered on the caller's current torch stream (no host synchronisation);
-    ``validate_actions=False`` also skips the reference's range checks on the action tensor, which need a host read.
+    With device buffers the returned tensors are ordered on the caller's current torch stream (no host synchronisation).
+    ``validate_actions``: ``True`` — the reference's range checks on the action tensor are made by the decode kernel on the
+    device and a bad id raises the reference's ValueError from a LATER ``step`` / ``check_actions()`` call (no host read on the
+    good path; 1-D int32 tensors — other layouts take the host-synchronous path); ``"strict"`` — checked on the host before
+    the step runs, as the reference does (a device->host read per check); ``False`` — no check.
 
     ``infos`` (the last element of what ``step`` returns): the reference's wrapper returns, from the step that ends an episode
     on, the dict StatsTracker.on_episode_end built (stats_tracker.py:26-76: ``game``, ``agent``, ``per_agent``, ``attributes``
@@ -306,6 +309,17 @@ class MettaGridBatchedEnv:
             eng.request_episode_stats()
         return out
 
+    def check_actions(self, wait: bool = True) -> None:
+        """Raise the reference's ValueError for a joint action id the device-side decode found out of range
+        (mettagrid_puffer_env.py:336-360).  ``step`` calls this with ``wait=False`` (no synchronisation: an error surfaces at
+        a later step, the offending ids having been played as invalid actions); call it with ``wait=True`` for certainty."""
+        flags, row, value = self.engine.poll_action_errors(wait)
+        if flags & 1:
+            raise ValueError(f"Actions must be non-negative, got {value} for agent {row}")
+        if flags & 2:
+            n, v = len(self.action_names), len(self.vibe_action_names)
+            raise ValueError(f"Action indices out of range [0, {n + n * v if v else n}), got {value} for agent {row}")
+
     def episode_infos(self) -> list:
         """The episodes that finished since the last call, one dict each in the reference's shape (stats_tracker.py:26-76):
         ``game``, ``agent``, ``per_agent`` (with ``log_per_agent``), ``episode_rewards``, ``attributes`` (seed, map_w, map_h,
@@ -337,10 +351,13 @@ class MettaGridBatchedEnv:
         if self._kind == "device":
             import torch
             a = actions if isinstance(actions, torch.Tensor) else torch.as_tensor(np.asarray(actions), device=eng.obs.device)
-            if self.supervisor is None and not self.validate_actions and a.ndim == 1 and a.dtype == torch.int32 and a.is_contiguous():
-                # one kernel on the engine's stream instead of a dozen elementwise torch kernels
+            if self.supervisor is None and self.validate_actions != "strict" and a.ndim == 1 and a.dtype == torch.int32 and a.is_contiguous():
+                # one kernel on the engine's stream instead of a dozen elementwise torch kernels; it also makes the reference's
+                # range checks (mettagrid_puffer_env.py:336-360) and raises a flag the host reads without synchronising
                 if tuple(a.shape) != tuple(eng.actions.shape):
                     raise ValueError(f"Expected {tuple(eng.actions.shape)} actions, got {tuple(a.shape)}")
+                if self.validate_actions:
+                    self.check_actions(wait=False)      # a bad id of an EARLIER step whose kernel has run by now
                 eng.wait_for_caller()
                 eng.set_joint_actions(a, len(self.action_names), self._vibe_ids_host)
             else:

@@ -325,7 +325,7 @@ def test_joint_action_decode_on_device_matches_host_rules():
     prog = compile_spec(presets.rung3_spec(), 32, 32, max_objects=192)
     pool = random_class_maps(prog, 32, 32, {"wall": 40, "extractor": 8, "chest": 4}, {"red": 8, "blue": 8}, range(4))
     E = 6
-    envs = [MettaGridBatchedEnv(prog, E, map_pool=pool, validate_actions=v, seed=5) for v in (False, True)]
+    envs = [MettaGridBatchedEnv(prog, E, map_pool=pool, validate_actions=v, seed=5) for v in (False, "strict", True)]
     for env in envs:
         env.reset()
     n = envs[0].transport_action_n
@@ -341,8 +341,29 @@ def test_joint_action_decode_on_device_matches_host_rules():
         a = torch.from_numpy(rng.randint(0, n, envs[0].num_agents).astype(np.int32)).cuda()
         outs = [env.step(a) for env in envs]
         torch.cuda.synchronize()
-        for x, y in zip(outs[0][:4], outs[1][:4]):
-            assert torch.equal(x, y), t
+        for other in outs[1:]:
+            for x, y in zip(outs[0][:4], other[:4]):
+                assert torch.equal(x, y), t
+    # the reference's range checks (mettagrid_puffer_env.py:336-360): on the host before the step ("strict"), or by the decode
+    # kernel with the error raised by a later call (True)
+    bad = torch.from_numpy(rng.randint(0, n, envs[0].num_agents).astype(np.int32)).cuda()
+    bad[37] = n + 3
+    bad[11] = n
+    with pytest.raises(ValueError, match="out of range"):
+        envs[1].step(bad)
+    envs[2].step(bad)                      # played with invalid action indices; flagged on the device
+    with pytest.raises(ValueError, match=r"out of range \[0, %d\), got %d for agent 11" % (n, n)):
+        envs[2].check_actions()
+    envs[2].check_actions()                # reported once
+    bad[5] = -2
+    envs[2].step(bad)
+    torch.cuda.synchronize()
+    envs[2].engine.sync()
+    with pytest.raises(ValueError, match="non-negative"):
+        envs[2].step(bad.clamp(min=0, max=n - 1))     # a later step sees the flag without waiting for anything
+    envs[2].check_actions()
+    envs[0].step(bad)                      # validate_actions=False: never raises
+    envs[0].check_actions.__self__.engine.poll_action_errors(True)
     for env in envs:
         env.close()
 
