@@ -248,10 +248,23 @@ enum {
 int mgx_set_profiling(mgx_engine* e, int32_t enabled);
 int mgx_get_step_timing(mgx_engine* e, float* ms_out /* [MGX_T_COUNT] */);
 
+/* Code specialised for THIS engine's program at run time.  The build specialises two kernels for the benchmark presets (the
+ * lean world kernel with straight-line handler code, the observation kernel with the shape as compile-time constants:
+ * mgx_handler_variant / mgx_obs_variant 3, 4, 5); for any other program the host can generate the same two units
+ * (csrc/mgx_jit_world.hip, csrc/mgx_jit_obs.hip; mettagrid_amd/jit.py drives hipcc --genco into a cache) and hand the code
+ * object to the engine, which loads it (hipModuleLoad), checks that it was built against this library's headers and for
+ * this program (handler-table fingerprint / observation shape) and launches it from the next mgx_step on (variant 9).
+ * Lean programs only.  Call between steps from the thread that steps the engine.  Results are identical: the generated
+ * code is the interpreter's statement sequence with the operands folded in.  No reference counterpart (the reference
+ * interprets handler objects built from the config: cpp/src/mettagrid/handler/handler.cpp:76-103). */
+enum { MGX_CODE_WORLD = 1, MGX_CODE_OBS = 2 };
+int mgx_attach_code(mgx_engine* e, int32_t kind, const char* code_object_path);
+
 /* Shape queries. */
 /* Which instance of the observation kernel the engine launches: 0 = the generic one (shape read at run time), 3 = the
  * instance compiled for the shape of BASELINE.json configs[2] (mettagrid_amd/gen_presets.py), 5 = the same shape with an
- * episode length set (max_steps read at run time). Diagnostic. */
+ * episode length set (max_steps read at run time), 9 = an instance compiled for this program at run time (mgx_attach_code).
+ * Diagnostic. */
 int32_t mgx_obs_variant(const mgx_engine* e);
 /* How the action dispatch of MettaGrid::_step (mettagrid_c.cpp:966-999) is executed: 0 = one lane per env, agents one
  * after another; 1 = one lane per agent, in rounds ordered by the agents' cell footprints (mgx_act.h) — chosen at
@@ -259,8 +272,11 @@ int32_t mgx_obs_variant(const mgx_engine* e);
 int32_t mgx_act_variant(const mgx_engine* e);
 /* Which code runs the handlers of the action phase: 0 = the interpreter; 3 / 4 = the straight-line code the build generated
  * for BASELINE.json configs[2] / configs[3] (mettagrid_amd/gen_handlers.py), selected when the program's handler tables
- * hash to the preset's fingerprint.  Same results. Diagnostic. */
+ * hash to the preset's fingerprint; 9 = code generated for this program at run time (mgx_attach_code).  Same results.
+ * Diagnostic. */
 int32_t mgx_handler_variant(const mgx_engine* e);
+/* 1: the world kernels keep the program in LDS (which of the two kernels of a world code object mgx_attach_code needs). */
+int32_t mgx_world_prog_in_lds(const mgx_engine* e);
 int32_t mgx_num_envs(const mgx_engine* e);
 int32_t mgx_num_agents(const mgx_engine* e);   /* per env */
 int32_t mgx_num_tokens(const mgx_engine* e);

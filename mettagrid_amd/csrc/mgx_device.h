@@ -152,7 +152,11 @@ struct MgxDev {
 // the launching engine's table (content compare; a change first waits for the kernels still reading the old content),
 // so two engines alive in one process (train + eval) do not disturb each other.
 #ifdef MGX_CONST_DEV
+#ifdef MGX_JIT_UNIT   // a code object loaded at run time (mgx_jit_world.hip): the host reaches the symbol through hipModuleGetGlobal
+__constant__ MgxDev g_mgx_dev;
+#else
 static __constant__ MgxDev g_mgx_dev;
+#endif
 #endif
 
 template <class D> __device__ __forceinline__ const int32_t* mgx_cls(const D& d, int cls) {

@@ -295,6 +295,16 @@ struct mgx_engine {
   bool auto_reset = false;
   int pool_stride = 1;
   uint32_t step_seq = 0;
+  // code objects specialised for this engine's program at run time (mgx_attach_code; mettagrid_amd/jit.py)
+  struct Jit {
+    hipModule_t mod = nullptr;
+    hipFunction_t f0 = nullptr, f1 = nullptr;   // world: the kernel for this engine's prog_in_lds; obs: with / without rewards
+    void* dev_sym = nullptr;                     // world: address of the module's g_mgx_dev
+    MgxDev dev_host{};                           // ... and what it holds
+    bool dev_valid = false;
+    int epg = 0, threads = 0;
+  } jit_world, jit_obs;
+  unsigned long long handler_fp = 0;  // FNV-1a of the handler tables (gen_handlers.py fingerprint())
   int32_t* d_done_list = nullptr;   // [E] the envs of d_next_mask in ascending order (mgx_episode_end_kernel) ...
   uint32_t* d_done_n = nullptr;     // [1] ... and how many: what the restart and episode-statistics kernels walk
   // episode-end statistics (mgx_set_episode_stats; csrc/mgx_episode.h)
@@ -375,8 +385,10 @@ static int size_obs_lds(mgx_engine* e) {
   }
   e->lds_obs = lds_for(e->obs_ew);
   if (const char* pad = getenv("MGX_OBS_LDS_PAD")) e->lds_obs += (size_t)atoi(pad);   // (occupancy experiments: unused LDS behind the layout)
+  const bool keep_jit = e->obs_variant == 9 && e->jit_obs.mod && e->lds_obs <= 64 * 1024;   // (the shape does not depend on the pool size)
   e->obs_variant = 0;
-  if (!getenv("MGX_OBS_GENERIC")) {
+  if (keep_jit) e->obs_variant = 9;
+  else if (!getenv("MGX_OBS_GENERIC")) {
     if (!d.X && e->obs_blk_lds && mgx_obs_shape_matches<MgxObsShapeR3>(d, e->obs_blk_words, (e->rewards_early ? 1 : e->rewards_mid ? 2 : 0))) e->obs_variant = 3;
     else if (!d.X && e->obs_blk_lds && mgx_obs_shape_matches<MgxObsShapeR3AnyLength>(d, e->obs_blk_words, (e->rewards_early ? 1 : e->rewards_mid ? 2 : 0))) e->obs_variant = 5;   // same shape, max_steps set
     // (an instance for the shape of configs[3], MgxObsShapeR4, was measured too: 5.07 ms against the generic kernel's 5.01 —
@@ -437,6 +449,37 @@ static void launch_obs_t(mgx_engine* e, bool with_rewards, const uint8_t* mask, 
     hipLaunchKernelGGL((mgx_obs_kernel<true, X, PL, NTH, EW, K>), grid, block, e->lds_obs, e->stream, dd, e->pool_tokens, e->pool_prefix, mask, e->obs_blk_start, e->obs_blk_words, (e->rewards_early ? 1 : e->rewards_mid ? 2 : 0), (void*)nullptr, (const float*)nullptr, 0, 0, ll, ln, l.passes);
   else
     hipLaunchKernelGGL((mgx_obs_kernel<false, X, PL, NTH, EW, K>), grid, block, e->lds_obs, e->stream, dd, e->pool_tokens, e->pool_prefix, mask, e->obs_blk_start, e->obs_blk_words, (e->rewards_early ? 1 : e->rewards_mid ? 2 : 0), (void*)nullptr, (const float*)nullptr, 0, 0, ll, ln, l.passes);
+}
+// The observation kernel of a run-time code object: same arguments as mgx_obs_kernel, through hipModuleLaunchKernel.
+static int launch_obs_jit(mgx_engine* e, bool with_rewards, const uint8_t* mask, const MgxList& l) {
+  const bool listed = !with_rewards && l.list;
+  MgxDev dd = e->d;
+  for (int k = MGX_SEC_INV_FEATURES; k < MGX_SEC_WORDLIST; k++) dd.sec[k] -= e->obs_blk_start;   // (PL: relative to the LDS copy)
+  int pool_tokens = e->pool_tokens, pool_prefix = e->pool_prefix, blk_start = e->obs_blk_start, blk_words = e->obs_blk_words;
+  int rmode = e->rewards_early ? 1 : e->rewards_mid ? 2 : 0, zero = 0, passes = l.passes;
+  void* box = nullptr;
+  const float* scale = nullptr;
+  const uint8_t* m = listed ? nullptr : mask;
+  const int32_t* ll = listed ? l.list : nullptr;
+  const uint32_t* ln = listed ? l.n : nullptr;
+  void* params[] = {&dd, &pool_tokens, &pool_prefix, &m, &blk_start, &blk_words, &rmode, &box, &scale, &zero, &zero, &ll, &ln, &passes};
+  const unsigned grid = listed ? list_grid(e, l, 128, 2048) : (unsigned)e->d.E;
+  HIP_TRY(hipModuleLaunchKernel(with_rewards ? e->jit_obs.f0 : e->jit_obs.f1, grid, 1, 1, (unsigned)e->jit_obs.threads, 1, 1, (unsigned)e->lds_obs,
+                                e->stream, params, nullptr));
+  return MGX_OK;
+}
+// The lean world kernel of a run-time code object: its MgxDev lives in the module's constant memory.
+static int launch_world_jit(mgx_engine* e, int prog_words) {
+  mgx_engine::Jit& j = e->jit_world;
+  if (!j.dev_valid || memcmp(&j.dev_host, &e->d, sizeof(MgxDev)) != 0) {
+    memcpy(&j.dev_host, &e->d, sizeof(MgxDev));   // (stream-ordered: the kernels still reading the old content are ahead of the copy)
+    HIP_TRY(hipMemcpyAsync(j.dev_sym, &j.dev_host, sizeof(MgxDev), hipMemcpyHostToDevice, e->stream));
+    j.dev_valid = true;
+  }
+  void* params[] = {&prog_words};
+  const unsigned grid = (unsigned)((e->d.E + j.epg - 1) / j.epg);
+  HIP_TRY(hipModuleLaunchKernel(j.f0, grid, 1, 1, (unsigned)j.threads, 1, 1, (unsigned)e->lds_world, e->stream, params, nullptr));
+  return MGX_OK;
 }
 // Device-memory copy of e->d, brought up to date (stream-ordered) whenever the host table changed.
 static const MgxDev* dev_copy(mgx_engine* e) {
@@ -502,6 +545,11 @@ static int launch_obs(mgx_engine* e, bool with_rewards, const uint8_t* mask = nu
                             e->box_C, e->box_dtype, with_rewards ? nullptr : l.list, l.n, (int)list_grid(e, l, 128, 2048), l.passes))
       return fail(MGX_ERR_PROGRAM, "mgx_step: no dense-output instance of the observation kernel for this configuration");
     HIP_TRY(hipGetLastError());
+    return MGX_OK;
+  }
+  if (e->obs_variant == 9) {   // the instance compiled for this program at run time (mgx_attach_code)
+    int jrc = launch_obs_jit(e, with_rewards, mask, l);
+    if (jrc) return jrc;
     return MGX_OK;
   }
   // a program whose shape equals a preset's runs that preset's instance of the kernel (shape = compile-time constants)
@@ -982,6 +1030,7 @@ int mgx_create(const int32_t* program, size_t program_words, const uint16_t* cla
       mix(C[MGX_C_ON_USE]); mix(C[MGX_C_ON_AFTER_USE]); mix(C[MGX_C_ON_TICK]);
     }
     mix(P[MGX_H_GAME_ON_TICK]);
+    e->handler_fp = h;
     d.gen_prog = getenv("MGX_NO_GEN") ? 0 : (!d.X && h == MGX_GEN_R3_FP) ? 3 : (d.X && h == MGX_GEN_R4_FP) ? 4 : 0;
     if (getenv("MGX_VERBOSE")) fprintf(stderr, "[mgx] handler code: %s\n", d.gen_prog ? "generated for this program at build()" : "interpreter");
   }
@@ -1226,6 +1275,8 @@ void mgx_destroy(mgx_engine* e) {
   if (e->d_objs) (void)hipFree(e->d_objs);
   if (e->h_flags) (void)hipHostFree(e->h_flags);
   if (e->h_act_err) (void)hipHostFree(e->h_act_err);
+  if (e->jit_world.mod) (void)hipModuleUnload(e->jit_world.mod);
+  if (e->jit_obs.mod) (void)hipModuleUnload(e->jit_obs.mod);
   free_episode_stats(e);
   for (int i = 0; i <= MGX_T_COUNT; i++) if (e->ev[i]) (void)hipEventDestroy(e->ev[i]);
   if (e->world_done) (void)hipEventDestroy(e->world_done);
@@ -1544,6 +1595,68 @@ int mgx_get_episodes(mgx_engine* e, uint32_t* episodes, int32_t* map_index) {
   return MGX_OK;
 }
 
+int mgx_attach_code(mgx_engine* e, int32_t kind, const char* path) {
+  if (!e || !path) return fail(MGX_ERR_BAD_ARG, "mgx_attach_code: null argument");
+#ifdef MGX_CPU_EMU
+  return fail(MGX_ERR_BAD_ARG, "mgx_attach_code: not part of the sanitizer build");
+#else
+  HIP_TRY(hipSetDevice(e->device));
+  const MgxDev& d = e->d;
+  if (kind != MGX_CODE_WORLD && kind != MGX_CODE_OBS) return fail(MGX_ERR_BAD_ARG, "mgx_attach_code: unknown kind");
+  if (d.X) return fail(MGX_ERR_PROGRAM, "mgx_attach_code: run-time code objects exist for lean programs only");
+  mgx_engine::Jit& j = kind == MGX_CODE_WORLD ? e->jit_world : e->jit_obs;
+  if (j.mod) return fail(MGX_ERR_BAD_ARG, "mgx_attach_code: a code object of this kind is attached already");
+  hipModule_t mod = nullptr;
+  hipError_t he = hipModuleLoad(&mod, path);
+  if (he != hipSuccess) return fail(MGX_ERR_HIP, std::string("mgx_attach_code: hipModuleLoad(") + path + "): " + hipGetErrorString(he));
+  auto refuse = [&](const std::string& why) { (void)hipModuleUnload(mod); return fail(MGX_ERR_PROGRAM, "mgx_attach_code: " + why); };
+  auto read_sym = [&](const char* name, void* dst, size_t bytes) -> bool {
+    hipDeviceptr_t p = nullptr;
+    size_t n = 0;
+    if (hipModuleGetGlobal(&p, &n, mod, name) != hipSuccess || n < bytes) return false;
+    return hipMemcpy(dst, p, bytes, hipMemcpyDeviceToHost) == hipSuccess;
+  };
+  if (kind == MGX_CODE_WORLD) {
+    if (d.act_par) return refuse("the engine runs the lane-per-agent dispatch (MGX_ACT_LEAN), not the kernel this code object replaces");
+    unsigned long long info[8] = {};
+    if (!read_sym("mgx_jit_info", info, sizeof info) || info[0] != 0x4D47584A49545731ull) return refuse("not a world code object");
+    if (info[1] != sizeof(MgxDev) || info[6] != (unsigned long long)MGX_VERSION) return refuse("built against other headers than this libmgx");
+    if (info[4] != e->handler_fp) {
+      char buf[96];
+      snprintf(buf, sizeof buf, " (code object %016llx, engine %016llx)", info[4], e->handler_fp);
+      return refuse(std::string("generated for another program (handler tables differ)") + buf);
+    }
+    if (e->lds_world > 64 * 1024) return refuse("the kernel needs more than 64 KiB of LDS");
+    hipDeviceptr_t sym = nullptr;
+    size_t n = 0;
+    if (hipModuleGetGlobal(&sym, &n, mod, "g_mgx_dev") != hipSuccess || n != sizeof(MgxDev)) return refuse("no g_mgx_dev symbol of the right size");
+    if (hipModuleGetFunction(&j.f0, mod, e->prog_in_lds ? "mgx_jit_world_pl" : "mgx_jit_world_pg") != hipSuccess)
+      return refuse(std::string("no ") + (e->prog_in_lds ? "mgx_jit_world_pl" : "mgx_jit_world_pg") + " kernel");
+    j.dev_sym = sym; j.epg = (int)info[2]; j.threads = (int)info[3]; j.dev_valid = false;
+    j.mod = mod;
+    e->d.gen_prog = (int)info[5];
+  } else {
+    long long info[24] = {};
+    if (!read_sym("mgx_jit_obs_info", info, sizeof info) || info[0] != 0x4D47584A49544F31ll) return refuse("not an observation code object");
+    if (info[1] != (long long)sizeof(MgxDev) || info[4] != MGX_VERSION) return refuse("built against other headers than this libmgx");
+    if (!e->obs_blk_lds || e->box_dtype != MGX_BOX_OFF) return refuse("the engine does not run the lean token-row kernel with the program block in LDS");
+    const long long* K = info + 5;   // H, W, A, S, T, NOFF, BASE, NOV, NT, NRW, FLAGS, MAX_STEPS, BLKW, MASK_FEAT, REWARDS_EARLY
+    const int rmode = e->rewards_early ? 1 : e->rewards_mid ? 2 : 0;
+    const bool same = d.H == K[0] && d.W == K[1] && d.A == K[2] && d.S == K[3] && d.T == K[4] && d.NOFF == K[5] && d.base == K[6] &&
+                      d.n_obs_values == K[7] && d.NT == K[8] && d.NRW == K[9] && d.flags == K[10] && (K[11] < 0 || d.max_steps == K[11]) &&
+                      e->obs_blk_words == K[12] && d.aoe_mask_feat == K[13] && rmode == K[14];
+    if (!same) return refuse("compiled for another observation shape");
+    if (e->lds_obs > 64 * 1024) return refuse("the kernel needs more than 64 KiB of LDS");
+    if (hipModuleGetFunction(&j.f0, mod, "mgx_jit_obs_r") != hipSuccess || hipModuleGetFunction(&j.f1, mod, "mgx_jit_obs_n") != hipSuccess)
+      return refuse("kernels missing");
+    j.threads = (int)info[2];
+    j.mod = mod;
+    e->obs_variant = 9;
+  }
+  return MGX_OK;
+#endif
+}
+
 int mgx_set_episode_stats(mgx_engine* e, int32_t enabled, int32_t log_capacity, int32_t log_per_agent) {
   if (!e) return fail(MGX_ERR_BAD_ARG, "mgx_set_episode_stats: null engine");
   HIP_TRY(hipSetDevice(e->device));
@@ -1695,7 +1808,8 @@ int mgx_step(mgx_engine* e) {
       if (d.act_par) {
         mgx_launch_act_fast_s0(e->prog_in_lds, e->lds_act, e->stream, e->d, pw);   // (one constant-memory copy: an opt-in path)
       } else {
-        if (e->slot == 0) mgx_launch_world_fast_s0(e->prog_in_lds, e->lds_world, e->stream, e->d, pw);
+        if (e->jit_world.mod) { int jrc = launch_world_jit(e, pw); if (jrc) return jrc; }
+        else if (e->slot == 0) mgx_launch_world_fast_s0(e->prog_in_lds, e->lds_world, e->stream, e->d, pw);
         else mgx_launch_world_fast_s1(e->prog_in_lds, e->lds_world, e->stream, e->d, pw);
       }
       MGX_MARK(1); MGX_MARK(2); MGX_MARK(3);
@@ -2144,6 +2258,7 @@ int mgx_get_step_timing(mgx_engine* e, float* ms_out) {
 int32_t mgx_obs_variant(const mgx_engine* e) { return e ? e->obs_variant : 0; }
 int32_t mgx_act_variant(const mgx_engine* e) { return e ? e->d.act_par : 0; }
 int32_t mgx_handler_variant(const mgx_engine* e) { return e ? e->d.gen_prog : 0; }
+int32_t mgx_world_prog_in_lds(const mgx_engine* e) { return e && e->prog_in_lds ? 1 : 0; }
 int32_t mgx_num_envs(const mgx_engine* e) { return e ? e->d.E : 0; }
 int32_t mgx_num_agents(const mgx_engine* e) { return e ? e->d.A : 0; }
 int32_t mgx_num_tokens(const mgx_engine* e) { return e ? e->d.T : 0; }

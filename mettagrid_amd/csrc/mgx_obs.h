@@ -257,12 +257,11 @@ template <bool WITH_REWARDS, bool X, bool PL, int NTH, int EW, class K, bool BOX
 static __device__ __forceinline__ void mgx_obs_env(const MgxDev& d, const int env, uint8_t* smem, int pool_tokens, int pool_prefix,
                                                    const uint8_t* env_mask, int blk_start, int blk_words_arg, int rewards_early_arg,
                                                    void* box_out, const float* box_scale, int box_C, int box_dtype, int stat_passes);
-template <bool WITH_REWARDS, bool X, bool PL, int NTH = MGX_OBS_THREADS, int EW = NTH / MGX_WAVE, class K = MgxObsShapeDyn, bool BOX = false>
-__global__ void __launch_bounds__(NTH) mgx_obs_kernel(MgxDev d, int pool_tokens, int pool_prefix, const uint8_t* env_mask,
-                                                                  int blk_start, int blk_words_arg, int rewards_early_arg,
-                                                                  void* box_out, const float* box_scale, int box_C, int box_dtype,
-                                                                  const int32_t* env_list, const uint32_t* env_list_n, int stat_passes) {
-  MGX_KERNARG_ENTRY(d);
+// The kernel's body (also what the run-time specialised code objects wrap: mgx_jit_obs.hip).
+template <bool WITH_REWARDS, bool X, bool PL, int NTH, int EW, class K, bool BOX>
+static __device__ __forceinline__ void mgx_obs_run(const MgxDev& d, int pool_tokens, int pool_prefix, const uint8_t* env_mask, int blk_start,
+                                                   int blk_words_arg, int rewards_early_arg, void* box_out, const float* box_scale, int box_C,
+                                                   int box_dtype, const int32_t* env_list, const uint32_t* env_list_n, int stat_passes) {
   extern __shared__ __align__(16) uint8_t smem[];
   const bool listed = !WITH_REWARDS && env_list != nullptr;   // (constant false in the instances the step launches)
   const int n_listed = listed ? (int)*env_list_n : 0;
@@ -273,6 +272,15 @@ __global__ void __launch_bounds__(NTH) mgx_obs_kernel(MgxDev d, int pool_tokens,
     if (!listed) break;
     __syncthreads();   // the next env's staging overwrites this one's LDS
   }
+}
+template <bool WITH_REWARDS, bool X, bool PL, int NTH = MGX_OBS_THREADS, int EW = NTH / MGX_WAVE, class K = MgxObsShapeDyn, bool BOX = false>
+__global__ void __launch_bounds__(NTH) mgx_obs_kernel(MgxDev d, int pool_tokens, int pool_prefix, const uint8_t* env_mask,
+                                                                  int blk_start, int blk_words_arg, int rewards_early_arg,
+                                                                  void* box_out, const float* box_scale, int box_C, int box_dtype,
+                                                                  const int32_t* env_list, const uint32_t* env_list_n, int stat_passes) {
+  MGX_KERNARG_ENTRY(d);
+  mgx_obs_run<WITH_REWARDS, X, PL, NTH, EW, K, BOX>(d, pool_tokens, pool_prefix, env_mask, blk_start, blk_words_arg, rewards_early_arg, box_out,
+                                                    box_scale, box_C, box_dtype, env_list, env_list_n, stat_passes);
 }
 template <bool WITH_REWARDS, bool X, bool PL, int NTH, int EW, class K, bool BOX>
 static __device__ __forceinline__ void mgx_obs_env(const MgxDev& d, const int env, uint8_t* smem, int pool_tokens, int pool_prefix,

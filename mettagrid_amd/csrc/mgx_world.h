@@ -178,6 +178,7 @@ struct MgxValueStack {
 
 template <class Env> struct MgxGenR3;   // generated at build(): mgx_handlers_gen.h
 template <class Env> struct MgxGenR4;
+template <class Env> struct MgxGenJ;    // generated at run time for the program at hand (mettagrid_amd/jit.py): MGX_GEN_HEADER
 template <class PP, bool X>
 struct MgxEnvT {  // per-lane view of one env
   typedef PP ProgPtr;
@@ -2233,7 +2234,10 @@ __device__ __forceinline__ void mgx_world_entry(const MgxDev& d, int prog_words,
 
 
 #ifdef MGX_GEN_HANDLERS
-#include "mgx_handlers_gen.h"
+#ifndef MGX_GEN_HEADER
+#define MGX_GEN_HEADER "mgx_handlers_gen.h"
+#endif
+#include MGX_GEN_HEADER
 #endif
 }  // namespace MGX_TU_NS
 using namespace MGX_TU_NS;

@@ -89,7 +89,9 @@ def load_lib():
     L.mgx_count_objects_with_tag.argtypes = [vp, i32, i32, C.POINTER(i32)]
     L.mgx_set_profiling.argtypes = [vp, i32]
     L.mgx_get_step_timing.argtypes = [vp, vp]
-    for name in ("mgx_num_envs", "mgx_num_agents", "mgx_num_tokens", "mgx_obs_variant", "mgx_act_variant", "mgx_handler_variant"):
+    L.mgx_attach_code.argtypes = [vp, i32, C.c_char_p]
+    for name in ("mgx_num_envs", "mgx_num_agents", "mgx_num_tokens", "mgx_obs_variant", "mgx_act_variant", "mgx_handler_variant",
+                 "mgx_world_prog_in_lds"):
         getattr(L, name).argtypes = [vp]
         getattr(L, name).restype = i32
     L.mgx_state_bytes.argtypes = [vp]
@@ -122,7 +124,12 @@ class BatchedMettaGrid:
     ``buffers="host"``: numpy arrays; actions are uploaded and results downloaded on every step (PCIe-inclusive).
     """
 
-    def __init__(self, prog: Program, class_maps: np.ndarray, seeds, device: int = 0, buffers: str = "device") -> None:
+    def __init__(self, prog: Program, class_maps: np.ndarray, seeds, device: int = 0, buffers: str = "device",
+                 specialize="auto") -> None:
+        """``specialize``: compile the world / observation kernels for THIS program in the background and switch to them when
+        they are ready (mettagrid_amd/jit.py; results are identical).  ``"auto"``: for batches of at least 1 024 envs whose
+        program is not one the build already specialised; ``"async"`` / ``"sync"`` (wait in the constructor): always;
+        ``False``: never."""
         self.L = load_lib()
         self.prog = prog
         cm = np.ascontiguousarray(class_maps, dtype=np.uint16)
@@ -175,6 +182,41 @@ class BatchedMettaGrid:
                                                  self.actions, self.vibe_actions)), mem_kind=0)
         else:
             raise ValueError("buffers must be 'device' or 'host'")
+        self._jit_jobs, self.jit_errors = [], []
+        if specialize and (specialize != "auto" or self.E >= 1024):
+            self._start_jit(wait=specialize == "sync")
+
+    # ---- run-time specialisation (include/mgx.h mgx_attach_code) ----
+    def _start_jit(self, wait: bool = False) -> None:
+        from . import jit
+        if not jit.enabled():
+            return
+        kinds = [k for k, have in (("world", self.handler_variant != 0 or self.act_variant != 0), ("obs", self.obs_variant != 0)) if not have]
+        if kinds:
+            self._jit_jobs = jit.start(self.prog, bool(self.L.mgx_world_prog_in_lds(self.h)), kinds)
+        if wait:
+            for j in self._jit_jobs:
+                j.wait()
+        self._poll_jit()
+
+    def _poll_jit(self) -> None:
+        from . import jit
+        for j in list(self._jit_jobs):
+            if not j.ready():
+                continue
+            self._jit_jobs.remove(j)
+            if j.error is None:
+                rc = self.L.mgx_attach_code(self.h, jit.KINDS[j.kind], j.path.encode())
+                if rc != 0:
+                    j.error = self.L.mgx_last_error().decode()
+            if j.error is not None:   # the generic kernels stay: slower, same results
+                self.jit_errors.append((j.kind, j.error))
+                if os.environ.get("MGX_VERBOSE"):
+                    print(f"[mgx] run-time specialisation of the {j.kind} kernel failed: {j.error}", flush=True)
+
+    def jit_pending(self) -> bool:
+        """True while a code object for this engine is still compiling (``step`` attaches it when it is done)."""
+        return bool(self._jit_jobs)
 
     def _bind(self, obs, term, trunc, rew, act, vact, mem_kind: int, rows=None, tokens=None) -> None:
         _check(self.L.mgx_set_buffers(self.h, obs, term, trunc, rew, act, vact,
@@ -194,6 +236,8 @@ class BatchedMettaGrid:
 
     # ---- stepping ----
     def step(self, check_errors: bool = False) -> None:
+        if self._jit_jobs:
+            self._poll_jit()
         _check(self.L.mgx_step(self.h))
         if check_errors:
             self.raise_env_errors()

@@ -10,6 +10,7 @@ from mettagrid_amd.compiler import UnsupportedFeature, compile_spec, observation
 from mettagrid_amd.fmt import K
 from mettagrid_amd.mapgen import random_class_maps
 from mettagrid_amd.umap import UMap, from_pydict
+import helpers as hp
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -231,3 +232,23 @@ def test_handler_generator_is_deterministic_and_header_is_current():
     assert a == b and fa == fb
     assert open(gen_handlers.OUT).read() == a
     assert "MGX_GEN_R3_FP" in fa and "MGX_GEN_R4_FP" in fa and "0x0000000000000000" not in fa
+
+
+def test_jit_plan_and_observation_unit_compiles(tmp_path, monkeypatch):
+    """mettagrid_amd/jit.py: lean programs get a world and an observation code object, extended ones none; the observation
+    unit (seconds to compile) goes through hipcc --genco here, the world unit (minutes) on the GPU box (tests/test_gpu_jit.py)."""
+    from mettagrid_amd import jit, presets
+    monkeypatch.setenv("MGX_JIT_CACHE", str(tmp_path))
+    spec_f, map_f, _, _ = hp.SCENARIOS["torture"]
+    prog = compile_spec(spec_f(), *map_f(0).shape)
+    plan = jit.plan(prog)
+    assert sorted(plan) == ["obs", "world"] and all(str(tmp_path) in plan[k][0] for k in plan)
+    assert "MgxGenJ" in plan["world"][2][1] and any(a.startswith("-DMGX_JIT_FP=0x") for a in plan["world"][1])
+    r4 = compile_spec(presets.rung4_spec(), 64, 64, max_objects=presets.RUNG4_MAX_OBJECTS)
+    assert jit.plan(r4) == {}
+    (job,) = jit.start(prog, True, kinds=("obs",))
+    assert job.wait(600) and job.error is None, job.error
+    blob = open(job.path, "rb").read()
+    assert b"mgx_jit_obs_r" in blob and b"mgx_jit_obs_n" in blob and b"mgx_jit_obs_info" in blob
+    (again,) = jit.start(prog, True, kinds=("obs",))     # second request: straight from the cache
+    assert again.ready() and again.path == job.path
