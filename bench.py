@@ -208,17 +208,30 @@ def cpu_leg(rung: int, cpu_steps: int) -> dict:
 
 # ---- the GPU measurement of one rung ---------------------------------------------------------------------------------
 def measure(rung: int, cms: np.ndarray, *, envs: int, steps: int, warmup: int, rounds: int, groups: int, gather_kind: str,
-            rank: int, local_rank: int, world: int, dist) -> dict:
+            rank: int, local_rank: int, world: int, dist, spec=None, generic: bool = False, specialize="auto") -> dict:
+    """spec: another game on the rung's maps (the run-time specialisation leg); generic: the kernels any program gets — no
+    build-time preset instance, no generated handlers (MGX_NO_GEN / MGX_OBS_GENERIC at mgx_create), no run-time code objects."""
     import torch
     from mettagrid_amd.compiler import compile_spec
     from mettagrid_amd.dist import GatherToRoot, shard_seeds
     from mettagrid_amd.groups import EnvGroups
 
-    spec, H, W, S, objs, agents, mapf, desc, per = workload(rung)
-    prog = compile_spec(spec, H, W, max_objects=S)
+    spec0, H, W, S, objs, agents, mapf, desc, per = workload(rung)
+    prog = compile_spec(spec if spec is not None else spec0, H, W, max_objects=S)
     E, A, T = envs, prog.num_agents, prog.num_tokens
     seeds = shard_seeds(rank, world, E)
-    grp = EnvGroups(prog, cms, seeds, device=local_rank, groups=groups)
+    saved = {k: os.environ.get(k) for k in ("MGX_NO_GEN", "MGX_OBS_GENERIC")}
+    if generic:
+        os.environ.update(MGX_NO_GEN="1", MGX_OBS_GENERIC="1")
+    try:
+        grp = EnvGroups(prog, cms, seeds, device=local_rank, groups=groups, specialize=False if generic else specialize)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    variants = {"obs": grp.engines[0].obs_variant, "act": grp.engines[0].act_variant, "handler": grp.engines[0].handler_variant}
     G = groups
 
     # pre-generated actions resident in HBM (protocol of python/src/mettagrid/perf/harness.py:32-34)
@@ -335,7 +348,7 @@ def measure(rung: int, cms: np.ndarray, *, envs: int, steps: int, warmup: int, r
             traffic = None
     return {
         "value": world * E * A * steps / wall, "ms_per_step": wall * 1e3 / steps, "device_ms_per_step": dev_ms / steps,
-        "steps": steps, "warmup": warmup,
+        "steps": steps, "warmup": warmup, "variants": variants,
         "rounds": {"n": len(per_round), "steps_per_round": steps // rounds, "mean": mean * world, "std": std * world, "cv": cv,
                    "unstable": bool(cv > 0.20), "per_gpu": world > 1},
         "kernels_ms": {"world_actions": seg["actions"], "aoe": seg["aoe"], "world_tail": seg["tail"],
@@ -502,6 +515,15 @@ def main() -> None:
         if extras:
             cpu4 = cpu_leg(4, 12000)
 
+    jit_spec = jit_jobs = None
+    jit_t0 = time.perf_counter()
+    if extras:   # the run-time specialisation leg: start its compiles now (child processes), they run beside everything below
+        from mettagrid_amd import jit, presets
+        from mettagrid_amd.compiler import compile_spec
+        jit_spec = presets.rung3_spec(obs_tokens=192, use_attack_mutation=False)   # not a build-time preset: other handlers, other shape
+        if jit.enabled():
+            jit_jobs = jit.start(compile_spec(jit_spec, 32, 32, max_objects=192), True)
+
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the step engine has no CPU fallback")
@@ -515,8 +537,29 @@ def main() -> None:
 
     common = dict(envs=args.envs, groups=args.groups, gather_kind=args.gather, rank=rank, local_rank=local_rank, world=world, dist=dist)
     head = measure(args.rung, cms, steps=args.steps, warmup=args.warmup, rounds=args.rounds, **common)
+    r4 = wrap = gen = jit_leg = long_run = None
+    if extras:
+        # the headline workload over the reference harness' protocol length whatever --steps says
+        # (python/src/mettagrid/perf/harness.py:100-209: >= 1 000 iterations, >= 10 rounds)
+        lr = measure(3, cms, steps=max(1000, args.steps), warmup=max(20, args.warmup), rounds=10, **common)
+        long_run = {k: lr[k] for k in ("value", "ms_per_step", "device_ms_per_step", "steps", "warmup", "rounds", "kernels_ms")}
+        short = dict(steps=min(args.steps, 100), warmup=10, rounds=5)
+        g3 = measure(3, cms, generic=True, **short, **common)
+        gen = {k: g3[k] for k in ("value", "ms_per_step", "steps", "variants", "kernels_ms")}
+        gen["note"] = "same workload on the kernels every program gets: shape read at run time, handler interpreter"
+        # another program (flat damage instead of the Attack mutation, 192 tokens): generic kernels, then the code objects
+        # compiled for it while this bench was running
+        j0 = measure(3, cms, spec=jit_spec, generic=True, **short, **common)
+        if jit_jobs is not None:
+            for j in jit_jobs:
+                j.wait(600)
+            compile_s = time.perf_counter() - jit_t0
+            j1 = measure(3, cms, spec=jit_spec, specialize="sync", **short, **common)
+            jit_leg = {"workload": "rung-3 maps, flat damage instead of the Attack mutation, T = 192 (not a build-time preset)",
+                       "generic": {k: j0[k] for k in ("value", "ms_per_step", "variants", "kernels_ms")},
+                       "specialised": {k: j1[k] for k in ("value", "ms_per_step", "variants", "kernels_ms")},
+                       "code_objects_ready_after_s": compile_s, "errors": [j.error for j in jit_jobs if j.error]}
     del cms
-    r4 = wrap = None
     if extras:
         r4 = measure(4, cms4, steps=args.rung4_steps, warmup=20, rounds=min(5, args.rung4_steps), **common)
         del cms4
@@ -532,8 +575,15 @@ def main() -> None:
             "device_ms_per_step": head["device_ms_per_step"],
             "rounds": head["rounds"],
             "kernels_ms": head["kernels_ms"],
+            "variants": head["variants"],
             "roofline": head["roofline"],
         }
+        if long_run is not None:
+            out["long_run"] = long_run
+        if gen is not None:
+            out["generic"] = gen
+        if jit_leg is not None:
+            out["run_time_specialisation"] = jit_leg
         if cpu is not None:
             out["cpu_baseline"] = cpu
         if r4 is not None:

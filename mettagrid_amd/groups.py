@@ -22,7 +22,7 @@ from .engine import BatchedMettaGrid
 
 
 class EnvGroups:
-    def __init__(self, prog, class_maps, seeds, device: int = 0, groups: int = 2) -> None:
+    def __init__(self, prog, class_maps, seeds, device: int = 0, groups: int = 2, specialize="auto") -> None:
         import torch
         cm = np.ascontiguousarray(class_maps, dtype=np.uint16)
         E = cm.shape[0]
@@ -45,7 +45,8 @@ class EnvGroups:
         for g in range(groups):
             r0, r1 = g * eg * self.A, (g + 1) * eg * self.A
             bufs = {n: getattr(self, n)[r0:r1] for n in ("obs", "terminals", "truncations", "rewards", "actions", "vibe_actions")}
-            self.engines.append(BatchedMettaGrid(prog, cm[g * eg:(g + 1) * eg], seeds[g * eg:(g + 1) * eg], device=device, buffers=bufs))
+            self.engines.append(BatchedMettaGrid(prog, cm[g * eg:(g + 1) * eg], seeds[g * eg:(g + 1) * eg], device=device, buffers=bufs,
+                                                 specialize=specialize))
         if groups > 1:   # ring: world(g) after world(g-1); world(0) of the next step after world(G-1) of this one
             for g in range(groups):
                 self.engines[g].chain_world_after(self.engines[g - 1])
