@@ -88,7 +88,8 @@ int mgx_chain_world(mgx_engine* e, mgx_engine* after);
  * mettagrid_amd/dist.py): the NEXT engine work that writes observations / rewards / terminals / truncations — the
  * observation kernel of the next mgx_step, or an episode restart — first waits for `hip_event` (a hipEvent_t recorded by
  * the caller on any stream of the engine's device).  The world-update kernels of that step are not held back: they do not
- * touch those buffers.  The event must stay alive until that work has been enqueued.  NULL clears a pending wait.  No
+ * touch those buffers.  The event must stay alive until that work has been enqueued.  NULL clears a pending wait; a second
+ * event given while one is pending does not replace it: the engine's stream waits for the pending one at once.  No
  * reference counterpart: the reference's caller and engine share one thread. */
 int mgx_wait_before_outputs(mgx_engine* e, void* hip_event);
 

@@ -526,10 +526,11 @@ static int launch_obs(mgx_engine* e, bool with_rewards, const uint8_t* mask = nu
   (void)with_rewards; (void)mask; (void)l;
   return launch_terr(e);  // sanitizer build: the wavefront-cooperative observation kernel is not emulated
 #endif
+  const bool terr_fresh = e->terr_fresh;   // (consumed here whatever happens below: a stale "fresh" would skip a needed refresh)
+  e->terr_fresh = false;
   int trc = consume_out_fence(e);
   if (trc) return trc;
-  if (!e->terr_fresh) trc = launch_terr(e);   // (mgx_step already refreshed the maps for the area-effect kernel and nothing since can have changed them)
-  e->terr_fresh = false;
+  if (!terr_fresh) trc = launch_terr(e);   // (mgx_step already refreshed the maps for the area-effect kernel and nothing since can have changed them)
   if (trc) return trc;
   MGX_TRACE_POINT(e, "terr kernel");
   if (e->d.obsval) mgx_launch_values(e->stream, e->d, dev_copy(e), 0, mask);
@@ -1780,6 +1781,7 @@ int mgx_step(mgx_engine* e) {
   HIP_TRY(hipSetDevice(e->device));
   const MgxDev& d = e->d;
   const size_t rows = (size_t)d.E * d.A;
+  e->terr_fresh = false;
   if (e->mem_kind == MGX_MEM_HOST) {
     HIP_TRY(hipMemcpyAsync(e->own_act, e->h_act, rows * 4, hipMemcpyHostToDevice, e->stream));
     HIP_TRY(hipMemcpyAsync(e->own_vact, e->h_vact, rows * 4, hipMemcpyHostToDevice, e->stream));
@@ -1893,6 +1895,12 @@ int mgx_chain_world(mgx_engine* e, mgx_engine* after) {
 
 int mgx_wait_before_outputs(mgx_engine* e, void* hip_event) {
   if (!e) return fail(MGX_ERR_BAD_ARG, "mgx_wait_before_outputs: null engine");
+  if (e->out_fence && hip_event && e->out_fence != (hipEvent_t)hip_event) {
+    // a second consumer before the next writer: the first one's event is not dropped — the engine's stream waits for it now
+    // (coarser than needed: the world update of the next step waits too)
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamWaitEvent(e->stream, e->out_fence, 0));
+  }
   e->out_fence = (hipEvent_t)hip_event;
   return MGX_OK;
 }

@@ -890,8 +890,8 @@ static __device__ __forceinline__ void mgx_obs_env(const MgxDev& d, const int en
     if constexpr (BOX) {
       // ---- the agent's dense box from its staging row: the cell values are stored over the zeros the whole workgroup
       // streamed out at the start of the kernel (waited for in front of the first barrier).  Tokens that share a cell are
-      // adjacent in a row this kernel built (the tag tokens of one object): the first lane of such a run adds the rest in
-      // token order. ----
+      // adjacent in a row this kernel built (the tag tokens of one object) — the first lane of such a run adds the rest in
+      // token order — except a global token and a same-feature token of the centre object (below). ----
       const bool f32 = box_dtype == MGX_BOX_F32;
       const int Hh = 2 * hr + 1, Ww = 2 * wr + 1, cells = box_C * Hh * Ww;
       const int bytes = cells * (f32 ? 4 : 2);
@@ -906,9 +906,23 @@ static __device__ __forceinline__ void mgx_obs_env(const MgxDev& d, const int en
         if (key == 0xFFFFFFFFu) continue;
         if (k > 0 && key_of(s_row[k - 1]) == key) continue;   // a later token of a run: its first lane adds it
         const int f = (int)((key >> 8) & 0xFFu), y = (int)((key >> 4) & 0xFu), x = (int)(key & 0xFu);
+        const bool global_tok = (tok & 0xFFu) == 0xFEu;
+        // The one way two tokens of a key are NOT neighbours: a global token (location 0xFE, counted on the centre cell; the
+        // globals lead the row) and a token of the object ON the centre cell with the same feature id.  np.add.at
+        // (grid_obs_wrapper.py:57-95) adds them in token order, so the global token's lane adds every later match and
+        // a centre-cell token that finds its key among the leading globals leaves the cell to that lane.
+        if (!global_tok && (key & 0xFFu) == (uint32_t)((hr << 4) | wr)) {
+          bool taken = false;
+          for (int j = 0; j < k && (s_row[j] & 0xFFu) == 0xFEu; j++) taken = taken || key_of(s_row[j]) == key;
+          if (taken) continue;
+        }
         const float sc = box_scale[f];
         float sum = __fdiv_rn((float)((tok >> 16) & 0xFFu), sc);
-        for (int j = k + 1; j < T && key_of(s_row[j]) == key; j++) sum = __fadd_rn(sum, __fdiv_rn((float)((s_row[j] >> 16) & 0xFFu), sc));
+        if (global_tok) {
+          for (int j = k + 1; j < T; j++) if (key_of(s_row[j]) == key) sum = __fadd_rn(sum, __fdiv_rn((float)((s_row[j] >> 16) & 0xFFu), sc));
+        } else {
+          for (int j = k + 1; j < T && key_of(s_row[j]) == key; j++) sum = __fadd_rn(sum, __fdiv_rn((float)((s_row[j] >> 16) & 0xFFu), sc));
+        }
         if (y < Hh && x < Ww && f < box_C) {
           const int cellidx = (f * Hh + y) * Ww + x;
           if (f32) {

@@ -196,6 +196,7 @@ struct MgxEnvT {  // per-lane view of one env
   mutable int grid_dirty;           // a grid cell was written since do_move last looked at the move target
 #ifdef MGX_ACT_TU
   int act_pos = 0;  // this lane's place in the order the reference walks the agents in (shuffled order / agent index)
+  mutable uint32_t act_seq = 0;   // game-stat SETs this lane has made in this tick (the later of two sets by one agent wins)
   // StatsMutation on a game-scope stat from concurrently running agents: the set of the LAST agent in order must win.
   // Each set goes to a per-env LDS cell as (position + 1) << 32 | value bits under a 64-bit max; mgx_act_body applies the
   // surviving value when the phase is over.  (The host only selects this kernel when nothing reads those stats mid-phase.)
@@ -205,7 +206,10 @@ struct MgxEnvT {  // per-lane view of one env
   __device__ __forceinline__ void act_gstat_set(int id, float v) const {
     int k = 0;
     while (k < d.act_ngset - 1 && d.act_gset_ids[k] != id) k++;
-    const unsigned long long w = ((unsigned long long)(act_pos + 1) << 32) | (unsigned long long)__float_as_uint(v);
+    // key: order position, then this lane's set count — game_stats->set is last-write-wins (stats_tracker.hpp), so of two
+    // sets by the same agent in one chain (on_use, then on_after_use) the later one must survive, not the larger bit pattern
+    const uint32_t seq = act_seq < 255u ? act_seq++ : 255u;
+    const unsigned long long w = ((unsigned long long)(act_pos + 1) << 40) | ((unsigned long long)seq << 32) | (unsigned long long)__float_as_uint(v);
     atomicMax(act_gset_cells() + k * MGX_WORLD_EPG + mgx_world_lane(), w);
   }
 #endif

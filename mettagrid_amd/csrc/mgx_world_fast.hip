@@ -26,6 +26,8 @@
 #endif
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 
@@ -72,12 +74,24 @@ size_t mgx_world_fast_lds_bytes(int A) { return (size_t)mgx_world_lds_fixed(A, f
 // Keeps this slot's g_mgx_dev equal to the launching engine's MgxDev.  A change of content first waits for the kernels
 // that still read the old content (another engine on the same slot, or re-bound buffers).
 static std::mutex g_dev_mutex;
-static MgxDev g_dev_host;
-static bool g_dev_valid = false;
+static MgxDev g_dev_host_dev[16];     // the __constant__ symbol exists once per DEVICE: one host image for each
+static bool g_dev_valid_dev[16] = {false};
+static bool g_thrash_warned = false;
 void MGX_CAT(mgx_launch_world_fast_s, MGX_SLOT)(bool prog_lds, size_t lds, hipStream_t stream, const MgxDev& d, int prog_words) {
   std::lock_guard<std::mutex> lock(g_dev_mutex);
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+  MgxDev& g_dev_host = g_dev_host_dev[dev];
+  bool& g_dev_valid = g_dev_valid_dev[dev];
   if (!g_dev_valid || memcmp(&g_dev_host, &d, sizeof(MgxDev)) != 0) {
-    if (g_dev_valid) (void)hipDeviceSynchronize();
+    if (g_dev_valid) {
+      (void)hipDeviceSynchronize();
+      if (!g_thrash_warned && getenv("MGX_VERBOSE")) {   // two engines alternating on one slot pay a device-wide wait per step
+        fprintf(stderr, "[mgx] %s: the constant-memory engine table of device %d changed (another engine on the same slot, or re-bound "
+                        "buffers): device synchronised before the upload\n", __func__, dev);
+        g_thrash_warned = true;
+      }
+    }
     (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_mgx_dev), &d, sizeof(MgxDev), 0, hipMemcpyHostToDevice, stream);
     memcpy(&g_dev_host, &d, sizeof(MgxDev));
     g_dev_valid = true;

@@ -268,7 +268,7 @@ class BatchedMettaGrid:
         """The next engine work that writes observations / rewards / terminals / truncations waits for ``event`` (a recorded
         ``torch.cuda.Event``, kept alive here until then); the next step's world update does not (include/mgx.h
         mgx_wait_before_outputs).  Used by ``dist.GatherToRoot`` to order a step behind the staging copy of the previous one."""
-        self._out_fence = event
+        self._out_fences = (getattr(self, "_out_fences", []) + [event])[-4:]   # (several consumers: none is freed while pending)
         _check(self.L.mgx_wait_before_outputs(self.h, C.c_void_p(event.cuda_event)))
 
     def reset_envs(self, env_mask, class_maps=None, seeds=None) -> None:
@@ -652,12 +652,14 @@ class BatchedMettaGrid:
 
     @property
     def obs_variant(self) -> int:
-        """0: generic observation kernel; 3: the instance compiled for the shape of BASELINE.json configs[2] (gen_presets.py)."""
+        """0: generic observation kernel; 3: the instance compiled for the shape of BASELINE.json configs[2] (gen_presets.py);
+        5: that shape with an episode length read at run time; 9: an instance compiled for this program at run time (jit.py)."""
         return int(self.L.mgx_obs_variant(self.h))
 
     @property
     def handler_variant(self) -> int:
-        """0: handler interpreter; 3 / 4: code generated at build() for the rung-3 / rung-4 preset (gen_handlers.py)."""
+        """0: handler interpreter; 3 / 4: code generated at build() for the rung-3 / rung-4 preset (gen_handlers.py); 9: code
+        generated for this program at run time (jit.py)."""
         return int(self.L.mgx_handler_variant(self.h))
 
     @property

@@ -69,6 +69,25 @@ def test_crowded_lean_arena(monkeypatch):
     _against_oracle(prog, cms, np.arange(E, dtype=np.uint32) + 77, 60, 5, "crowded lean arena", 1)
 
 
+def test_two_game_stat_sets_in_one_chain(monkeypatch):
+    """on_use sets a game stat to a LARGE value, the actor's on_after_use sets it to a SMALL one: game_stats->set is
+    last-write-wins, so the small value must survive on the lane-per-agent kernel too (its per-env cell orders the sets by
+    (order position, set count), not by bit pattern)."""
+    from mettagrid_amd import spec as S
+    monkeypatch.setenv("MGX_ACT_LEAN", "1")
+    spec = presets.rung3_spec()
+    A_, T_ = S.ACTOR, S.TARGET
+    spec.objects["chest"].on_use = S.Handler([], [S.SetStat("chest.mark", S.ConstValue(1000.0), scope="game", entity=T_)], "mark_big")
+    for ag in spec.agents:
+        ag.on_after_use = S.Handler([], [S.SetStat("chest.mark", S.SumValue([S.InventoryValue("laser")], [1.0]), scope="game", entity=A_)],
+                                    "mark_small")
+    prog = compile_spec(spec, 11, 11, max_objects=192)
+    E = 12
+    maps = [random_map(11, 11, {"wall": 3, "extractor": 2, "chest": 6}, {"red": 8, "blue": 8}, 40 + s) for s in range(E)]
+    cms = np.stack([prog.class_map(m) for m in maps])
+    _against_oracle(prog, cms, np.arange(E, dtype=np.uint32) + 9, 40, 8, "double game-stat set", 1)
+
+
 def test_crowded_extended_arena():
     """BASELINE.json configs[3] rules (64 agents, four teams) squeezed into 20x20: AoE, territory and events run behind a
     dispatch in which a third of the agents conflict with somebody every step."""

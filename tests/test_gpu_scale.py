@@ -19,9 +19,13 @@ from mettagrid_amd.mapgen import random_class_maps
 pytestmark = pytest.mark.gpu
 
 
-def _run_and_check(E, sample, steps, seed0=0, rung=3, actions=None, obs_tokens=None):
+def _run_and_check(E, sample, steps, seed0=0, rung=3, actions=None, obs_tokens=None, generic=False):
     import torch
-    if rung == 3:
+    if rung == 2:
+        spec = presets.rung2_spec()
+        prog = compile_spec(spec, 32, 32, max_objects=192)
+        cms = np.stack([prog.class_map(presets.rung2_map(seed0 + e)) for e in range(E)])
+    elif rung == 3:
         spec = presets.rung3_spec()
         prog = compile_spec(spec, 32, 32, max_objects=192)
         cms = random_class_maps(prog, 32, 32, {"wall": 40, "extractor": 8, "chest": 4}, {"red": 8, "blue": 8},
@@ -35,7 +39,7 @@ def _run_and_check(E, sample, steps, seed0=0, rung=3, actions=None, obs_tokens=N
             cms = cms[np.arange(E) % distinct]
     A, T = prog.num_agents, prog.num_tokens
     seeds = np.arange(seed0, seed0 + E, dtype=np.uint32)
-    eng = BatchedMettaGrid(prog, cms, seeds, buffers="device")
+    eng = BatchedMettaGrid(prog, cms, seeds, buffers="device", specialize=False)
     oracles = {i: op.OracleSim(prog, cms[i], int(seeds[i])) for i in sample}
     for o in oracles.values():
         o.reinit_buffers()
@@ -69,7 +73,9 @@ def _run_and_check(E, sample, steps, seed0=0, rung=3, actions=None, obs_tokens=N
         check(t + 1)
     bits, first = eng.poll_errors()
     assert bits == 0, (bits, first)
-    if obs_tokens is None and E >= 150:   # configs[2] at its own shape runs the specialised observation kernel
+    if generic:
+        assert (eng.obs_variant, eng.handler_variant) == (0, 0), (eng.obs_variant, eng.handler_variant)
+    elif obs_tokens is None and E >= 150 and rung != 2:   # configs[2] at its own shape runs the specialised observation kernel
         assert eng.obs_variant == (3 if rung == 3 else 0), eng.obs_variant
     return eng, T
 
@@ -92,6 +98,41 @@ def test_full_size_sampled_parity_and_row_wellformedness():
     # every agent sees at least its global tokens and itself
     assert (~empty[:, 0]).all().item()
     assert torch.isfinite(eng.rewards).all().item()
+
+
+@pytest.mark.parametrize("rung", [3, 4])
+def test_full_size_generic_kernels_against_the_oracle(rung, monkeypatch):
+    """The kernels ANY program gets — observation shape read at run time, handler interpreter — at BASELINE's full size against
+    the oracle (the specialised instances are what the two tests around this one run)."""
+    monkeypatch.setenv("MGX_NO_GEN", "1")
+    monkeypatch.setenv("MGX_OBS_GENERIC", "1")
+    sample = [0, 63, 64, 4097, 32767, 32768, 50001, 65535]
+    _run_and_check(65536, sample, steps=3, rung=rung, generic=True)
+
+
+def test_rung2_4096_envs_first_32_envs_128_steps():
+    """SURVEY.md 8d rung 2 (BASELINE.json configs[1]): 4 096 envs x 32x32, 16 agents, move + change_vibe; the first 32 envs
+    against the oracle after every one of 128 steps, then the state digest of ALL 4 096 envs against envs replayed on the
+    oracle's side of the engine boundary (same engine code, 32-env batches cannot hide a cross-env leak at 4 096)."""
+    import torch
+    eng, _ = _run_and_check(4096, list(range(32)), steps=128, rung=2)
+    big = eng.state_digests()
+    # the same 4 096 envs, stepped in batches of 512 with the same action stream: equal digests env by env
+    prog = eng.prog
+    A, n_act = prog.num_agents, len(prog.action_names)
+    cms = np.stack([prog.class_map(presets.rung2_map(e)) for e in range(4096)])
+    for b0 in range(0, 4096, 512):
+        part = BatchedMettaGrid(prog, cms[b0:b0 + 512], np.arange(b0, b0 + 512, dtype=np.uint32), buffers="device", specialize=False)
+        rng = np.random.default_rng(1234)
+        for t in range(128):
+            a = rng.integers(-1, n_act + 1, size=4096 * A).astype(np.int32)
+            v = rng.integers(0, n_act, size=4096 * A).astype(np.int32)
+            part.actions.copy_(torch.from_numpy(a[b0 * A:(b0 + 512) * A]))
+            part.vibe_actions.copy_(torch.from_numpy(v[b0 * A:(b0 + 512) * A]))
+            torch.cuda.synchronize()
+            part.step()
+        assert np.array_equal(part.state_digests(), big[b0:b0 + 512]), b0
+        part.close()
 
 
 def test_rung4_boundaries():
