@@ -630,9 +630,14 @@ const char* mgx_last_error(void) { return g_err.c_str(); }
 #define MGX_LAUNCH_INIT(stream, dc, maps, mi, sd, mask, l) hipLaunchKernelGGL(mgx_init_kernel, dim3((d.E + MGX_WAVE - 1) / MGX_WAVE), dim3(MGX_WAVE), 0, stream, dc, maps, mi, sd, mask)
 #else
 #define MGX_LAUNCH_INIT(stream, dc, maps, mi, sd, mask, l)                                                                          \
-  hipLaunchKernelGGL(mgx_init_wave_kernel, dim3((l).list ? list_grid(e, (l), 128, 2048) : (unsigned)d.E),                                  \
-                     dim3((unsigned)std::min(MGX_INIT_THREADS, std::max(MGX_WAVE, (d.H * d.W + MGX_WAVE - 1) / MGX_WAVE * MGX_WAVE))), 0, stream, dc, maps, mi, sd, \
-                     (l).list ? (const uint8_t*)nullptr : (mask), (l).list, (l).n)
+  do {                                                                                                                              \
+    const bool listed_ = (l).list != nullptr && (l).n_host < 0;   /* a list of unknown length: seeded inside the kernel */             \
+    if (!listed_) hipLaunchKernelGGL(mgx_seed_mt_kernel, dim3((unsigned)((d.E + 255) / 256)), dim3(256), 0, stream, dc, sd, mask);    \
+    hipLaunchKernelGGL(mgx_init_wave_kernel, dim3((l).list ? list_grid(e, (l), 128, 2048) : (unsigned)d.E),                          \
+                       dim3((unsigned)std::min(MGX_INIT_THREADS, std::max(MGX_WAVE, (d.H * d.W + MGX_WAVE - 1) / MGX_WAVE * MGX_WAVE))), 0, \
+                       stream, dc, maps, mi, listed_ ? (sd) : (const uint32_t*)nullptr, (l).list ? (const uint8_t*)nullptr : (mask),  \
+                       (l).list, (l).n);                                                                                             \
+  } while (0)
 #endif
 static std::mutex g_live_mu;
 static std::vector<mgx_engine*> g_live;  // engines between mgx_create and mgx_destroy

@@ -2428,6 +2428,23 @@ __global__ void __launch_bounds__(MGX_WAVE) mgx_init_kernel(const MgxDev* __rest
 #define MGX_INIT_MAX_PASSES 1024   // maps up to 255 x 255 = 1 017 passes of 64 cells
 static __device__ void mgx_init_wave_env(const MgxDev& d, const int env, const uint16_t* class_maps, const int32_t* map_index,
                                          const uint32_t* seeds, uint16_t* s_occ, uint16_t* s_ag, int* s_tot);
+// std::mt19937(seed) (bits/random.tcc seed()) of whole batches: one LANE per env, so that the 624 stores of a wavefront
+// are 256 contiguous bytes each (the state is env-minor: [word][env]).  Construction of all envs and masked restarts use it
+// (the in-kernel seeding of mgx_init_wave_kernel writes one 4-byte word per 64-byte line and env: 8 GB of partial-line
+// writes for 65 536 envs); list-driven restarts of a few dozen envs keep the in-kernel form, which hides behind the rest.
+__global__ void __launch_bounds__(256) mgx_seed_mt_kernel(const MgxDev* __restrict__ dp, const uint32_t* __restrict__ seeds,
+                                                          const uint8_t* __restrict__ env_mask) {
+  const MgxDev& d = *dp;
+  const int env = blockIdx.x * blockDim.x + threadIdx.x;
+  if (env >= d.E || (env_mask && !env_mask[env])) return;
+  const size_t E = (size_t)d.E;
+  uint32_t x = seeds[env];
+  d.mt[env] = x;
+  for (uint32_t i = 1; i < 624; i++) {
+    x = 1812433253u * (x ^ (x >> 30)) + i;
+    d.mt[i * E + env] = x;
+  }
+}
 __global__ void __launch_bounds__(MGX_INIT_THREADS) mgx_init_wave_kernel(const MgxDev* __restrict__ dp, const uint16_t* class_maps,
                                                                          const int32_t* map_index, const uint32_t* seeds,
                                                                          const uint8_t* env_mask, const int32_t* env_list,
@@ -2540,8 +2557,8 @@ static __device__ void mgx_init_wave_env(const MgxDev& d, const int env, const u
   __threadfence_block();   // the objects written by other wavefronts are read below
   __syncthreads();
   const int nobj = min(s_tot[0], d.S), nag = min(s_tot[1], d.A);
-  if (tid == (int)blockDim.x - 1) {   // std::mt19937(seed): bits/random.tcc seed() — beside the registration pass below
-    uint32_t x = seeds[env];
+  if (tid == (int)blockDim.x - 1 && seeds) {   // std::mt19937(seed): bits/random.tcc seed() — beside the registration pass below
+    uint32_t x = seeds[env];   // (seeds == nullptr: mgx_seed_mt_kernel has done it)
     d.mt[env] = x;
     for (uint32_t i = 1; i < 624; i++) {
       x = 1812433253u * (x ^ (x >> 30)) + i;
