@@ -249,6 +249,7 @@ def measure(rung: int, cms: np.ndarray, *, envs: int, steps: int, warmup: int, r
         # the step that next writes the gathered buffers is ordered behind the staging copy: only its observation kernel
         # waits (mgx_wait_before_outputs), the world update runs beside the copy
         gather = GatherToRoot(dist, root=0, device=torch.device("cuda", local_rank), producer_stream=ext,
+                              packed=("observations",) if gather_kind == "obs-packed" else (),
                               output_fence=grp.wait_before_outputs)
 
     def one_step(t: int, only=None) -> None:
@@ -267,7 +268,7 @@ def measure(rung: int, cms: np.ndarray, *, envs: int, steps: int, warmup: int, r
                     ev.record(exts[g])
                     ext.wait_event(ev)
             out = {"rewards": grp.rewards, "terminals": grp.terminals, "truncations": grp.truncations}
-            if gather_kind == "obs":
+            if gather_kind in ("obs", "obs-packed"):
                 out["observations"] = grp.obs
             gather.submit(out)
 
@@ -474,7 +475,7 @@ def main() -> None:
     ap.add_argument("--rounds", type=int, default=10, help="the timed steps are reported as this many rounds (mean / std / CV)")
     ap.add_argument("--envs", type=int, default=65536, help="envs per GPU")
     ap.add_argument("--rung", type=int, default=3, help="3 = BASELINE.json configs[2] (the headline metric), 4 = configs[3]")
-    ap.add_argument("--gather", choices=["none", "scalars", "obs"], default="none",
+    ap.add_argument("--gather", choices=["none", "scalars", "obs", "obs-packed"], default="none",
                     help="optional per-step gather of rewards/terminals/truncations (+obs) to rank 0: grouped RCCL "
                          "send/recv over xGMI on a side stream, overlapped with the next step (mettagrid_amd/dist.py)")
     ap.add_argument("--groups", type=int, default=1,

@@ -249,6 +249,22 @@ enum {
 int mgx_set_profiling(mgx_engine* e, int32_t enabled);
 int mgx_get_step_timing(mgx_engine* e, float* ms_out /* [MGX_T_COUNT] */);
 
+/* ---- Packed observation rows for the gather to the trainer rank ------------------------------------------
+ * A row of the observation buffer is a prefix of used tokens followed by 0xFF padding (mettagrid_c.cpp:319-375) and is about
+ * a third full; the per-step gather of BASELINE.json configs[4] is bound by the root's xGMI links, so ranks ship the used
+ * prefixes only: counts u16 [n_rows] and the used tokens back to back, packed u8 [total][3] (row order).  Engine-independent:
+ * raw device pointers and a hipStream_t (as void*); everything is enqueued on that stream.  scratch: device memory of
+ * mgx_pack_scratch_bytes(n_rows) bytes, holding afterwards the 32-bit exclusive token offsets [n_rows + 1] (last = total).
+ * capacity_tokens: room in `packed`; rows that would run past it are dropped and counted (mgx_pack_result).
+ * mgx_pack_result waits for the stream and returns the total / the number of dropped rows.  mgx_unpack_rows is the inverse:
+ * rows u8 [n_rows][n_tokens][3] with their 0xFF padding, byte for byte what was packed.  No reference counterpart. */
+int64_t mgx_pack_scratch_bytes(int64_t n_rows);
+int mgx_pack_rows(const uint8_t* rows, int64_t n_rows, int32_t n_tokens, uint16_t* counts, uint8_t* packed, int64_t capacity_tokens,
+                  uint32_t* scratch, void* hip_stream);
+int mgx_pack_result(const uint32_t* scratch, int64_t n_rows, int64_t* total_tokens, int32_t* overflow_rows, void* hip_stream);
+int mgx_unpack_rows(const uint8_t* packed, const uint16_t* counts, int64_t n_rows, int32_t n_tokens, uint8_t* rows, uint32_t* scratch,
+                    void* hip_stream);
+
 /* Code specialised for THIS engine's program at run time.  The build specialises two kernels for the benchmark presets (the
  * lean world kernel with straight-line handler code, the observation kernel with the shape as compile-time constants:
  * mgx_handler_variant / mgx_obs_variant 3, 4, 5); for any other program the host can generate the same two units

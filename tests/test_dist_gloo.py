@@ -47,15 +47,26 @@ def _worker(rank, world, port, q):
     assert list(shard_seeds(rank, world, E_PER_RANK)) == ids
     steps = _run_envs(ids)
     gather = GatherToRoot(dist, root=0)
+    packed = GatherToRoot(dist, root=0, packed=("observations",))   # the same rows as used prefixes (bench.py --gather obs-packed)
     got = []
     for out in steps:                      # one submit per step, like bench.py --gather obs
-        gather.submit({"rewards": torch.from_numpy(out["rewards"]), "terminals": torch.from_numpy(out["terminals"]),
-                       "truncations": torch.from_numpy(out["truncations"]), "observations": torch.from_numpy(out["obs"])})
+        tensors = {"rewards": torch.from_numpy(out["rewards"]), "terminals": torch.from_numpy(out["terminals"]),
+                   "truncations": torch.from_numpy(out["truncations"]), "observations": torch.from_numpy(out["obs"])}
+        gather.submit(tensors)
         res = gather.result()
         assert (res is None) == (rank != 0)
+        packed.submit(tensors)
+        pres = packed.result()
         if res is not None:
             got.append({k: v.numpy().copy() for k, v in res.items()})
+            # packed mode: same scalars, and the expanded rows are the whole-row gather byte for byte — from a third of the bytes
+            assert torch.equal(pres["rewards"], res["rewards"]) and torch.equal(pres["terminals"], res["terminals"])
+            assert torch.equal(packed.expand("observations"), res["observations"])
+            n_used = int((res["observations"][:, :, 0] != 0xFF).sum())
+            assert pres["observations_packed"].shape == (n_used, 3) and int(pres["observations_counts"].sum()) == n_used
+            assert pres["observations_packed"].numel() < 0.6 * res["observations"].numel()
     gather.finish()
+    packed.finish()
     t = max_over_ranks(dist, 1.0 + rank)
     if rank == 0:
         q.put((got, t))

@@ -13,7 +13,42 @@ pytestmark = pytest.mark.gpu
 E, STEPS = 2048, 10
 
 
-@pytest.mark.parametrize("fence", ["producer_stream", "output_kernels"])
+def test_pack_rows_kernels_round_trip():
+    """mgx_pack_rows / mgx_unpack_rows (csrc/mgx_pack.hip): counts, offsets and bytes against the torch statement of the same
+    thing, on real observation rows and on edge cases (empty rows, full rows, a row count that is not a multiple of anything)."""
+    import torch
+    from mettagrid_amd import presets
+    from mettagrid_amd.compiler import compile_spec
+    from mettagrid_amd.dist import pack_rows, unpack_rows
+    from mettagrid_amd.engine import BatchedMettaGrid
+    from mettagrid_amd.mapgen import random_class_maps
+
+    prog = compile_spec(presets.rung3_spec(), 32, 32, max_objects=192)
+    cms = random_class_maps(prog, 32, 32, {"wall": 40, "extractor": 8, "chest": 4}, {"red": 8, "blue": 8}, range(700))
+    eng = BatchedMettaGrid(prog, cms, np.arange(700, dtype=np.uint32))
+    eng.step()
+    eng.sync()
+    rows = eng.obs.clone()
+    rows[5] = 0xFF                                       # an empty row
+    rows[7, :, :] = 3                                    # a full row (no padding at all)
+    T = rows.shape[1]
+    counts, packed = pack_rows(rows)
+    torch.cuda.synchronize()
+    c_ref, p_ref = pack_rows(rows.cpu())
+    assert torch.equal(counts.cpu(), c_ref) and torch.equal(packed.cpu(), p_ref)
+    assert int(counts[5]) == 0 and int(counts[7]) == T and packed.shape[0] == int(c_ref.to(torch.int64).sum())
+    assert packed.numel() < 0.6 * rows.numel()           # what the gather saves
+    back = unpack_rows(counts, packed, T)
+    torch.cuda.synchronize()
+    assert torch.equal(back, rows)
+    for n in (1, 63, 4097, 11201):                       # across the scan's workgroup boundary (4 096 rows)
+        sub = rows[:n] if n <= rows.shape[0] else rows.repeat(2, 1, 1)[:n]
+        c, p = pack_rows(sub)
+        assert torch.equal(unpack_rows(c, p, T), sub), n
+    eng.close()
+
+
+@pytest.mark.parametrize("fence", ["producer_stream", "output_kernels", "packed"])
 def test_gather_rows_are_the_steps_own(fence):
     import torch
     import torch.distributed as dist
@@ -58,7 +93,8 @@ def test_gather_rows_are_the_steps_own(fence):
         eng = grp.engines[0]
         ext = torch.cuda.ExternalStream(eng.stream, device=torch.device("cuda", 0))
         gather = GatherToRoot(dist, root=0, device=torch.device("cuda", 0), producer_stream=ext, slots=STEPS,
-                              output_fence=grp.wait_before_outputs if fence == "output_kernels" else None)
+                              output_fence=grp.wait_before_outputs if fence in ("output_kernels", "packed") else None,
+                              packed=("observations",) if fence == "packed" else ())
         torch.cuda.synchronize()
         for t in range(STEPS):             # bench.py one_step: nothing here waits for the device
             with torch.cuda.stream(ext):
@@ -71,6 +107,8 @@ def test_gather_rows_are_the_steps_own(fence):
         torch.cuda.synchronize()
         for t in range(STEPS):
             got = gather.result_of(t)
+            if fence == "packed":          # the used prefixes travelled; expanded they are the step's rows byte for byte
+                got = dict(got, observations=gather.expand("observations", t))
             for k in names:
                 assert torch.equal(got[k], want[t][k]), f"{fence}: gathered {k} of step {t} are not step {t}'s rows"
         assert grp.poll_errors()[0] == 0
