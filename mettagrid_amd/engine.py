@@ -90,11 +90,12 @@ def load_lib():
     L.mgx_set_profiling.argtypes = [vp, i32]
     L.mgx_get_step_timing.argtypes = [vp, vp]
     L.mgx_attach_code.argtypes = [vp, i32, C.c_char_p]
-    L.mgx_pack_scratch_bytes.argtypes = [i64]
-    L.mgx_pack_scratch_bytes.restype = i64
-    L.mgx_pack_rows.argtypes = [vp, i64, i32, vp, vp, i64, vp, vp]
-    L.mgx_pack_result.argtypes = [vp, i64, C.POINTER(i64), C.POINTER(i32), vp]
-    L.mgx_unpack_rows.argtypes = [vp, vp, i64, i32, vp, vp, vp]
+    if hasattr(L, "mgx_pack_rows"):   # (absent from the CPU sanitizer build, tests/cpu_emu: wavefront-cooperative kernels)
+        L.mgx_pack_scratch_bytes.argtypes = [i64]
+        L.mgx_pack_scratch_bytes.restype = i64
+        L.mgx_pack_rows.argtypes = [vp, i64, i32, vp, vp, i64, vp, vp]
+        L.mgx_pack_result.argtypes = [vp, i64, C.POINTER(i64), C.POINTER(i32), vp]
+        L.mgx_unpack_rows.argtypes = [vp, vp, i64, i32, vp, vp, vp]
     for name in ("mgx_num_envs", "mgx_num_agents", "mgx_num_tokens", "mgx_obs_variant", "mgx_act_variant", "mgx_handler_variant",
                  "mgx_world_prog_in_lds"):
         getattr(L, name).argtypes = [vp]

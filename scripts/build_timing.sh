@@ -16,6 +16,7 @@ hipcc $F -c $C/mgx_decode.hip -o $O/d.o &
 hipcc $F -c $C/mgx_obs_box.hip -o $O/b.o &
 hipcc $F -DMGX_SLOT=0 -c $C/mgx_act_fast.hip -o $O/af0.o &
 hipcc $F -c $C/mgx_act_x.hip -o $O/ax.o &
+hipcc $F -c $C/mgx_pack.hip -o $O/pk.o &
 for job in $(jobs -p); do wait $job; done
 hipcc --offload-arch=gfx950 -shared -fPIC -o $ROOT/mettagrid_amd/libmgx_timing.so $O/*.o
 echo built libmgx_timing.so

@@ -37,7 +37,9 @@ static inline char2 make_char2(signed char a, signed char b) { return char2{a, b
 extern thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
 
 typedef int hipError_t;
-enum { hipSuccess = 0, hipErrorInvalidValue = 1 };
+enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorNotReady = 600 };
+typedef void* hipModule_t;      // run-time code objects are not part of the sanitizer build (mgx_attach_code refuses)
+typedef void* hipFunction_t;
 typedef struct emu_stream* hipStream_t;
 typedef struct emu_event* hipEvent_t;
 enum { hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3, hipStreamNonBlocking = 1 };
@@ -53,6 +55,9 @@ static inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
 static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
 static inline hipError_t hipMemset(void* p, int v, size_t n) { memset(p, v, n); return hipSuccess; }
 static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, int) { memcpy(d, s, n); return hipSuccess; }
+static inline hipError_t hipModuleUnload(hipModule_t) { return hipSuccess; }
+static inline hipError_t hipModuleLaunchKernel(hipFunction_t, unsigned, unsigned, unsigned, unsigned, unsigned, unsigned, unsigned, hipStream_t, void**, void**) { return hipErrorInvalidValue; }
 template <class T> static inline hipError_t hipMemcpyToSymbolAsync(T& sym, const void* s, size_t n, size_t, int, hipStream_t) { memcpy(&sym, s, n); return hipSuccess; }
 template <class T> static inline hipError_t hipMemcpyToSymbol(T& sym, const void* s, size_t n) { memcpy(&sym, s, n); return hipSuccess; }
 template <class T> static inline hipError_t hipMemcpyFromSymbol(void* d, T& sym, size_t n) { memcpy(d, &sym, n); return hipSuccess; }
@@ -66,6 +71,7 @@ static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e =
 static inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
 static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }
 static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return hipSuccess; }
 static inline hipError_t hipFuncSetAttribute(const void*, int, int) { return hipSuccess; }
 static inline hipError_t hipFuncGetAttributes(hipFuncAttributes* a, const void*) { a->localSizeBytes = 0; return hipSuccess; }
