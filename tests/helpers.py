@@ -480,3 +480,19 @@ def delta_spec() -> S.GameSpec:
 
 
 SCENARIOS["delta"] = (delta_spec, torture_map, 45, False)
+
+
+def reference_infos(prog, o) -> dict:
+    """What StatsTracker.on_episode_end puts into infos for ONE env (python/src/mettagrid/envs/stats_tracker.py:30-47), from
+    an oracle env's stats: the game dict, per key the sum over the agents that hold it in agent order / num_agents (Python
+    floats), the per-agent dicts.  Pinned to the reference's own StatsTracker by tests/test_infos_fixture.py."""
+    A = prog.num_agents
+    sd = sg.stats_dicts(prog, *o.raw_stats(), extra=o.invalid_index_extra())
+    agent = {}
+    for agent_stats in sd["agent"]:
+        for n, v in agent_stats.items():
+            agent[n] = agent.get(n, 0) + v
+    for n, v in agent.items():
+        agent[n] = v / A
+    return {"game": sd["game"], "agent": agent, "per_agent": {str(i): dict(s) for i, s in enumerate(sd["agent"])},
+            "episode_rewards": o.snapshot()["episode_rewards"], "steps": o.current_step}

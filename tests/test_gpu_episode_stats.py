@@ -18,18 +18,7 @@ from mettagrid_amd.signature import stats_dicts
 pytestmark = pytest.mark.gpu
 
 
-def reference_infos(prog, o) -> dict:
-    """What StatsTracker.on_episode_end puts into infos for ONE env (stats_tracker.py:30-47), from the oracle's stats."""
-    A = prog.num_agents
-    sd = stats_dicts(prog, *o.raw_stats(), extra=o.invalid_index_extra())
-    agent = {}
-    for agent_stats in sd["agent"]:
-        for n, v in agent_stats.items():
-            agent[n] = agent.get(n, 0) + v
-    for n, v in agent.items():
-        agent[n] = v / A
-    return {"game": sd["game"], "agent": agent, "per_agent": {str(i): dict(s) for i, s in enumerate(sd["agent"])},
-            "episode_rewards": o.snapshot()["episode_rewards"], "steps": o.current_step}
+from helpers import reference_infos  # noqa: E402  (pinned to the reference's StatsTracker by tests/test_infos_fixture.py)
 
 
 class HostTotals:
