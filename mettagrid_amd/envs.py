@@ -154,7 +154,7 @@ class MettaGridBatchedEnv:
                  seed_fn: Optional[Callable[[int, int, int], int]] = None, device: int = 0, seed: int = 0,
                  buffers: str = "device", map_pool: Optional[np.ndarray] = None, pool_stride: int = 1,
                  desync: bool = False, validate_actions: bool = True, episode_stats: bool = True, stats_interval: int = 1,
-                 episode_log: int = 0, log_per_agent: bool = False) -> None:
+                 episode_log: int = 0, log_per_agent: bool = False, specialize="auto") -> None:
         if (map_fn is None) == (map_pool is None):
             raise ValueError("give exactly one of map_fn and map_pool")
         self.prog = prog
@@ -180,6 +180,7 @@ class MettaGridBatchedEnv:
         self.stats_interval = max(1, int(stats_interval))
         self.episode_log = int(episode_log)
         self.log_per_agent = log_per_agent
+        self.specialize = specialize      # BatchedMettaGrid(specialize=...): run-time code objects for this program (jit.py)
         self._steps = 0
 
     def set_supervisor(self, supervisor) -> None:
@@ -246,12 +247,13 @@ class MettaGridBatchedEnv:
         if self.map_pool is not None:
             M = self.map_pool.shape[0]
             first = self.map_pool[np.arange(self.E) % M]
-            self._eng = BatchedMettaGrid(self.prog, first, self._seeds(), device=self._device, buffers=self._kind)
+            self._eng = BatchedMettaGrid(self.prog, first, self._seeds(), device=self._device, buffers=self._kind,
+                                         specialize=self.specialize)
             self._eng.set_map_pool(self.map_pool)
             self._eng.set_auto_reset(True, self.pool_stride, self.early_end_steps() if self.desync else None)
         else:
             self._eng = BatchedMettaGrid(self.prog, self._maps(range(self.E)), self._seeds(), device=self._device,
-                                         buffers=self._kind)
+                                         buffers=self._kind, specialize=self.specialize)
         if self.episode_stats:
             self._eng.set_episode_stats(True, self.episode_log, self.log_per_agent)
         self._steps = 0

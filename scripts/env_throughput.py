@@ -28,7 +28,8 @@ for validate, stats in ((False, True), (False, False), (True, True)):
     key = ("validate_actions" if validate else "unchecked_actions") + ("" if stats else "_no_episode_stats")
     if only and key not in only:
         continue
-    env = MettaGridBatchedEnv(prog, E, map_pool=pool, pool_stride=7, desync=True, validate_actions=validate, seed=1, episode_stats=stats)
+    env = MettaGridBatchedEnv(prog, E, map_pool=pool, pool_stride=7, desync=True, validate_actions=validate, seed=1, episode_stats=stats,
+                              specialize=os.environ.get("MGX_ENV_SPECIALIZE", "auto"))
     obs, _ = env.reset()
     n = env.transport_action_n   # joint ids: core actions, then (core, vibe) pairs
     gen = torch.Generator(device="cuda").manual_seed(3)
@@ -47,6 +48,7 @@ for validate, stats in ((False, True), (False, False), (True, True)):
     dt = time.perf_counter() - t0
     ep, _ = env.engine.episodes()
     bits, first = env.engine.poll_errors()
+    out[key + "_variants"] = [env.engine.obs_variant, env.engine.handler_variant]
     out[key] = {"agent_steps_per_s": env.num_agents * steps / dt, "ms_per_step": dt * 1e3 / steps,
                 "episodes_finished": int(ep.sum()), "env_error_bits": int(bits), "infos_returned": n_infos, "episodes_in_infos": n_eps}
     env.close()
