@@ -7,7 +7,7 @@ same configs, seeds, actions and set_inventory calls) on the REFERENCE — its P
 attached (python/src/mettagrid/envs/stats_tracker.py:26-76) and caller buffers bound the way ``MettaGridPufferEnv`` binds them
 (mettagrid_puffer_env.py:200-216: a second ``set_buffers``), on the reference C++ engine oracle/_ref — until the episode ends,
 and records what ``on_episode_end`` put into ``infos``: ``game``, ``agent``, ``per_agent``, the episode rewards and the
-attributes that do not depend on the wall clock.  Output: tests/golden/ref_infos_<scenario>.json (data only).
+attributes that do not depend on the wall clock.  Output: tests/golden/infos_<scenario>.json (data only).
 """
 from __future__ import annotations
 
@@ -61,12 +61,12 @@ def run(name: str) -> dict:
 def main() -> None:
     if len(sys.argv) == 3 and sys.argv[1] == "child":
         out = run(sys.argv[2])
-        json.dump(out, open(os.path.join(HERE, f"ref_infos_{sys.argv[2]}.json"), "w"), separators=(",", ":"), sort_keys=True)
+        json.dump(out, open(os.path.join(HERE, f"infos_{sys.argv[2]}.json"), "w"), separators=(",", ":"), sort_keys=True)
         return
     import subprocess
     for name in ("navigation", "chains"):
         subprocess.check_call([sys.executable, os.path.abspath(__file__), "child", name])
-        p = os.path.join(HERE, f"ref_infos_{name}.json")
+        p = os.path.join(HERE, f"infos_{name}.json")
         d = json.load(open(p))
         print(p, os.path.getsize(p), "bytes; ended at step", d["steps_played"], "; game keys", len(d["game"]), "; agent keys", len(d["agent"]))
 

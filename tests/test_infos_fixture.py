@@ -1,4 +1,4 @@
-"""`infos` against the REFERENCE's own StatsTracker.  tests/golden/ref_infos_<scenario>.json holds what
+"""`infos` against the REFERENCE's own StatsTracker.  tests/golden/infos_<scenario>.json holds what
 StatsTracker.on_episode_end (python/src/mettagrid/envs/stats_tracker.py:26-76) put into infos when the reference — its
 Python Simulation on its C++ engine, buffers bound as MettaGridPufferEnv binds them — played the committed action traces
 of ref_navigation / ref_chains to the end of the episode (tests/golden/make_infos_fixture.py).  Here: the oracle replays
@@ -22,7 +22,7 @@ NAMES = ["navigation", "chains"]
 
 def _load(name):
     doc = json.load(open(os.path.join(HERE, "golden", f"ref_{name}.json")))
-    want = json.load(open(os.path.join(HERE, "golden", f"ref_infos_{name}.json")))
+    want = json.load(open(os.path.join(HERE, "golden", f"infos_{name}.json")))
     z = np.load(os.path.join(HERE, "golden", f"ref_{name}.npz"))
     cfg = ref_tree.load(doc["config"])
     prog = from_reference.compile_reference_config(cfg, len(doc["map"]), len(doc["map"][0]))
