@@ -338,12 +338,13 @@ def measure(rung: int, cms: np.ndarray, *, envs: int, steps: int, warmup: int, r
     dom = "obs" if seg["obs"] >= seg["actions"] else "actions"
     bytes_per_agent_step = per["obs"] if dom == "obs" else per["world"]
     achieved = (E // G) * A * bytes_per_agent_step / (seg[dom] * 1e-3) / 1e9
-    traffic, source = None, None
+    traffic, source, valu_frac = None, None, None
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc):
         try:
             pj = json.load(open(pmc))
             traffic = pj.get(f"rung{rung}", {}).get(names[dom] + "_bytes_per_launch")
+            valu_frac = pj.get(f"rung{rung}", {}).get(names[dom] + "_valu_frac")
             source = f"profiles/pmc_traffic.json@{pj.get('build', '?')} (PMC FETCH_SIZE x2 + WRITE_SIZE of a profiled run, not this run)"
         except Exception:
             traffic = None
@@ -356,6 +357,7 @@ def measure(rung: int, cms: np.ndarray, *, envs: int, steps: int, warmup: int, r
                        "mgx_obs_kernel": seg["obs"], "rewards_ext": seg["rewards"]},
         "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                      "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": source,
+                     "valu_frac": valu_frac,   # share of SIMD cycles issuing VALU instructions (same profiled run as `traffic`)
                      "bytes_per_agent_step": bytes_per_agent_step, "tick_bytes_per_agent_step": per["tick"],
                      "kernel_ms": seg[dom]},
         "config": {"workload": desc, "baseline_config": f"configs[{rung - 1}]", "envs_per_gpu": E, "agents_per_env": A,

@@ -30,6 +30,15 @@ for rung in (3, 4):
         for r in rows[1:]:
             if "mgx" in r[0] or "rocclr" in r[0]:   # our kernels + the runtime's copies; torch's one-off generators dropped
                 w.writerow(r)
+    # average kernel durations of the kernel-trace pass (ns), for the issue fractions below
+    dur = {}
+    for r in rows[1:]:
+        if r and r[0].startswith("void mgx_obs_kernel<false"):   # (the initial-observation instance: not the step's kernel)
+            continue
+        try:
+            dur[r[0].replace("void ", "").split("<")[0].split("(")[0].split("::")[-1]] = float(r[3])
+        except (ValueError, IndexError):
+            pass
     t = {}
     for k, v in d.items():
         if "FETCH_SIZE" not in v or k.startswith("void mgx_obs_kernel<false"):   # (the <false> variant: initial observations)
@@ -37,6 +46,11 @@ for rung in (3, 4):
         name = k.replace("void ", "").split("<")[0].split("::")[-1]
         t[name] = {"FETCH_SIZE": v["FETCH_SIZE"], "WRITE_SIZE": v["WRITE_SIZE"]}
         t[name + "_bytes_per_launch"] = (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024
+        if "SQ_INSTS_VALU" in v and dur.get(name) and name != "mgx_terr_kernel":   # (its launches are mostly idle: no meaningful average)
+            # share of all SIMD cycles spent issuing vector-ALU instructions: wave-level VALU instructions x 4 cycles each
+            # (a wave64 instruction occupies its SIMD16 for four cycles) over 1 024 SIMDs x the kernel's duration at the
+            # 2.4 GHz peak engine clock (MI355X_MICROARCH.md) — a LOWER bound when the clock runs below peak
+            t[name + "_valu_frac"] = v["SQ_INSTS_VALU"] * 4.0 / (1024 * dur[name] * 2.4)
     traffic[f"rung{rung}"] = t
     for line in open(os.path.join(src, "trace.log")):
         if line.startswith('{"metric"'):
