@@ -271,10 +271,13 @@ int mgx_unpack_rows(const uint8_t* packed, const uint16_t* counts, int64_t n_row
  * (csrc/mgx_jit_world.hip, csrc/mgx_jit_obs.hip; mettagrid_amd/jit.py drives hipcc --genco into a cache) and hand the code
  * object to the engine, which loads it (hipModuleLoad), checks that it was built against this library's headers and for
  * this program (handler-table fingerprint / observation shape) and launches it from the next mgx_step on (variant 9).
- * Lean programs only.  Call between steps from the thread that steps the engine.  Results are identical: the generated
+ * World / observation units: lean programs; dispatch unit: extended programs.  Call between steps from the thread that
+ * steps the engine.  Results are identical: the generated
  * code is the interpreter's statement sequence with the operands folded in.  No reference counterpart (the reference
  * interprets handler objects built from the config: cpp/src/mettagrid/handler/handler.cpp:76-103). */
-enum { MGX_CODE_WORLD = 1, MGX_CODE_OBS = 2 };
+enum { MGX_CODE_WORLD = 1, MGX_CODE_OBS = 2,
+       MGX_CODE_ACT_X = 3 /* extended programs whose action dispatch runs one lane per agent (mgx_act_variant 1):
+                             csrc/mgx_jit_act_x.hip, the dispatch kernel with the program's handlers as straight-line code */ };
 int mgx_attach_code(mgx_engine* e, int32_t kind, const char* code_object_path);
 
 /* Shape queries. */
@@ -294,6 +297,9 @@ int32_t mgx_act_variant(const mgx_engine* e);
 int32_t mgx_handler_variant(const mgx_engine* e);
 /* 1: the world kernels keep the program in LDS (which of the two kernels of a world code object mgx_attach_code needs). */
 int32_t mgx_world_prog_in_lds(const mgx_engine* e);
+/* 1: the program uses the extended systems (area effects, territory, events, queries, dynamic tags) and runs the extended
+ * kernels; 0: a lean program. */
+int32_t mgx_is_extended(const mgx_engine* e);
 int32_t mgx_num_envs(const mgx_engine* e);
 int32_t mgx_num_agents(const mgx_engine* e);   /* per env */
 int32_t mgx_num_tokens(const mgx_engine* e);

@@ -303,7 +303,7 @@ struct mgx_engine {
     MgxDev dev_host{};                           // ... and what it holds
     bool dev_valid = false;
     int epg = 0, threads = 0;
-  } jit_world, jit_obs;
+  } jit_world, jit_obs, jit_actx;
   unsigned long long handler_fp = 0;  // FNV-1a of the handler tables (gen_handlers.py fingerprint())
   int32_t* d_done_list = nullptr;   // [E] the envs of d_next_mask in ascending order (mgx_episode_end_kernel) ...
   uint32_t* d_done_n = nullptr;     // [1] ... and how many: what the restart and episode-statistics kernels walk
@@ -479,6 +479,16 @@ static int launch_world_jit(mgx_engine* e, int prog_words) {
   void* params[] = {&prog_words};
   const unsigned grid = (unsigned)((e->d.E + j.epg - 1) / j.epg);
   HIP_TRY(hipModuleLaunchKernel(j.f0, grid, 1, 1, (unsigned)j.threads, 1, 1, (unsigned)e->lds_world, e->stream, params, nullptr));
+  return MGX_OK;
+}
+// The extended games' lane-per-agent dispatch of a run-time code object (same geometry as mgx_launch_act_x).
+static int launch_act_x_jit(mgx_engine* e, const MgxDev* dp, int prog_words) {
+  int ap = 1;
+  while (ap < e->d.A) ap <<= 1;
+  const int epg = e->jit_actx.epg;
+  void* params[] = {&dp, &prog_words};
+  HIP_TRY(hipModuleLaunchKernel(e->jit_actx.f0, (unsigned)((e->d.E + epg - 1) / epg), 1, 1, (unsigned)(epg * ap), 1, 1, (unsigned)e->lds_act, e->stream,
+                                params, nullptr));
   return MGX_OK;
 }
 // Device-memory copy of e->d, brought up to date (stream-ordered) whenever the host table changed.
@@ -1285,6 +1295,7 @@ void mgx_destroy(mgx_engine* e) {
   if (e->h_act_err) (void)hipHostFree(e->h_act_err);
   if (e->jit_world.mod) (void)hipModuleUnload(e->jit_world.mod);
   if (e->jit_obs.mod) (void)hipModuleUnload(e->jit_obs.mod);
+  if (e->jit_actx.mod) (void)hipModuleUnload(e->jit_actx.mod);
   free_episode_stats(e);
   for (int i = 0; i <= MGX_T_COUNT; i++) if (e->ev[i]) (void)hipEventDestroy(e->ev[i]);
   if (e->world_done) (void)hipEventDestroy(e->world_done);
@@ -1610,9 +1621,10 @@ int mgx_attach_code(mgx_engine* e, int32_t kind, const char* path) {
 #else
   HIP_TRY(hipSetDevice(e->device));
   const MgxDev& d = e->d;
-  if (kind != MGX_CODE_WORLD && kind != MGX_CODE_OBS) return fail(MGX_ERR_BAD_ARG, "mgx_attach_code: unknown kind");
-  if (d.X) return fail(MGX_ERR_PROGRAM, "mgx_attach_code: run-time code objects exist for lean programs only");
-  mgx_engine::Jit& j = kind == MGX_CODE_WORLD ? e->jit_world : e->jit_obs;
+  if (kind != MGX_CODE_WORLD && kind != MGX_CODE_OBS && kind != MGX_CODE_ACT_X) return fail(MGX_ERR_BAD_ARG, "mgx_attach_code: unknown kind");
+  if ((d.X != 0) != (kind == MGX_CODE_ACT_X))
+    return fail(MGX_ERR_PROGRAM, "mgx_attach_code: world / observation code objects are for lean programs, the dispatch one for extended programs");
+  mgx_engine::Jit& j = kind == MGX_CODE_WORLD ? e->jit_world : kind == MGX_CODE_OBS ? e->jit_obs : e->jit_actx;
   if (j.mod) return fail(MGX_ERR_BAD_ARG, "mgx_attach_code: a code object of this kind is attached already");
   hipModule_t mod = nullptr;
   hipError_t he = hipModuleLoad(&mod, path);
@@ -1624,7 +1636,19 @@ int mgx_attach_code(mgx_engine* e, int32_t kind, const char* path) {
     if (hipModuleGetGlobal(&p, &n, mod, name) != hipSuccess || n < bytes) return false;
     return hipMemcpy(dst, p, bytes, hipMemcpyDeviceToHost) == hipSuccess;
   };
-  if (kind == MGX_CODE_WORLD) {
+  if (kind == MGX_CODE_ACT_X) {
+    if (!d.act_par) return refuse("the engine does not run the lane-per-agent dispatch for this program");
+    unsigned long long info[8] = {};
+    if (!read_sym("mgx_jit_info", info, sizeof info) || info[0] != 0x4D47584A49544131ull) return refuse("not a dispatch code object");
+    if (info[1] != sizeof(MgxDev) || info[6] != (unsigned long long)MGX_VERSION) return refuse("built against other headers than this libmgx");
+    if (info[4] != e->handler_fp) return refuse("generated for another program (handler tables differ)");
+    if ((int)info[2] != mgx_act_x_epg()) return refuse("built for another workgroup shape");
+    if (e->lds_act > 64 * 1024) return refuse("the kernel needs more than 64 KiB of LDS");
+    if (hipModuleGetFunction(&j.f0, mod, "mgx_jit_act_x") != hipSuccess) return refuse("no mgx_jit_act_x kernel");
+    j.epg = (int)info[2];
+    j.mod = mod;
+    e->d.gen_prog = (int)info[5];
+  } else if (kind == MGX_CODE_WORLD) {
     if (d.act_par) return refuse("the engine runs the lane-per-agent dispatch (MGX_ACT_LEAN), not the kernel this code object replaces");
     unsigned long long info[8] = {};
     if (!read_sym("mgx_jit_info", info, sizeof info) || info[0] != 0x4D47584A49545731ull) return refuse("not a world code object");
@@ -1824,7 +1848,8 @@ int mgx_step(mgx_engine* e) {
       MGX_MARK(1); MGX_MARK(2); MGX_MARK(3);
     } else if (e->aoe_local && (d.NF > 0 || d.NM > 0 || d.NT > 0)) {
       if (d.act_par) {
-        mgx_launch_act_x(e->prog_in_lds, e->lds_act, e->stream, e->d, dev_copy_world_x(e), pw);
+        if (e->jit_actx.mod) { int jrc = launch_act_x_jit(e, dev_copy_world_x(e), pw); if (jrc) return jrc; }
+        else mgx_launch_act_x(e->prog_in_lds, e->lds_act, e->stream, e->d, dev_copy_world_x(e), pw);
         if (x_events) mgx_launch_world_x(e->prog_in_lds, e->lds_world, e->stream, e->d, dev_copy_world_x(e), pw, MGX_PH_EVENTS);
       } else {
         mgx_launch_world_x(e->prog_in_lds, e->lds_world, e->stream, e->d, dev_copy_world_x(e), pw, MGX_PH_ACTIONS | MGX_PH_EVENTS);
@@ -1841,7 +1866,8 @@ int mgx_step(mgx_engine* e) {
       MGX_MARK(3);
     } else {
       if (d.act_par) {
-        mgx_launch_act_x(e->prog_in_lds, e->lds_act, e->stream, e->d, dev_copy_world_x(e), pw);
+        if (e->jit_actx.mod) { int jrc = launch_act_x_jit(e, dev_copy_world_x(e), pw); if (jrc) return jrc; }
+        else mgx_launch_act_x(e->prog_in_lds, e->lds_act, e->stream, e->d, dev_copy_world_x(e), pw);
         mgx_launch_world_x(e->prog_in_lds, e->lds_world, e->stream, e->d, dev_copy_world_x(e), pw, MGX_PH_ALL & ~MGX_PH_ACTIONS);
       } else {
         mgx_launch_world_x(e->prog_in_lds, e->lds_world, e->stream, e->d, dev_copy_world_x(e), pw, MGX_PH_ALL);
@@ -2274,6 +2300,7 @@ int32_t mgx_obs_variant(const mgx_engine* e) { return e ? e->obs_variant : 0; }
 int32_t mgx_act_variant(const mgx_engine* e) { return e ? e->d.act_par : 0; }
 int32_t mgx_handler_variant(const mgx_engine* e) { return e ? e->d.gen_prog : 0; }
 int32_t mgx_world_prog_in_lds(const mgx_engine* e) { return e && e->prog_in_lds ? 1 : 0; }
+int32_t mgx_is_extended(const mgx_engine* e) { return e && e->d.X ? 1 : 0; }
 int32_t mgx_num_envs(const mgx_engine* e) { return e ? e->d.E : 0; }
 int32_t mgx_num_agents(const mgx_engine* e) { return e ? e->d.A : 0; }
 int32_t mgx_num_tokens(const mgx_engine* e) { return e ? e->d.T : 0; }

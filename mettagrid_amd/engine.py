@@ -97,7 +97,7 @@ def load_lib():
         L.mgx_pack_result.argtypes = [vp, i64, C.POINTER(i64), C.POINTER(i32), vp]
         L.mgx_unpack_rows.argtypes = [vp, vp, i64, i32, vp, vp, vp]
     for name in ("mgx_num_envs", "mgx_num_agents", "mgx_num_tokens", "mgx_obs_variant", "mgx_act_variant", "mgx_handler_variant",
-                 "mgx_world_prog_in_lds"):
+                 "mgx_world_prog_in_lds", "mgx_is_extended"):
         getattr(L, name).argtypes = [vp]
         getattr(L, name).restype = i32
     L.mgx_state_bytes.argtypes = [vp]
@@ -197,7 +197,10 @@ class BatchedMettaGrid:
         from . import jit
         if not jit.enabled():
             return
-        kinds = [k for k, have in (("world", self.handler_variant != 0 or self.act_variant != 0), ("obs", self.obs_variant != 0)) if not have]
+        if self.L.mgx_is_extended(self.h):   # extended programs: the lane-per-agent dispatch kernel, when the engine runs it
+            kinds = ["actx"] if self.act_variant == 1 and self.handler_variant == 0 and self.L.mgx_world_prog_in_lds(self.h) else []
+        else:
+            kinds = [k for k, have in (("world", self.handler_variant != 0 or self.act_variant != 0), ("obs", self.obs_variant != 0)) if not have]
         if kinds:
             self._jit_jobs = jit.start(self.prog, bool(self.L.mgx_world_prog_in_lds(self.h)), kinds)
         if wait:

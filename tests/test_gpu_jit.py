@@ -85,3 +85,46 @@ def test_code_object_of_another_program_is_refused(tmp_path, monkeypatch):
     assert eng.obs_variant == 0
     eng.step()
     eng.close()
+
+
+def test_extended_dispatch_kernel_specialised_at_run_time(tmp_path, monkeypatch):
+    """An extended program that is not the rung-4 preset (its chests mark a game stat): the lane-per-agent dispatch kernel is
+    compiled with this program's handlers as straight-line code (csrc/mgx_jit_act_x.hip), attached, and must reproduce the
+    oracle and the interpreter-driven kernel."""
+    from mettagrid_amd import presets
+    from mettagrid_amd import spec as S
+    from mettagrid_amd.mapgen import random_map
+    monkeypatch.setenv("MGX_JIT_CACHE", str(tmp_path))
+    spec = presets.rung4_spec(obs_tokens=400)
+    spec.objects["chest"].on_use = S.Handler([S.ResourceFilter(S.ACTOR, "ore", 2)],
+                                             [S.ResourceTransfer(S.ACTOR, S.TARGET, "ore", -2),
+                                              S.SetStat("chest.ore", S.InventoryValue("ore"), scope="game", entity=S.TARGET)], "deposit2")
+    prog = compile_spec(spec, 20, 20, max_objects=presets.RUNG4_MAX_OBJECTS)
+    objs = {"wall": 8, "extractor": 6, "chest": 4, "healer_red": 1, "healer_blue": 1, "healer_green": 1, "healer_yellow": 1,
+            "flag_red": 1, "flag_blue": 1, "flag_green": 1, "flag_yellow": 1, "hub": 1, "wire": 3}
+    E = 6
+    cms = np.stack([prog.class_map(random_map(20, 20, dict(objs), dict(presets.RUNG4_AGENTS), 700 + s)) for s in range(E)])
+    seeds = np.arange(E, dtype=np.uint32) + 21
+    assert sorted(jit.plan(prog)) == ["actx"]
+    eng = BatchedMettaGrid(prog, cms, seeds, buffers="host", specialize="sync")
+    assert eng.jit_errors == [] and eng.act_variant == 1 and eng.handler_variant == 9, (eng.jit_errors, eng.act_variant, eng.handler_variant)
+    plain = BatchedMettaGrid(prog, cms, seeds, buffers="host", specialize=False)
+    assert plain.handler_variant == 0
+    oracles = [op.OracleSim(prog, cms[e], int(seeds[e])) for e in range(E)]
+    for o in oracles:
+        o.reinit_buffers()
+    A, n = prog.num_agents, len(prog.action_names)
+    rng = np.random.default_rng(4)
+    for t in range(56):
+        a = rng.integers(0, n, E * A).astype(np.int32)
+        v = rng.integers(0, n, E * A).astype(np.int32)
+        for g in (eng, plain):
+            g.actions[:] = a
+            g.vibe_actions[:] = v
+            g.step()
+        snap = eng.snapshot()
+        for e, o in enumerate(oracles):
+            o.step(a[e * A:(e + 1) * A], v[e * A:(e + 1) * A])
+            hp.compare_snapshots(o.snapshot(), {k: x[e * A:(e + 1) * A] for k, x in snap.items()}, f"extended jit env {e} step {t}")
+    assert np.array_equal(eng.state_digests(), plain.state_digests())
+    eng.close(); plain.close()
