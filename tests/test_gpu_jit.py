@@ -106,6 +106,26 @@ def test_extended_dispatch_kernel_specialised_at_run_time(tmp_path, monkeypatch)
     cms = np.stack([prog.class_map(random_map(20, 20, dict(objs), dict(presets.RUNG4_AGENTS), 700 + s)) for s in range(E)])
     seeds = np.arange(E, dtype=np.uint32) + 21
     assert sorted(jit.plan(prog)) == ["actx"]
+    # the reference's handler-chain config (fixture of its own converter: AoE, an event, a materialized query) compiles beside it
+    doc = json.load(open(os.path.join(HERE, "golden", "ref_chains.json")))
+    zc = np.load(os.path.join(HERE, "golden", "ref_chains.npz"))
+    chains = from_reference.compile_reference_config(ref_tree.load(doc["config"]), len(doc["map"]), len(doc["map"][0]))
+    pending = jit.start(prog, True) + jit.start(chains, True)
+    for j in pending:
+        assert j.wait(900) and j.error is None, j.error
+    ce = BatchedMettaGrid(chains, chains.class_map(doc["map"])[None], [doc["seed"]], buffers="host", specialize="sync")
+    assert ce.jit_errors == []
+    assert ce.handler_variant == (9 if ce.act_variant == 1 else 0), (ce.act_variant, ce.handler_variant)
+    keys = ("obs", "rewards", "terminals", "truncations", "action_success", "episode_rewards")
+    for t in range(doc["steps"]):          # against the REFERENCE's recorded trace
+        for when, agent_id, inv in doc["set_inventory"]:
+            if when == t:
+                ce.set_inventory(0, agent_id, dict(map(tuple, inv)))
+        ce.actions[:] = zc["actions"][t]
+        ce.vibe_actions[:] = zc["vibe_actions"][t]
+        ce.step()
+        hp.compare_snapshots({k: zc[k][t + 1] for k in keys}, ce.snapshot(), f"ref_chains (variant {ce.handler_variant}) step {t + 1}")
+    ce.close()
     eng = BatchedMettaGrid(prog, cms, seeds, buffers="host", specialize="sync")
     assert eng.jit_errors == [] and eng.act_variant == 1 and eng.handler_variant == 9, (eng.jit_errors, eng.act_variant, eng.handler_variant)
     plain = BatchedMettaGrid(prog, cms, seeds, buffers="host", specialize=False)
