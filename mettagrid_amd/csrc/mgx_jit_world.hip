@@ -11,6 +11,9 @@
 #define MGX_TU_NS mgx_tu_jit
 #define MGX_CONST_DEV 1
 #define MGX_WORLD_IDS 1
+#ifndef MGX_NO_WORLD_HELPERS
+#define MGX_WORLD_HELPERS 1   // idle upper half-wavefronts take half of the batched per-agent passes (mgx_world.h)
+#endif
 #define MGX_GEN_HANDLERS MgxGenJ
 #define MGX_GEN_ID MGX_JIT_GEN_ID
 #define MGX_JIT_GEN_ID 9   // MgxDev::gen_prog of an engine running this code object

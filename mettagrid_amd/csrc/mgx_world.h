@@ -101,6 +101,16 @@ MGX_DBG_LINKAGE __device__ unsigned long long mgx_dbg_cycles[16];
 #define MGX_WORLD_EPG 64
 #endif
 #define MGX_WORLD_THREADS (MGX_WAVE * (MGX_WORLD_EPG / MGX_WORLD_LPW))
+// MGX_WORLD_HELPERS (the lean lane-per-env kernel at 32 envs per wavefront): the upper 32 lanes of a wavefront, which used
+// to leave at once, stay as HELPERS of the lower 32 — helper lane h shares env, LDS cells and everything with lane h - 32 and
+// takes the second half of the agents in the three batched per-agent passes (staging, deferred bookkeeping, coverage), whose
+// time is the number of chunks of eight agents a lane walks; during the serial action dispatch it is masked off and costs
+// nothing.  Same instruction stream, half the trips of those passes.
+#if defined(MGX_WORLD_HELPERS) && !defined(MGX_CPU_EMU) && !defined(MGX_ACT_TU) && MGX_WORLD_LPW * 2 == MGX_WAVE
+#define MGX_HELPERS_ON 1
+#else
+#define MGX_HELPERS_ON 0
+#endif
 #ifdef MGX_ACT_TU
 // Agent-parallel action kernel (mgx_act.h): a workgroup owns MGX_WORLD_EPG envs, each env a run of A' = blockDim / EPG
 // consecutive lanes (A' = agents per env rounded up to a power of two, <= 64: an env never straddles a wavefront).
@@ -108,7 +118,11 @@ __device__ __forceinline__ int mgx_act_shift() { return (31 - __clz((int)blockDi
 __device__ __forceinline__ int mgx_world_lane() { return (int)(threadIdx.x >> mgx_act_shift()); }
 #else
 __device__ __forceinline__ int mgx_world_lane() {  // index of this lane's env inside the workgroup's 64-env group
+#if MGX_HELPERS_ON
+  return (int)((threadIdx.x >> 6) * MGX_WORLD_LPW + (threadIdx.x & (MGX_WORLD_LPW - 1)));   // (a helper lane: its partner's)
+#else
   return (int)((threadIdx.x >> 6) * MGX_WORLD_LPW + (threadIdx.x & (MGX_WAVE - 1)));
+#endif
 }
 #endif
 
@@ -1770,14 +1784,15 @@ struct MgxEnvT {  // per-lane view of one env
   // of a chunk in flight together.  Per agent at most four stat cells change: the result counter of each stream
   // (success or failed), action.failed (+1 per failed call, added one by one like the reference) and
   // max_steps_without_motion (set when a call's incremented counter exceeds it).
-  __device__ MGX_BIG void bookkeeping_flush() const {
-    const int A = d.A, lane = AL().lane;
+  __device__ MGX_BIG void bookkeeping_flush(int a_lo = 0, int a_hi = 1 << 30) const {   // agents [a_lo, min(a_hi, A))
+    const int A = min(d.A, a_hi), lane = AL().lane;
+    const int AS = d.A;   // stride of the vibe-stream result bytes
     const int s_max = d.wk[MGX_S_MAX_STEPS_WITHOUT_MOTION], s_failed = d.wk[MGX_S_ACTION_FAILED];
     // the six result counters as scalars (a lane-varying index into d.wk would be a memory load per agent)
     const int w_noop_ok = d.wk[MGX_S_NOOP_SUCCESS], w_noop_no = d.wk[MGX_S_NOOP_SUCCESS + 1];
     const int w_move_ok = d.wk[MGX_S_MOVE_SUCCESS], w_move_no = d.wk[MGX_S_MOVE_SUCCESS + 1];
     const int w_vibe_ok = d.wk[MGX_S_VIBE_SUCCESS], w_vibe_no = d.wk[MGX_S_VIBE_SUCCESS + 1];
-    for (int i0 = 0; i0 < A; i0 += 8) {
+    for (int i0 = a_lo; i0 < A; i0 += 8) {
       int id0[8], id1[8], nfail[8];
       uint32_t res0[8], res1[8], swm0[8], tw[8];
       float v0[8], v1[8], vf[8], vm[8];
@@ -1786,7 +1801,7 @@ struct MgxEnvT {  // per-lane view of one env
         const int i = min(i0 + q, A - 1);
         const int li = i * MGX_WORLD_EPG + lane;
         res0[q] = (uint32_t)(uint16_t)AL().act[li];
-        res1[q] = (uint32_t)(uint16_t)AL().act[A * MGX_WORLD_EPG + li];
+        res1[q] = (uint32_t)(uint16_t)AL().act[AS * MGX_WORLD_EPG + li];
         if (i0 + q >= A) res0[q] = res1[q] = 0;
         // result bytes have bit 0 set; an action id that was never handled (invalid / wrong stream) is cleared by the caller
         auto stat_of = [&](uint32_t r) {
@@ -1926,10 +1941,10 @@ struct MgxEnvT {  // per-lane view of one env
 
   // track_coverage of every agent (mettagrid_c.cpp:1054-1056).  Agents are independent here, so the loads of eight
   // of them are issued together.  Both stat keys exist since Agent::init (mgx_init_kernel calls track_coverage).
-  __device__ MGX_BIG void track_coverage_all() const {
-    const int A = d.A, lane = AL().lane;
+  __device__ MGX_BIG void track_coverage_all(int a_lo = 0, int a_hi = 1 << 30) const {   // agents [a_lo, min(a_hi, A))
+    const int A = min(d.A, a_hi), lane = AL().lane;
     const int su = d.wk[MGX_S_CELL_UNIQUE], sm = d.wk[MGX_S_CELL_MAXDIST];
-    for (int i0 = 0; i0 < A; i0 += 8) {
+    for (int i0 = a_lo; i0 < A; i0 += 8) {
       uint16_t rc8[8], cov8[8];
 #pragma unroll
       for (int q = 0; q < 8; q++) {
@@ -2088,7 +2103,8 @@ __device__ __forceinline__ void mgx_dispatch_one(const ENV& e, const MgxDev& d, 
 // itself ran in mgx_act_kernel).
 enum { MGX_PH_ACTIONS = 1, MGX_PH_AOE = 2, MGX_PH_TAIL = 4, MGX_PH_EVENTS = 8, MGX_PH_ALL = 15 };
 template <class PP, bool X>
-__device__ __forceinline__ void mgx_world_body(const MgxDev& d, PP P, uint8_t* order, MgxXLds xl, MgxALds al, int lane, int env, int phases) {
+__device__ __forceinline__ void mgx_world_body(const MgxDev& d, PP P, uint8_t* order, MgxXLds xl, MgxALds al, int lane, int env, int phases,
+                                               const bool helper = false) {
   MgxEnvT<PP, X> e(d, P, env);
   e.xl = xl;
   const int A = d.A;
@@ -2096,14 +2112,19 @@ __device__ __forceinline__ void mgx_world_body(const MgxDev& d, PP P, uint8_t* o
   if constexpr (!X) phases = MGX_PH_ALL;
   const bool act = (phases & MGX_PH_ACTIONS) != 0;
   const bool evt = (phases & MGX_PH_EVENTS) != 0;
-  e.step = act ? ++d.step[env] : d.step[env];
+  // the agents a lane walks in the batched passes: all of them, or (MGX_WORLD_HELPERS) the first chunks for the env's own
+  // lane and the rest for its helper
+  constexpr bool HELP = !X && MGX_HELPERS_ON;
+  const int a_split = HELP ? min(A, ((A + 1) / 2 + 7) & ~7) : A;
+  const int a_lo = helper ? a_split : 0, a_hi = helper ? A : a_split;
+  if (!helper) e.step = act ? ++d.step[env] : d.step[env];
   if constexpr (X) {
     if (phases == MGX_PH_EVENTS && !(d.any_on_tick && !d.tick_in_aoe)) {  // launched behind mgx_act_kernel: most steps have no event due
       const uint32_t k = d.next_event[env];
       if (k >= (uint32_t)d.n_schedule || (uint32_t)d.P[d.sec[MGX_SEC_SCHEDULE] + k * MGX_SC_WORDS + MGX_SC_TIMESTEP] > e.step) return;
     }
   }
-  if (act) {  // executed_actions / _action_success cleared (mettagrid_c.cpp:944,962-964): done here (a few 16-byte
+  if (act && !helper) {  // executed_actions / _action_success cleared (mettagrid_c.cpp:944,962-964): done here (a few 16-byte
               // stores per env) instead of two memset launches per step
     if ((A & 3) == 0) {
       uint4* ex = (uint4*)(d.executed + e.ao(0));
@@ -2118,7 +2139,7 @@ __device__ __forceinline__ void mgx_world_body(const MgxDev& d, PP P, uint8_t* o
   // ---- stage every agent's own state + both action streams in LDS.  The loads of one chunk are independent, so
   // they are all in flight together instead of one HBM round trip per agent inside the serial loop below. ----
   const bool want_stepprev = (d.flags & MGX_G_LAST_ACTION_MOVE) != 0;
-  for (int i0 = 0; i0 < A; i0 += 8) {
+  for (int i0 = a_lo; i0 < a_hi; i0 += 8) {
     uint16_t slot8[8], prev8[8];
     uint32_t swm8[8];
     int32_t a8[8], v8[8];
@@ -2137,7 +2158,7 @@ __device__ __forceinline__ void mgx_world_body(const MgxDev& d, PP P, uint8_t* o
 #pragma unroll
     for (int q = 0; q < 8; q++) {
       int i = i0 + q;
-      if (i < A) {
+      if (i < a_hi) {
         int li = i * MGX_WORLD_EPG + lane;
         al.slot[li] = slot8[q]; al.rc[li] = rc8[q]; al.prev[li] = prev8[q]; al.swm[li] = swm8[q];
         if (al.cls) al.cls[li] = cls8[q];
@@ -2149,6 +2170,11 @@ __device__ __forceinline__ void mgx_world_body(const MgxDev& d, PP P, uint8_t* o
   }
   e.al_ = al;
   MGX_TICK(0);
+  if constexpr (HELP) {   // the helper's half of the staging is read by the env's own lane below (same wavefront: program order)
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (!helper) {
   if (act) mgx_shuffle_order(e, order, lane, A);
   // Action dispatch (mettagrid_c.cpp:966-999).  The reference loops over priority levels max..0 and, inside each,
   // over the primary then the vibe stream.  Every real action handler has priority 0 and the only thing the
@@ -2194,9 +2220,14 @@ __device__ __forceinline__ void mgx_world_body(const MgxDev& d, PP P, uint8_t* o
       e.apply_top(d.game_on_tick, c);
     }
   }
+  }   // !helper
   MGX_TICK(4);
-  if (d.defer_book && act) e.bookkeeping_flush();
-  if (phases & MGX_PH_TAIL) e.track_coverage_all();
+  if constexpr (HELP) {   // ... and the dispatch's result bytes / positions by the helper
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (d.defer_book && act) e.bookkeeping_flush(a_lo, a_hi);
+  if (phases & MGX_PH_TAIL) e.track_coverage_all(a_lo, a_hi);
   MGX_TICK(5);
 }
 
@@ -2207,6 +2238,7 @@ __device__ __forceinline__ void mgx_world_entry(const MgxDev& d, int prog_words,
   uint8_t* order = mgx_dyn_lds;
   const int lane = mgx_world_lane();
   const bool active = (threadIdx.x & (MGX_WAVE - 1)) < MGX_WORLD_LPW;
+  const bool helper = !X && MGX_HELPERS_ON && !active;   // upper half of the wavefront (see MGX_WORLD_HELPERS)
   const int env = blockIdx.x * MGX_WORLD_EPG + lane;
   MgxXLds xl;
   xl.lane = lane;
@@ -2228,11 +2260,11 @@ __device__ __forceinline__ void mgx_world_entry(const MgxDev& d, int prog_words,
     int4* dst = (int4*)lprog;
     for (int i = threadIdx.x; i < prog_words / 4; i += blockDim.x) dst[i] = src[i];
     __syncthreads();
-    if (!active || env >= d.E) return;
-    mgx_world_body<MgxLdsProg, X>(d, (MgxLdsProg)lprog, order, xl, al, lane, env, phases);
+    if ((!active && !helper) || env >= d.E) return;
+    mgx_world_body<MgxLdsProg, X>(d, (MgxLdsProg)lprog, order, xl, al, lane, env, phases, helper);
   } else {
-    if (!active || env >= d.E) return;
-    mgx_world_body<MgxGlobalProg, X>(d, d.P, order, xl, al, lane, env, phases);
+    if ((!active && !helper) || env >= d.E) return;
+    mgx_world_body<MgxGlobalProg, X>(d, d.P, order, xl, al, lane, env, phases, helper);
   }
 }
 

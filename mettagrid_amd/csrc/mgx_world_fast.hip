@@ -12,6 +12,9 @@
 #define MGX_TU_NS MGX_CAT(mgx_tu_fast, MGX_SLOT)
 #define MGX_CONST_DEV 1
 #define MGX_WORLD_IDS 1
+#ifndef MGX_NO_WORLD_HELPERS
+#define MGX_WORLD_HELPERS 1   // idle upper half-wavefronts take half of the batched per-agent passes (mgx_world.h)
+#endif
 #ifndef MGX_NO_GEN_HANDLERS
 #define MGX_GEN_HANDLERS MgxGenR3   // straight-line handler code of the preset (mgx_handlers_gen.h), used when MgxDev::gen_prog says so
 #define MGX_GEN_ID 3
