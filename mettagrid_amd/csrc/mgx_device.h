@@ -41,6 +41,8 @@ struct MgxDev {
   int gen_prog;           // 3 / 4: the program's handler tables equal the preset the build generated straight-line code for (0: none)
   int act_par;            // 1: the action dispatch runs in mgx_act_kernel (one lane per AGENT, conflict-ordered rounds; mgx_act.h)
   int act_tick;           // 1: ... and the per-agent on_tick handlers too (lean games), one lane per agent
+  int tick_split;         // 1: every per-agent on_tick handler touches its own agent only: in the lean lane-per-env kernel the
+                          //    env's helper lane (MGX_WORLD_HELPERS) runs them for the second half of the agents
   int act_ngset;          // game-scope stats the action-phase handlers SET (StatsMutation): applied in agent order at the end
   int act_gset_ids[4];
   int act_lds_extra;      // bytes per workgroup behind the game-stat cells: footprints u32[A'][EPG] | cell map u8[EPG][H*W] (0: no cell map)

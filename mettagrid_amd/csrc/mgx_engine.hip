@@ -1150,6 +1150,14 @@ int mgx_create(const int32_t* program, size_t program_words, const uint16_t* cla
       act_roots.push_back(C[MGX_C_ON_AFTER_USE]);
       tick_roots.push_back(C[MGX_C_ON_TICK]);
     }
+    {   // on_tick handlers that stay with their agent (no game-scope stat, no UseTarget, nothing that moves): the helper lanes
+        // of the lean kernel may run them for half of the agents (MgxDev::tick_split)
+      const std::vector<int> gset_saved = gset;
+      const bool ok = d.any_on_tick && !d.X && local(tick_roots, false) && !saw_use_target && gset.size() == gset_saved.size();
+      gset = gset_saved;
+      saw_use_target = false;
+      d.tick_split = (ok && !getenv("MGX_NO_TICK_SPLIT")) ? 1 : 0;
+    }
     if (par && !local(act_roots, true)) par = false;
     bool tick = false;
     if (par && !d.X) {   // the lean kernel is the whole world update: its on_tick handlers must be lane-local as well

@@ -2117,7 +2117,11 @@ __device__ __forceinline__ void mgx_world_body(const MgxDev& d, PP P, uint8_t* o
   constexpr bool HELP = !X && MGX_HELPERS_ON;
   const int a_split = HELP ? min(A, ((A + 1) / 2 + 7) & ~7) : A;
   const int a_lo = helper ? a_split : 0, a_hi = helper ? A : a_split;
-  if (!helper) e.step = act ? ++d.step[env] : d.step[env];
+  {   // ++current_step (:933): both lanes of a pair read the old value in the same instruction, the env's own lane stores
+    const uint32_t s0 = d.step[env];
+    e.step = act ? s0 + 1 : s0;
+    if (act && !helper) d.step[env] = e.step;
+  }
   if constexpr (X) {
     if (phases == MGX_PH_EVENTS && !(d.any_on_tick && !d.tick_in_aoe)) {  // launched behind mgx_act_kernel: most steps have no event due
       const uint32_t k = d.next_event[env];
@@ -2174,6 +2178,7 @@ __device__ __forceinline__ void mgx_world_body(const MgxDev& d, PP P, uint8_t* o
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     __builtin_amdgcn_wave_barrier();
   }
+  const bool split_tick = HELP && d.tick_split != 0;   // the agents' on_tick handlers stay with their agent: the pair shares them
   if (!helper) {
   if (act) mgx_shuffle_order(e, order, lane, A);
   // Action dispatch (mettagrid_c.cpp:966-999).  The reference loops over priority levels max..0 and, inside each,
@@ -2190,7 +2195,7 @@ __device__ __forceinline__ void mgx_world_body(const MgxDev& d, PP P, uint8_t* o
   if constexpr (X) {
     if (evt && d.n_schedule > 0) e.process_events();  // mettagrid_c.cpp:1009-1011
   }
-  if (d.any_on_tick && evt && !d.tick_in_aoe) {
+  if (d.any_on_tick && evt && !d.tick_in_aoe && !split_tick) {
     for (int i = 0; i < A; i++) {  // per-agent on_tick (mettagrid_c.cpp:1019-1024); slot and class come from LDS
       const int li = i * MGX_WORLD_EPG + lane;
       const int slot = al.slot[li];
@@ -2221,11 +2226,24 @@ __device__ __forceinline__ void mgx_world_body(const MgxDev& d, PP P, uint8_t* o
     }
   }
   }   // !helper
-  MGX_TICK(4);
   if constexpr (HELP) {   // ... and the dispatch's result bytes / positions by the helper
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     __builtin_amdgcn_wave_barrier();
   }
+  if constexpr (HELP) {
+    if (d.any_on_tick && evt && split_tick) {
+      for (int i = a_lo; i < a_hi; i++) {  // per-agent on_tick (mettagrid_c.cpp:1019-1024), each lane of the pair its half
+        const int li = i * MGX_WORLD_EPG + lane;
+        const int slot = al.slot[li];
+        const int h = (al.cls ? e.cls(al.cls[li]) : e.cls_of(slot))[MGX_C_ON_TICK];
+        if (h >= 0) {
+          MgxCtx c = mgx_ctx(slot, slot);
+          e.apply_top(h, c);
+        }
+      }
+    }
+  }
+  MGX_TICK(4);
   if (d.defer_book && act) e.bookkeeping_flush(a_lo, a_hi);
   if (phases & MGX_PH_TAIL) e.track_coverage_all(a_lo, a_hi);
   MGX_TICK(5);
