@@ -41,6 +41,9 @@ struct MgxDev {
   int gen_prog;           // 3 / 4: the program's handler tables equal the preset the build generated straight-line code for (0: none)
   int act_par;            // 1: the action dispatch runs in mgx_act_kernel (one lane per AGENT, conflict-ordered rounds; mgx_act.h)
   int act_tick;           // 1: ... and the per-agent on_tick handlers too (lean games), one lane per agent
+  int duo;                // 1: the lean lane-per-env kernel dispatches TWO agents of an env at a time — the env's own lane the next
+                          //    agent in order, its helper lane (MGX_WORLD_HELPERS) the one after it when their cell footprints are
+                          //    disjoint (host analysis like act_par: handlers stay with actor and target, move range 1)
   int tick_split;         // 1: every per-agent on_tick handler touches its own agent only: in the lean lane-per-env kernel the
                           //    env's helper lane (MGX_WORLD_HELPERS) runs them for the second half of the agents
   int act_ngset;          // game-scope stats the action-phase handlers SET (StatsMutation): applied in agent order at the end

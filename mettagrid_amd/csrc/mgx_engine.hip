@@ -1150,6 +1150,22 @@ int mgx_create(const int32_t* program, size_t program_words, const uint16_t* cla
       act_roots.push_back(C[MGX_C_ON_AFTER_USE]);
       tick_roots.push_back(C[MGX_C_ON_TICK]);
     }
+    // Two agents of an env side by side in the lean lane-per-env kernel (MgxDev::duo, mgx_world.h): the same conditions as the
+    // lane-per-agent dispatch — every handler an action reaches stays with actor and target, move handlers look one cell
+    // ahead, at most four game-scope stats are SET — without that kernel's shape limits.
+    bool duo = !d.X && !getenv("MGX_NO_DUO") && d.A >= 2;
+    std::vector<int> duo_gset;
+    {
+      for (int k = 0; k < d.n_move_handlers; k++)
+        if (mh[k * MGX_MH_WORDS + MGX_MH_MAX_RANGE] != 1) duo = false;
+      const std::vector<int> gset_saved = gset;
+      gset.clear();
+      if (duo && !local(act_roots, true)) duo = false;
+      duo_gset = gset;
+      gset = gset_saved;
+      saw_use_target = false;
+      if (duo_gset.size() > 4) duo = false;
+    }
     {   // on_tick handlers that stay with their agent (no game-scope stat, no UseTarget, nothing that moves): the helper lanes
         // of the lean kernel may run them for half of the agents (MgxDev::tick_split)
       const std::vector<int> gset_saved = gset;
@@ -1173,6 +1189,12 @@ int mgx_create(const int32_t* program, size_t program_words, const uint16_t* cla
     d.act_tick = (par && tick) ? 1 : 0;
     d.act_ngset = par ? (int)gset.size() : 0;
     for (int k = 0; k < 4; k++) d.act_gset_ids[k] = (par && k < (int)gset.size()) ? gset[k] : -1;
+    d.duo = (duo && !par) ? 1 : 0;
+    if (d.duo) {   // the paired dispatch orders game-stat SETs through the same per-env cells
+      d.act_ngset = (int)duo_gset.size();
+      for (int k = 0; k < 4; k++) d.act_gset_ids[k] = k < (int)duo_gset.size() ? duo_gset[k] : -1;
+    }
+    if (getenv("MGX_VERBOSE")) fprintf(stderr, "[mgx] lean dispatch: %s\n", d.duo ? "two agents of an env at a time (disjoint footprints)" : "one agent at a time");
     if (getenv("MGX_VERBOSE")) fprintf(stderr, "[mgx] action dispatch: one lane per %s\n", par ? "agent (conflict-ordered rounds)" : "env");
   }
   {  // reward code made only of inventory / constant arithmetic reads nothing the observation kernel writes

@@ -151,7 +151,7 @@ __host__ __device__ inline int mgx_world_xlds_off(int A) { return ((A * MGX_WORL
 __host__ __device__ inline int mgx_world_lds_fixed(int A, bool X, bool aoe_lds = true, int act_extra = 0) {
   int o = ((A * MGX_WORLD_EPG + 15) & ~15) + ((mgx_world_alds_bytes(A) + 15) & ~15);
   if (X) o += MGX_VM_WORDS * MGX_WORLD_EPG * 4 + (aoe_lds ? 28 * MGX_WORLD_EPG * 4 + 8 * MGX_WORLD_EPG * 8 : 0);
-#ifdef MGX_ACT_TU
+#if defined(MGX_ACT_TU) || MGX_HELPERS_ON
   o += MGX_ACT_GSET * MGX_WORLD_EPG * 8;  // (order position + 1) << 32 | f32 bits of the last game-stat set, per env
   o += act_extra;
 #endif
@@ -208,8 +208,9 @@ struct MgxEnvT {  // per-lane view of one env
   MgxALds al_;
   mutable int cur_agent, cur_slot;  // agent whose action is being executed (LDS write-through of its position)
   mutable int grid_dirty;           // a grid cell was written since do_move last looked at the move target
-#ifdef MGX_ACT_TU
+#if defined(MGX_ACT_TU) || MGX_HELPERS_ON
   int act_pos = 0;  // this lane's place in the order the reference walks the agents in (shuffled order / agent index)
+  bool duo_on = false;   // (MGX_HELPERS_ON) two lanes of this env dispatch agents side by side: shared per-env words need care
   mutable uint32_t act_seq = 0;   // game-stat SETs this lane has made in this tick (the later of two sets by one agent wins)
   // StatsMutation on a game-scope stat from concurrently running agents: the set of the LAST agent in order must win.
   // Each set goes to a per-env LDS cell as (position + 1) << 32 | value bits under a 64-bit max; mgx_act_body applies the
@@ -283,7 +284,11 @@ struct MgxEnvT {  // per-lane view of one env
     int a = d.obj_agent[so(slot)];
     return a == MGX_NO_AGENT ? -1 : a;
   }
+#if MGX_HELPERS_ON
+  __device__ __forceinline__ void flag(uint32_t bit) const { atomicOr(&d.err[envi()], bit); }   // (two lanes of an env may flag at once)
+#else
   __device__ __forceinline__ void flag(uint32_t bit) const { d.err[envi()] |= bit; }
+#endif
 
   // ---- stats (systems/stats_tracker.hpp:69-90) ----
   __device__ __forceinline__ void astat_touch(int agent, int id) const { d.ag_touched[ao(agent) * d.NSW + (id >> 5)] |= 1u << (id & 31); }
@@ -1021,6 +1026,8 @@ struct MgxEnvT {  // per-lane view of one env
         float v = eval_value<TOPQ>(a3, e, c, 0);
 #ifdef MGX_ACT_TU
         if (a0 == 0) act_gstat_set(a2, v);
+#elif MGX_HELPERS_ON
+        if (a0 == 0) { if (duo_on) act_gstat_set(a2, v); else gstat_set(a2, v); }
 #else
         if (a0 == 0) gstat_set(a2, v);
 #endif
@@ -2179,8 +2186,7 @@ __device__ __forceinline__ void mgx_world_body(const MgxDev& d, PP P, uint8_t* o
     __builtin_amdgcn_wave_barrier();
   }
   const bool split_tick = HELP && d.tick_split != 0;   // the agents' on_tick handlers stay with their agent: the pair shares them
-  if (!helper) {
-  if (act) mgx_shuffle_order(e, order, lane, A);
+  if (!helper && act) mgx_shuffle_order(e, order, lane, A);
   // Action dispatch (mettagrid_c.cpp:966-999).  The reference loops over priority levels max..0 and, inside each,
   // over the primary then the vibe stream.  Every real action handler has priority 0 and the only thing the
   // higher (empty) levels do is repeat the invalid-index bookkeeping, so one pass per stream with the invalid-index
@@ -2188,10 +2194,93 @@ __device__ __forceinline__ void mgx_world_body(const MgxDev& d, PP P, uint8_t* o
   PP acts = P + d.sec[MGX_SEC_ACTIONS];
   const int repeats = d.max_priority + 1;
   MGX_TICK(1);
+  // MgxDev::duo (MGX_WORLD_HELPERS): the env's own lane runs the next agent a of the order and its helper lane the agent b
+  // behind it IN THE SAME TRIP when their cell footprints {own cell, cell ahead} are disjoint — then nothing a's action
+  // reads or writes is touched by b's (host analysis: handlers stay with actor and target), and b cannot have been moved by
+  // a (a swap or a move onto b's cell shares a cell) — otherwise b waits one trip.  Every env advances through its own
+  // order by one or two agents per trip; the wavefront loops until its slowest env is through.  The vibe stream only
+  // writes the acting agent: always two at a time.  Game-scope stat SETs go through the per-env LDS cells of the
+  // lane-per-agent kernels (position in the order, then set count: last-write-wins whatever lane ran first).
+  bool duo = false;
+#if MGX_HELPERS_ON
+  if constexpr (HELP) {
+    duo = d.duo != 0 && act;
+    if (duo) {
+      e.duo_on = true;
+      if (!helper) {
+        unsigned long long* cells = e.act_gset_cells();
+        for (int k = 0; k < MGX_ACT_GSET; k++) cells[k * MGX_WORLD_EPG + lane] = 0ull;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+#endif
   for (int stream = 0; stream < (act ? 2 : 0); stream++) {
-    for (int k = 0; k < A; k++) mgx_dispatch_one(e, d, acts, al, order[k * MGX_WORLD_EPG + lane], stream, lane, repeats);
+    int q = 0;   // this env's place in its order (the same in both lanes of a pair)
+    for (;;) {
+      const bool more = q < A && (duo || !helper);
+      if (__ballot(more) == 0ull) break;
+      bool run = more && !helper;
+      int k = q, adv = 1;
+#if MGX_HELPERS_ON
+      if constexpr (HELP) {
+        if (duo) {
+          const bool has_b = q + 1 < A;
+          k = min(q + (helper ? 1 : 0), A - 1);
+          uint32_t F = 0xFFFFFFFFu;   // own cell << 16 | cell ahead (= own cell when the action is no move)
+          if (more && stream == 0) {
+            const int ai = order[k * MGX_WORLD_EPG + lane];
+            const uint32_t own = al.rc[ai * MGX_WORLD_EPG + lane];
+            uint32_t tgt = own;
+            const int a = al.act[ai * MGX_WORLD_EPG + lane];
+            if (a >= 0 && a < d.nact && acts[a * MGX_AC_WORDS + MGX_AC_KIND] == MGX_AK_MOVE && d.n_move_handlers > 0) {
+              const int orient = acts[a * MGX_AC_WORDS + MGX_AC_ARG];  // orientation.hpp:28-48
+              const int dx = (orient == 2 || orient == 4 || orient == 6) ? -1 : (orient == 3 || orient == 5 || orient == 7) ? 1 : 0;
+              const int dy = (orient == 0 || orient == 4 || orient == 5) ? -1 : (orient == 1 || orient == 6 || orient == 7) ? 1 : 0;
+              const int r = (int)(own >> 8) + dy, c = (int)(own & 0xFF) + dx;
+              if (r >= 0 && c >= 0 && r < d.H && c < d.W) tgt = (uint32_t)((r << 8) | c);
+            }
+            F = (own << 16) | tgt;
+          }
+          const uint32_t Fo = (uint32_t)__shfl_xor((int)F, 32);
+          const uint32_t Fa = helper ? Fo : F, Fb = helper ? F : Fo;
+          const bool disjoint = (Fa >> 16) != (Fb & 0xFFFFu) && (Fa & 0xFFFFu) != (Fb >> 16) && (Fa & 0xFFFFu) != (Fb & 0xFFFFu);
+          const bool indep = has_b && (stream == 1 || disjoint);
+          run = more && (!helper || indep);
+          adv = indep ? 2 : 1;
+          e.act_pos = k;
+        }
+      }
+#endif
+      if (run) mgx_dispatch_one(e, d, acts, al, order[k * MGX_WORLD_EPG + lane], stream, lane, repeats);
+#if MGX_HELPERS_ON
+      if constexpr (HELP) {
+        if (duo) {   // what the pair wrote is visible to both before the next trip's footprints and actions
+          __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+          __builtin_amdgcn_wave_barrier();
+        }
+      }
+#endif
+      q += adv;
+    }
     MGX_TICK(2 + stream);
   }
+#if MGX_HELPERS_ON
+  if constexpr (HELP) {
+    if (duo) {   // the surviving game-stat sets (mgx_act.h mgx_act_apply_gsets)
+      if (!helper) {
+        unsigned long long* cells = e.act_gset_cells();
+        for (int k = 0; k < d.act_ngset; k++) {
+          const unsigned long long w = cells[k * MGX_WORLD_EPG + lane];
+          if (w) e.gstat_set(d.act_gset_ids[k], __uint_as_float((uint32_t)w));
+        }
+      }
+      e.duo_on = false;
+    }
+  }
+#endif
+  if (!helper) {
   if constexpr (X) {
     if (evt && d.n_schedule > 0) e.process_events();  // mettagrid_c.cpp:1009-1011
   }
@@ -2272,6 +2361,9 @@ __device__ __forceinline__ void mgx_world_entry(const MgxDev& d, int prog_words,
     xl.def_delta = nullptr;
     xl.terr_score = nullptr;
   }
+#if MGX_HELPERS_ON
+  off += MGX_ACT_GSET * MGX_WORLD_EPG * 8;   // the game-stat cells of the paired dispatch (mgx_world_lds_fixed): the program copy follows them
+#endif
   if (PROG_LDS) {
     int32_t* lprog = (int32_t*)(mgx_dyn_lds + off);
     const int4* src = (const int4*)(d.P + d.hot_lo);  // (hot_lo: 0, or the first word of the hot range: MGX_HOT_PROG)
