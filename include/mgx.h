@@ -300,6 +300,10 @@ int32_t mgx_world_prog_in_lds(const mgx_engine* e);
 /* 1: the program uses the extended systems (area effects, territory, events, queries, dynamic tags) and runs the extended
  * kernels; 0: a lean program. */
 int32_t mgx_is_extended(const mgx_engine* e);
+/* 1: the lean lane-per-env dispatch (mgx_act_variant 0) runs two agents of an env per trip where their cell footprints are
+ * disjoint (MgxDev::duo, csrc/mgx_world.h) — chosen at mgx_create under the conditions of the lane-per-agent dispatch.
+ * Same results. Diagnostic. */
+int32_t mgx_dispatch_pairs(const mgx_engine* e);
 int32_t mgx_num_envs(const mgx_engine* e);
 int32_t mgx_num_agents(const mgx_engine* e);   /* per env */
 int32_t mgx_num_tokens(const mgx_engine* e);

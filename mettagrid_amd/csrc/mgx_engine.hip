@@ -2331,6 +2331,7 @@ int32_t mgx_act_variant(const mgx_engine* e) { return e ? e->d.act_par : 0; }
 int32_t mgx_handler_variant(const mgx_engine* e) { return e ? e->d.gen_prog : 0; }
 int32_t mgx_world_prog_in_lds(const mgx_engine* e) { return e && e->prog_in_lds ? 1 : 0; }
 int32_t mgx_is_extended(const mgx_engine* e) { return e && e->d.X ? 1 : 0; }
+int32_t mgx_dispatch_pairs(const mgx_engine* e) { return e && e->d.duo ? 1 : 0; }
 int32_t mgx_num_envs(const mgx_engine* e) { return e ? e->d.E : 0; }
 int32_t mgx_num_agents(const mgx_engine* e) { return e ? e->d.A : 0; }
 int32_t mgx_num_tokens(const mgx_engine* e) { return e ? e->d.T : 0; }

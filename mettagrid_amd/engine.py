@@ -97,7 +97,7 @@ def load_lib():
         L.mgx_pack_result.argtypes = [vp, i64, C.POINTER(i64), C.POINTER(i32), vp]
         L.mgx_unpack_rows.argtypes = [vp, vp, i64, i32, vp, vp, vp]
     for name in ("mgx_num_envs", "mgx_num_agents", "mgx_num_tokens", "mgx_obs_variant", "mgx_act_variant", "mgx_handler_variant",
-                 "mgx_world_prog_in_lds", "mgx_is_extended"):
+                 "mgx_world_prog_in_lds", "mgx_is_extended", "mgx_dispatch_pairs"):
         getattr(L, name).argtypes = [vp]
         getattr(L, name).restype = i32
     L.mgx_state_bytes.argtypes = [vp]
@@ -675,6 +675,11 @@ class BatchedMettaGrid:
     def act_variant(self) -> int:
         """0: action dispatch with one lane per env; 1: one lane per agent in conflict-ordered rounds (csrc/mgx_act.h)."""
         return int(self.L.mgx_act_variant(self.h))
+
+    @property
+    def dispatch_pairs(self) -> int:
+        """1: the lean lane-per-env dispatch runs two agents of an env per trip where their footprints are disjoint."""
+        return int(self.L.mgx_dispatch_pairs(self.h))
 
     @property
     def state_bytes(self) -> int:
