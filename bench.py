@@ -232,7 +232,7 @@ def measure(rung: int, cms: np.ndarray, *, envs: int, steps: int, warmup: int, r
             else:
                 os.environ[k] = v
     variants = {"obs": grp.engines[0].obs_variant, "act": grp.engines[0].act_variant, "handler": grp.engines[0].handler_variant,
-                "pairs": grp.engines[0].dispatch_pairs}
+                "pairs": grp.engines[0].dispatch_pairs, "int_book": grp.engines[0].integer_bookkeeping}
     G = groups
 
     # pre-generated actions resident in HBM (protocol of python/src/mettagrid/perf/harness.py:32-34)

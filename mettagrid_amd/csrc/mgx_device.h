@@ -38,6 +38,8 @@ struct MgxDev {
                           // sec[] entries are relative to it in that kernel's copy of this table)
   int x_aoe_lds;          // 1: the extended world kernel runs the AoE phase itself and keeps its scratch in LDS
   int defer_book;         // 1: per-action bookkeeping stats are applied in one batched pass at the end of the tick
+  int shadow;             // 1: ... and into the integer record ag_cnt instead of the agents' stat rows; the float cells are
+                          // written from it (mgx_shadow_flush_kernel) before anything reads them
   int gen_prog;           // 3 / 4: the program's handler tables equal the preset the build generated straight-line code for (0: none)
   int act_par;            // 1: the action dispatch runs in mgx_act_kernel (one lane per AGENT, conflict-ordered rounds; mgx_act.h)
   int act_tick;           // 1: ... and the per-agent on_tick handlers too (lean games), one lane per agent
@@ -76,6 +78,8 @@ struct MgxDev {
   int32_t* ag_invk;       // [E][A][MGX_INVALID_EXTRA] out-of-window invalid action indices seen this episode ...
   float* ag_invn;         // ... and how often (0 = free pair)
   uint32_t* ag_swm;       // [E][A] steps_without_motion
+  uint32_t* ag_cnt;       // [E][A][8] (32-byte records) noop ok/failed, move ok/failed, change_vibe ok/failed, action.failed,
+                          // max steps without motion — what the per-action bookkeeping counts, as integers (d.shadow)
   uint32_t* ag_maxdist;   // [E][A]
   uint32_t* ag_unique;    // [E][A]
   uint32_t* ag_seen;      // [E][A][SEENW]

@@ -608,12 +608,30 @@ static void free_episode_stats(mgx_engine* e) {
   e->d_ep_log = nullptr; e->d_ep_log_state = nullptr; e->h_ep_snap = nullptr; e->ep_ev = nullptr;
   e->ep_stats = false; e->ep_pending = false; e->ep_log_cap = 0;
 }
+// d.shadow: bring the float stat cells of the listed envs (or all) up to date with the integer counters (mgx_episode.h)
+static int flush_shadow(mgx_engine* e, const int32_t* list, const uint32_t* list_n, unsigned grid) {
+#ifndef MGX_CPU_EMU
+  if (!e->d.shadow) return MGX_OK;
+  hipLaunchKernelGGL(mgx_shadow_flush_kernel, dim3(grid), dim3(256), 0, e->stream, dev_copy(e), list, list_n);
+  HIP_TRY(hipGetLastError());
+#else
+  (void)e; (void)list; (void)list_n; (void)grid;
+#endif
+  return MGX_OK;
+}
+static int flush_shadow_all(mgx_engine* e) {
+  return flush_shadow(e, nullptr, nullptr, (unsigned)std::min<long long>(((long long)e->d.E * e->d.A + 255) / 256, 4096));
+}
 // Episode-end statistics of the envs in the done list (csrc/mgx_episode.h): records, then batch totals (+ log).
 static int launch_episode_stats(mgx_engine* e) {
 #ifndef MGX_CPU_EMU
   const MgxDev& d = e->d;
   MgxList dl;
   dl.n_host = -1;
+  {
+    int frc = flush_shadow(e, (const int32_t*)e->d_done_list, (const uint32_t*)e->d_done_n, (list_grid(e, dl, 128, 2048) * (unsigned)d.A + 255) / 256);
+    if (frc) return frc;
+  }
   hipLaunchKernelGGL(mgx_episode_record_kernel, dim3((list_grid(e, dl, 128, 2048) + 3) / 4), dim3(256), 0, e->stream, dev_copy(e), e->ep,
                      (const int32_t*)e->d_done_list, (const uint32_t*)e->d_done_n, e->d_ep_rec, e->d_ep_log, (const uint32_t*)e->d_ep_log_state,
                      e->ep_log_cap, (const uint32_t*)e->d_early, (const uint32_t*)e->d_episodes, (const int32_t*)e->d_map_index,
@@ -776,6 +794,7 @@ int mgx_create(const int32_t* program, size_t program_words, const uint16_t* cla
   A_(e->alloc_env(&d.ag_invk, A * MGX_INVALID_EXTRA));
   A_(e->alloc_env(&d.ag_invn, A * MGX_INVALID_EXTRA));
   A_(e->alloc_env(&d.ag_swm, A));
+  A_(e->alloc_env(&d.ag_cnt, A * 8));
   A_(e->alloc_env(&d.ag_maxdist, A));
   A_(e->alloc_env(&d.ag_unique, A));
   A_(e->alloc_env(&d.ag_seen, A * d.SEENW));
@@ -978,6 +997,27 @@ int mgx_create(const int32_t* program, size_t program_words, const uint16_t* cla
       }
     }
     d.defer_book = (reads_agent_stats || writes_booked) ? 0 : 1;  // (flushed at the end of the launch that runs the action phase)
+    // ... and can be kept as integers beside the stat rows (mgx_world.h tail_shadow) when nothing on the device reads the
+    // cells between two flushes: no game value at all — rewards and observation values included — reads one of them or a
+    // coverage stat, and no mutation writes a coverage stat.  Lean lane-per-env dispatch only.
+    bool shadow = d.defer_book && !d.X && !getenv("MGX_NO_SHADOW");
+#ifdef MGX_CPU_EMU
+    shadow = false;   // (the sanitizer build has no flush kernel)
+#endif
+    auto shadowed = [&](int id) { return booked(id) || id == d.wk[MGX_S_CELL_UNIQUE] || id == d.wk[MGX_S_CELL_MAXDIST]; };
+    for (int i = 0; i < n_code; i++)
+      if (code[i * MGX_GV_WORDS + MGX_GV_OP] == MGX_GOP_STAT && code[i * MGX_GV_WORDS + MGX_GV_A0] != 1 && shadowed(code[i * MGX_GV_WORDS + MGX_GV_A1]))
+        shadow = false;
+    for (int i = 0; i < n_mut; i++) {
+      const int32_t* m = P + d.sec[MGX_SEC_MUTS] + i * MGX_MU_WORDS;
+      if (m[MGX_MU_OP] == MGX_MOP_STATS && m[MGX_MU_A0] != 0 && shadowed(m[MGX_MU_A2])) shadow = false;
+      if (m[MGX_MU_OP] == MGX_MOP_GAME_VALUE && m[MGX_MU_A1] >= 0) {
+        const int32_t* V = P + d.sec[MGX_SEC_OBS_VALUES] + m[MGX_MU_A1] * MGX_OV_WORDS;
+        const int32_t* c0 = P + d.sec[MGX_SEC_GV_CODE] + V[MGX_OV_GV_START] * MGX_GV_WORDS;
+        if (V[MGX_OV_GV_COUNT] > 0 && c0[MGX_GV_OP] == MGX_GOP_STAT && c0[MGX_GV_A0] != 1 && shadowed(c0[MGX_GV_A1])) shadow = false;
+      }
+    }
+    d.shadow = shadow ? 1 : 0;
   }
   if (d.X) {  // can the action phase's top-level handlers run on the register VM?  (mgx_world.h apply_top)
     bool flat = !getenv("MGX_NO_FLAT_TOP");
@@ -1185,6 +1225,7 @@ int mgx_create(const int32_t* program, size_t program_words, const uint16_t* cla
     par = false;   // wavefront-cooperative (ballot / readlane): not part of the sanitizer build
 #endif
     d.act_par = par ? 1 : 0;
+    if (d.act_par) d.shadow = 0;   // (the lane-per-agent dispatch flushes its bookkeeping into the stat rows: bookkeeping_flush_one)
     d.act_replay = getenv("MGX_ACT_SHUFFLE_REPLAY") ? 1 : 0;
     d.act_tick = (par && tick) ? 1 : 0;
     d.act_ngset = par ? (int)gset.size() : 0;
@@ -2007,7 +2048,9 @@ int mgx_get_stats(mgx_engine* e, int32_t env, float* game_values, uint8_t* game_
   if (!e || env < 0 || env >= e->d.E) return fail(MGX_ERR_BAD_ARG, "mgx_get_stats: bad env");
   const MgxDev& d = e->d;
   std::vector<uint32_t> gt(d.NGW), at((size_t)d.A * d.NSW);
-  int rc = d2h(e, game_values, d.game_stats + (size_t)env * d.NG, (size_t)d.NG * 4);
+  int rc = flush_shadow_all(e);
+  if (rc) return rc;
+  rc = d2h(e, game_values, d.game_stats + (size_t)env * d.NG, (size_t)d.NG * 4);
   if (rc) return rc;
   rc = d2h(e, gt.data(), d.game_touched + (size_t)env * d.NGW, (size_t)d.NGW * 4);
   if (rc) return rc;
@@ -2174,6 +2217,7 @@ int mgx_state_digests(mgx_engine* e, uint64_t* out) {
   if (!e || !out) return fail(MGX_ERR_BAD_ARG, "mgx_state_digests: null argument");
   HIP_TRY(hipSetDevice(e->device));
   if (!e->d_digest) { int rc = e->alloc(&e->d_digest, (size_t)e->d.E); if (rc) return rc; }
+  { int rc = flush_shadow_all(e); if (rc) return rc; }
   hipLaunchKernelGGL(mgx_digest_kernel, dim3((unsigned)e->d.E), dim3(MGX_WAVE), 0, e->stream, dev_copy(e), e->d_digest);
   HIP_TRY(hipGetLastError());
   return d2h(e, out, e->d_digest, (size_t)e->d.E * 8);
@@ -2332,6 +2376,7 @@ int32_t mgx_handler_variant(const mgx_engine* e) { return e ? e->d.gen_prog : 0;
 int32_t mgx_world_prog_in_lds(const mgx_engine* e) { return e && e->prog_in_lds ? 1 : 0; }
 int32_t mgx_is_extended(const mgx_engine* e) { return e && e->d.X ? 1 : 0; }
 int32_t mgx_dispatch_pairs(const mgx_engine* e) { return e && e->d.duo ? 1 : 0; }
+int32_t mgx_integer_bookkeeping(const mgx_engine* e) { return e && e->d.shadow ? 1 : 0; }
 int32_t mgx_num_envs(const mgx_engine* e) { return e ? e->d.E : 0; }
 int32_t mgx_num_agents(const mgx_engine* e) { return e ? e->d.A : 0; }
 int32_t mgx_num_tokens(const mgx_engine* e) { return e ? e->d.T : 0; }

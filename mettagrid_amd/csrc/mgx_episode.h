@@ -58,6 +58,31 @@ static inline MgxEpLayout mgx_ep_layout(int NG, int NS, int A, int NSP, int per_
 }
 
 #ifndef MGX_CPU_EMU
+// d.shadow (mgx_world.h tail_shadow): the counters the per-action bookkeeping keeps as integers -> their float stat cells, for
+// the envs of a list (list_n on the device) or all of them (list == nullptr); one lane per agent.  A cell that is only ever
+// incremented by 1.f holds (float)min(count, 2^24); max_steps_without_motion is the largest counter value seen, converted;
+// the two coverage stats are set() to the current integers (objects/agent.cpp:49-57).  Idempotent.
+__global__ void __launch_bounds__(256) mgx_shadow_flush_kernel(const MgxDev* __restrict__ dp, const int32_t* __restrict__ list,
+                                                               const uint32_t* __restrict__ list_n) {
+  const MgxDev& d = *dp;
+  const long long rows = (long long)(list ? (int)*list_n : d.E) * d.A;
+  const int ids[8] = {d.wk[MGX_S_NOOP_SUCCESS], d.wk[MGX_S_NOOP_SUCCESS + 1], d.wk[MGX_S_MOVE_SUCCESS], d.wk[MGX_S_MOVE_SUCCESS + 1],
+                      d.wk[MGX_S_VIBE_SUCCESS], d.wk[MGX_S_VIBE_SUCCESS + 1], d.wk[MGX_S_ACTION_FAILED], d.wk[MGX_S_MAX_STEPS_WITHOUT_MOTION]};
+  const int su = d.wk[MGX_S_CELL_UNIQUE], sm = d.wk[MGX_S_CELL_MAXDIST];
+  for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < rows; k += (long long)gridDim.x * blockDim.x) {
+    const int env = list ? list[k / d.A] : (int)(k / d.A);
+    const size_t ao = (size_t)env * d.A + (size_t)(k % d.A);
+    const uint4 a = ((const uint4*)d.ag_cnt)[ao * 2], b = ((const uint4*)d.ag_cnt)[ao * 2 + 1];
+    const uint32_t c[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    float* row = d.ag_stats + ao * d.NSP;
+#pragma unroll
+    for (int q = 0; q < 8; q++)
+      if (ids[q] >= 0) row[ids[q]] = (float)(q == 7 ? c[q] : min(c[q], 1u << 24));
+    if (su >= 0) row[su] = (float)d.ag_unique[ao];
+    if (sm >= 0) row[sm] = (float)d.ag_maxdist[ao];
+  }
+}
+
 // log_state: [0] records in the log, [1] records dropped since the last drain (log full).
 __global__ void __launch_bounds__(256) mgx_episode_record_kernel(const MgxDev* __restrict__ dp, const MgxEpLayout L,
                                                                  const int32_t* __restrict__ list, const uint32_t* __restrict__ list_n,

@@ -1865,6 +1865,85 @@ struct MgxEnvT {  // per-lane view of one env
     }
   }
 
+  // d.shadow: bookkeeping_flush + track_coverage_all in ONE pass over the agents, with the counters of the bookkeeping kept
+  // as integers in the agent's 32-byte ag_cnt record instead of six cells of its stat row (one 128-byte line per agent
+  // read and written back every step for +1.f on two of them): two 16-byte loads and stores.  The float cells — and
+  // cell.unique_visited / cell.max_distance_from_spawn, which ag_unique / ag_maxdist already hold — are written by
+  // mgx_shadow_flush_kernel before anything reads them.  (float)min(count, 2^24) is what count additions of 1.f give.
+  __device__ MGX_BIG void tail_shadow(int a_lo = 0, int a_hi = 1 << 30) const {   // agents [a_lo, min(a_hi, A))
+    const int A = min(d.A, a_hi), lane = AL().lane;
+    const int AS = d.A;   // stride of the vibe-stream result bytes
+    const uint4* __restrict__ cnt = (const uint4*)d.ag_cnt;
+    uint4* __restrict__ cnt_w = (uint4*)d.ag_cnt;
+    for (int i0 = a_lo; i0 < A; i0 += 8) {
+      uint32_t res0[8], res1[8], swm0[8];
+      uint4 c0[8], c1[8];
+      uint16_t rc8[8], cov8[8], sp8[8];
+      uint32_t w8[8], un8[8], md8[8];
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        const int i = min(i0 + q, A - 1);
+        const int li = i * MGX_WORLD_EPG + lane;
+        res0[q] = (uint32_t)(uint16_t)AL().act[li];
+        res1[q] = (uint32_t)(uint16_t)AL().act[AS * MGX_WORLD_EPG + li];
+        if (i0 + q >= A) res0[q] = res1[q] = 0;
+        swm0[q] = d.ag_swm[ao(i)];
+        c0[q] = cnt[ao(i) * 2];
+        c1[q] = cnt[ao(i) * 2 + 1];
+        rc8[q] = AL().rc[li];
+        cov8[q] = d.ag_covrc[ao(i)];
+      }
+#pragma unroll
+      for (int q = 0; q < 8; q++) {   // second level, only for agents that moved
+        const int i = i0 + q;
+        if (i < A && rc8[q] != cov8[q]) {
+          const int bit = (rc8[q] >> 8) * d.W + (rc8[q] & 0xFF);
+          sp8[q] = d.ag_spawn[ao(i)];
+          w8[q] = d.ag_seen[ao(i) * d.SEENW + (bit >> 5)];
+          un8[q] = d.ag_unique[ao(i)];
+          md8[q] = d.ag_maxdist[ao(i)];
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        const int i = i0 + q;
+        if (i < A && rc8[q] != cov8[q]) {   // track_coverage (objects/agent.cpp:49-57): the position changed since the last call
+          const int r = rc8[q] >> 8, c = rc8[q] & 0xFF;
+          const int bit = r * d.W + c;
+          d.ag_covrc[ao(i)] = rc8[q];
+          if (!(w8[q] & (1u << (bit & 31)))) {
+            d.ag_seen[ao(i) * d.SEENW + (bit >> 5)] = w8[q] | (1u << (bit & 31));
+            d.ag_unique[ao(i)] = un8[q] + 1;
+          }
+          const int dist = abs((int)(sp8[q] >> 8) - r) + abs(c - (int)(sp8[q] & 0xFF));
+          if ((uint32_t)dist > md8[q]) d.ag_maxdist[ao(i)] = (uint32_t)dist;
+        }
+        if (i >= A || !((res0[q] | res1[q]) & 1)) continue;
+        const int li = i * MGX_WORLD_EPG + lane;
+        // replay the calls (actions/action_handler.hpp:78-105): result bytes have bit 0 set, bit 3 = success, bit 4 = moved
+        uint32_t swm = swm0[q];
+        uint4 a = c0[q], b = c1[q];
+#pragma unroll
+        for (int call = 0; call < 2; call++) {
+          const uint32_t r = call ? res1[q] : res0[q];
+          if (!(r & 1)) continue;
+          if (r & 16) swm = 0;
+          else { swm += 1; b.w = max(b.w, swm); }
+          const int kind = (r >> 1) & 3;
+          const uint32_t ok = (r >> 3) & 1u, no = ok ^ 1u;
+          if (kind == MGX_AK_NOOP) { a.x += ok; a.y += no; }
+          else if (kind == MGX_AK_MOVE) { a.z += ok; a.w += no; }
+          else { b.x += ok; b.y += no; }
+          b.z += no;
+        }
+        d.ag_swm[ao(i)] = swm;
+        d.ag_prev[ao(i)] = AL().prev[li];
+        cnt_w[ao(i) * 2] = a;
+        cnt_w[ao(i) * 2 + 1] = b;
+      }
+    }
+  }
+
   // bookkeeping_flush for ONE agent (the lane-per-agent kernel, mgx_act.h: every lane flushes its own agent)
   __device__ MGX_BIG void bookkeeping_flush_one(int i) const {
     const int A = d.A, lane = AL().lane;
@@ -2333,8 +2412,11 @@ __device__ __forceinline__ void mgx_world_body(const MgxDev& d, PP P, uint8_t* o
     }
   }
   MGX_TICK(4);
-  if (d.defer_book && act) e.bookkeeping_flush(a_lo, a_hi);
-  if (phases & MGX_PH_TAIL) e.track_coverage_all(a_lo, a_hi);
+  if (!X && d.shadow && act) e.tail_shadow(a_lo, a_hi);   // (d.shadow implies d.defer_book)
+  else {
+    if (d.defer_book && act) e.bookkeeping_flush(a_lo, a_hi);
+    if (phases & MGX_PH_TAIL) e.track_coverage_all(a_lo, a_hi);
+  }
   MGX_TICK(5);
 }
 

@@ -97,7 +97,7 @@ def load_lib():
         L.mgx_pack_result.argtypes = [vp, i64, C.POINTER(i64), C.POINTER(i32), vp]
         L.mgx_unpack_rows.argtypes = [vp, vp, i64, i32, vp, vp, vp]
     for name in ("mgx_num_envs", "mgx_num_agents", "mgx_num_tokens", "mgx_obs_variant", "mgx_act_variant", "mgx_handler_variant",
-                 "mgx_world_prog_in_lds", "mgx_is_extended", "mgx_dispatch_pairs"):
+                 "mgx_world_prog_in_lds", "mgx_is_extended", "mgx_dispatch_pairs", "mgx_integer_bookkeeping"):
         getattr(L, name).argtypes = [vp]
         getattr(L, name).restype = i32
     L.mgx_state_bytes.argtypes = [vp]
@@ -680,6 +680,11 @@ class BatchedMettaGrid:
     def dispatch_pairs(self) -> int:
         """1: the lean lane-per-env dispatch runs two agents of an env per trip where their footprints are disjoint."""
         return int(self.L.mgx_dispatch_pairs(self.h))
+
+    @property
+    def integer_bookkeeping(self) -> int:
+        """1: the per-action bookkeeping counters live as integers beside the stat rows (written into them before any read)."""
+        return int(self.L.mgx_integer_bookkeeping(self.h))
 
     @property
     def state_bytes(self) -> int:
