@@ -32,7 +32,8 @@ enum {
   MGX_ENV_INVALID_KEY_RANGE = 2,/* action.invalid_index.<k> outside the tracked window (include/mgx_program.h) */
   MGX_ENV_DEPTH = 4,            /* handler / inventory-limit recursion deeper than the engine supports */
   MGX_ENV_TOO_MANY_OBJECTS = 8, /* map holds more objects than MGX_H_MAX_OBJECTS slots */
-  MGX_ENV_TOKEN_POOL = 16       /* per-env LDS token cache of the observation kernel exhausted */
+  MGX_ENV_TOKEN_POOL = 16,      /* per-env LDS token cache of the observation kernel exhausted */
+  MGX_ENV_INTERNAL = 0x8000     /* set by mgx_state_digests: a per-agent mirror (cell, class) differs from the object row — an engine bug */
 };
 
 /* MettaGrid(GameConfig, map, seed) — cpp/bindings/mettagrid_c.cpp:42-191, _init_grid :200-269.

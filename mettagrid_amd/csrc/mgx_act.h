@@ -163,7 +163,7 @@ __device__ __forceinline__ void mgx_act_body(const MgxDev& d, PP P, uint8_t* ord
     const uint16_t slot = d.ag_obj[e.ao(i)], prev = d.ag_prev[e.ao(i)];
     const uint32_t swm = d.ag_swm[e.ao(i)];
     const int32_t a = d.actions[e.ao(i)], v = d.vibe_actions[e.ao(i)];
-    const uint16_t rc = d.obj_rc[e.so(slot)], cls = d.obj_cls[e.so(slot)];
+    const uint16_t rc = d.ag_rc[e.ao(i)], cls = d.ag_cls[e.ao(i)];   // (per-agent mirrors of the object row: one round of loads)
     const int li = i * MGX_WORLD_EPG + envl;
     al.slot[li] = slot; al.rc[li] = rc; al.prev[li] = prev; al.swm[li] = swm;
     if (al.cls) al.cls[li] = cls;

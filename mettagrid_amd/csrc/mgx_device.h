@@ -73,6 +73,10 @@ struct MgxDev {
   uint16_t* ag_obj;       // [E][A] slot of agent i
   uint16_t* ag_prev;      // [E][A] Agent::prev_location
   uint16_t* ag_spawn;     // [E][A]
+  uint16_t* ag_rc;        // [E][A] the agent's cell = obj_rc of its object, kept beside it by every writer (move_object, the swap
+                          // mutation, construction): staging an env's agents is then ONE round of loads, not slot -> object row
+  uint16_t* ag_cls;       // [E][A] class of the agent's object (an object never changes class)
+  uint32_t* ag_rwinfo;    // [E][A] reward records of the agent's class: start | count << 16 (an object never changes class)
   uint16_t* ag_stepprev;  // [E][A] MettaGrid::_prev_agent_locations
   uint16_t* ag_covrc;     // [E][A] position at the last coverage update (0xFFFF = never)
   int32_t* ag_invk;       // [E][A][MGX_INVALID_EXTRA] out-of-window invalid action indices seen this episode ...

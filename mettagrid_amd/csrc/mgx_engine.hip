@@ -135,6 +135,10 @@ __global__ void __launch_bounds__(MGX_WAVE) mgx_digest_kernel(const MgxDev* __re
     }
     h = mgx_fnv(h, __float_as_uint(d.episode_rewards[e.ao(a)]));
     h = mgx_fnv(h, (uint32_t)d.success[e.ao(a)]);
+    {  // the per-agent mirrors of the object row (MgxDev::ag_rc, ag_cls) against the row itself
+      const size_t so = e.so(d.ag_obj[e.ao(a)]);
+      if (d.ag_rc[e.ao(a)] != d.obj_rc[so] || d.ag_cls[e.ao(a)] != d.obj_cls[so]) d.err[env] |= MGX_ENV_INTERNAL;
+    }
     const uint16_t c = d.obj_cls[e.so(d.ag_obj[e.ao(a)])];   // current_stat_reward (systems/reward.hpp:36-42)
     const int nrw = c == MGX_DEAD_CLASS ? 0 : mgx_cls(d, c)[MGX_C_REWARD_COUNT];
     float tot = 0.f;
@@ -789,6 +793,9 @@ int mgx_create(const int32_t* program, size_t program_words, const uint16_t* cla
   A_(e->alloc_env(&d.ag_obj, A));
   A_(e->alloc_env(&d.ag_prev, A));
   A_(e->alloc_env(&d.ag_spawn, A));
+  A_(e->alloc_env(&d.ag_rc, A));
+  A_(e->alloc_env(&d.ag_rwinfo, A));
+  A_(e->alloc_env(&d.ag_cls, A));
   A_(e->alloc_env(&d.ag_stepprev, A));
   A_(e->alloc_env(&d.ag_covrc, A, 0xFF));
   A_(e->alloc_env(&d.ag_invk, A * MGX_INVALID_EXTRA));

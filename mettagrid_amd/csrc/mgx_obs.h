@@ -439,17 +439,22 @@ static __device__ __forceinline__ void mgx_obs_env(const MgxDev& d, const int en
       const uint16_t sprev = d.ag_stepprev[e.ao(i)];
       const uint16_t spawn = d.ag_spawn[e.ao(i)];
       const float vs = step > 0 ? e.astat_get(i, sid_visited) : 0.f;
-      const uint16_t rc = d.obj_rc[e.so(slot)];
-      const int32_t* C = mgx_cls(d, d.obj_cls[e.so(slot)]);
+      // the agent's cell and its class's reward records from the per-agent mirrors (MgxDev::ag_rc, ag_rwinfo): every load of
+      // this loop is independent — one memory round trip in front of the first barrier instead of three (slot -> object row ->
+      // class record)
+      const uint16_t rc = d.ag_rc[e.ao(i)];
+      const uint32_t rwi = d.ag_rwinfo[e.ao(i)];
       s_agents[i] = slot | ((uint32_t)rc << 16);
       s_aginfo[i] = ((uint32_t)ex & 0xFF) | (rc != sprev ? 0x100u : 0u);
       s_spawn[i] = spawn;
       s_vstat[i] = vs;
-      s_rwinfo[i] = ((uint32_t)C[MGX_C_REWARD_START] & 0xFFFFu) | ((uint32_t)C[MGX_C_REWARD_COUNT] << 16);
+      s_rwinfo[i] = rwi;
       if constexpr (X) {
-        if (want_mask)   // the observer's own tag bitset (friend / foe of a cell's owner tag), once per env
+        if (want_mask) {   // the observer's own tag bitset (friend / foe of a cell's owner tag), once per env
+          const int32_t* C = d.obj_tags ? nullptr : mgx_cls(d, d.obj_cls[e.so(slot)]);
           for (int w = 0; w < TW; w++)
             s_agtags[i * TW + w] = d.obj_tags ? d.obj_tags[e.so(slot) * MGX_TAG_WORDS + w] : (uint32_t)C[MGX_C_TAGS + w];
+        }
       }
     }
     if constexpr (X) {
@@ -520,7 +525,13 @@ static __device__ __forceinline__ void mgx_obs_env(const MgxDev& d, const int en
       }
       const bool is_static = (cinfo >> 31) != 0;
       const bool is_agent = (cinfo & 0x40000000u) != 0;
-      // inventory amounts in iteration order (second round trip, again all loads in flight together)
+      // Inventory amounts in iteration order.  Extended kernels: the whole 32-byte row is loaded with the fields above (the
+      // same round trip; picking the items out by their order word first made it a second one: rung 4 3.55 -> 3.35 ms) and an
+      // item's amount is picked out of the eight row words when its tokens are written.  Lean kernels keep the second round
+      // trip of per-item loads: the picks cost 15 VGPRs and 27 spilled SGPRs there (rung 3: 0.52 -> 0.59 ms).
+      static_assert(MGX_INV_PITCH == 16, "inventory rows are two 16-byte words");
+      uint4 r0 = make_uint4(0u, 0u, 0u, 0u), r1 = r0;
+      if constexpr (X) { r0 = ((const uint4*)(d.obj_inv + o * MGX_INV_PITCH))[0]; r1 = ((const uint4*)(d.obj_inv + o * MGX_INV_PITCH))[1]; }
       uint32_t amt[MGX_MAX_ITEMS];
       uint32_t live_mask = 0;
       {
@@ -529,10 +540,17 @@ static __device__ __forceinline__ void mgx_obs_env(const MgxDev& d, const int en
         for (int k = 0; k < MGX_MAX_ITEMS; k++) {
           const int item = (int)((ord >> (4 * k)) & 0xF);
           live = live && item != 0xF;
-          amt[k] = live ? (uint32_t)d.obj_inv[o * MGX_INV_PITCH + item] : 0u;
+          if constexpr (!X) amt[k] = live ? (uint32_t)d.obj_inv[o * MGX_INV_PITCH + item] : 0u;
           if (live) live_mask |= 1u << k;
         }
       }
+      auto amount_of = [&](int k, int item) -> uint32_t {
+        if constexpr (!X) return amt[k];
+        const uint32_t lo = (item & 4) ? ((item & 2) ? r0.w : r0.z) : ((item & 2) ? r0.y : r0.x);
+        const uint32_t hi = (item & 4) ? ((item & 2) ? r1.w : r1.z) : ((item & 2) ? r1.y : r1.x);
+        const uint32_t w = (item & 8) ? hi : lo;
+        return (item & 1) ? (w >> 16) : (w & 0xFFFFu);
+      };
       int ntags = (cinfo >> 24) & 0x3F;
       uint32_t tagw[MGX_TAG_WORDS];
       if (dyn_tags && !is_static) {
@@ -565,7 +583,7 @@ static __device__ __forceinline__ void mgx_obs_env(const MgxDev& d, const int en
             if (live_mask & (1u << k)) {
               const int item = (int)((ord >> (4 * k)) & 0xF);
               VP F = feat + item * MGX_IF_WORDS;
-              uint32_t rem = amt[k];
+              uint32_t rem = amount_of(k, item);
               w.put((uint32_t)F[0], B.lo(rem));
               rem = B.hi(rem);
               for (int pdig = 1; rem > 0; pdig++) { w.put((uint32_t)F[pdig], B.lo(rem)); rem = B.hi(rem); }

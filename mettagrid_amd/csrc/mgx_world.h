@@ -857,9 +857,12 @@ struct MgxEnvT {  // per-lane view of one env
     cell(rc >> 8, rc & 0xFF) = 0;
     grid_dirty = 1;
     d.obj_rc[so(slot)] = (uint16_t)((r << 8) | c);
-    if (AL().rc) {
-      if (own) AL().rc[cur_agent * MGX_WORLD_EPG + AL().lane] = (uint16_t)((r << 8) | c);
-      else { int a = agent_of(slot); if (a >= 0) AL().rc[a * MGX_WORLD_EPG + AL().lane] = (uint16_t)((r << 8) | c); }
+    {
+      const int a = slot == cur_slot ? cur_agent : agent_of(slot);
+      if (a >= 0) {
+        d.ag_rc[ao(a)] = (uint16_t)((r << 8) | c);
+        if (AL().rc) AL().rc[a * MGX_WORLD_EPG + AL().lane] = (uint16_t)((r << 8) | c);
+      }
     }
     territory_moved(slot);
     return true;
@@ -1047,6 +1050,8 @@ struct MgxEnvT {  // per-lane view of one env
         cell(ry >> 8, ry & 0xFF) = (uint16_t)(c.actor + 1); grid_dirty = 1;
         d.obj_rc[so(c.actor)] = ry;
         d.obj_rc[so(c.target)] = rx;
+        d.ag_rc[ao(xa)] = ry;
+        d.ag_rc[ao(ya)] = rx;
         if (AL().rc) { AL().rc[xa * MGX_WORLD_EPG + AL().lane] = ry; AL().rc[ya * MGX_WORLD_EPG + AL().lane] = rx; }
         territory_moved(c.actor);  // on_object_moved twice (core/grid.hpp:100-103)
         territory_moved(c.target);
@@ -2230,7 +2235,7 @@ __device__ __forceinline__ void mgx_world_body(const MgxDev& d, PP P, uint8_t* o
   // they are all in flight together instead of one HBM round trip per agent inside the serial loop below. ----
   const bool want_stepprev = (d.flags & MGX_G_LAST_ACTION_MOVE) != 0;
   for (int i0 = a_lo; i0 < a_hi; i0 += 8) {
-    uint16_t slot8[8], prev8[8];
+    uint16_t slot8[8], prev8[8], rc8[8], cls8[8];
     uint32_t swm8[8];
     int32_t a8[8], v8[8];
 #pragma unroll
@@ -2241,10 +2246,9 @@ __device__ __forceinline__ void mgx_world_body(const MgxDev& d, PP P, uint8_t* o
       swm8[q] = d.ag_swm[e.ao(i)];
       a8[q] = d.actions[e.ao(i)];
       v8[q] = d.vibe_actions[e.ao(i)];
+      rc8[q] = d.ag_rc[e.ao(i)];     // (per-agent mirrors of the object row: no second round of loads behind the slot)
+      cls8[q] = d.ag_cls[e.ao(i)];
     }
-    uint16_t rc8[8], cls8[8];
-#pragma unroll
-    for (int q = 0; q < 8; q++) { rc8[q] = d.obj_rc[e.so(slot8[q])]; cls8[q] = d.obj_cls[e.so(slot8[q])]; }
 #pragma unroll
     for (int q = 0; q < 8; q++) {
       int i = i0 + q;
@@ -2553,6 +2557,9 @@ __global__ void __launch_bounds__(MGX_WAVE) mgx_init_kernel(const MgxDev* __rest
       d.ag_obj[e.ao(ai)] = (uint16_t)slot;
       d.ag_prev[e.ao(ai)] = rc;
       d.ag_spawn[e.ao(ai)] = rc;
+      d.ag_rc[e.ao(ai)] = rc;
+      d.ag_cls[e.ao(ai)] = (uint16_t)cls;
+      d.ag_rwinfo[e.ao(ai)] = ((uint32_t)C[MGX_C_REWARD_START] & 0xFFFFu) | ((uint32_t)C[MGX_C_REWARD_COUNT] << 16);
       d.ag_stepprev[e.ao(ai)] = rc;
       d.ag_covrc[e.ao(ai)] = 0xFFFF;
       for (int q = 0; q < MGX_INVALID_EXTRA; q++) d.ag_invn[e.ao(ai) * MGX_INVALID_EXTRA + q] = 0.f;
@@ -2759,6 +2766,9 @@ static __device__ void mgx_init_wave_env(const MgxDev& d, const int env, const u
       d.ag_obj[e.ao(ai)] = (uint16_t)slot;
       d.ag_prev[e.ao(ai)] = rc;
       d.ag_spawn[e.ao(ai)] = rc;
+      d.ag_rc[e.ao(ai)] = rc;
+      d.ag_cls[e.ao(ai)] = (uint16_t)cls;
+      d.ag_rwinfo[e.ao(ai)] = ((uint32_t)C[MGX_C_REWARD_START] & 0xFFFFu) | ((uint32_t)C[MGX_C_REWARD_COUNT] << 16);
       d.ag_stepprev[e.ao(ai)] = rc;
       d.ag_covrc[e.ao(ai)] = 0xFFFF;
       for (int q = 0; q < MGX_INVALID_EXTRA; q++) d.ag_invn[e.ao(ai) * MGX_INVALID_EXTRA + q] = 0.f;

@@ -594,6 +594,9 @@ class BatchedMettaGrid:
         """uint64 [E]: digest of every env's signature state (objects, stats, rewards, success, step) in one kernel."""
         out = np.empty(self.E, np.uint64)
         _check(self.L.mgx_state_digests(self.h, out.ctypes.data))
+        bits, first = self.poll_errors()
+        if bits & 0x8000:  # MGX_ENV_INTERNAL: the digest kernel found a per-agent mirror out of step with its object row
+            raise MgxError(f"env {first}: internal consistency check failed (per-agent mirror differs from the object row)")
         return out
 
     # ---- policy-side token decode (SURVEY.md §8f-3) ----
