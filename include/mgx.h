@@ -305,10 +305,11 @@ int32_t mgx_is_extended(const mgx_engine* e);
  * disjoint (MgxDev::duo, csrc/mgx_world.h) — chosen at mgx_create under the conditions of the lane-per-agent dispatch.
  * Same results. Diagnostic. */
 int32_t mgx_dispatch_pairs(const mgx_engine* e);
-/* 1: the per-action bookkeeping of the lean dispatch (actions/action_handler.hpp:78-105: action.<kind>.success / .failed,
- * action.failed, status.max_steps_without_motion) and the two coverage stats are kept as integers beside the agents' stat
- * rows and written into them before anything reads them (mgx_get_stats, the episode records, mgx_state_digests) — chosen at
- * mgx_create when no game value or mutation of the program touches those stats.  Same results.  Diagnostic. */
+/* Non-zero: the counters of the per-action bookkeeping (actions/action_handler.hpp:78-105: action.<kind>.success / .failed,
+ * action.failed, status.max_steps_without_motion; bit 0) and the two coverage stats (objects/agent.cpp:49-57; bit 1, lean
+ * lane-per-env dispatch only) are kept as integers beside the agents' stat rows and written into them before anything reads
+ * them (mgx_get_stats, the episode records, mgx_state_digests) — chosen at mgx_create when no game value or mutation of the
+ * program touches those stats.  0, 1 or 3.  Same results.  Diagnostic. */
 int32_t mgx_integer_bookkeeping(const mgx_engine* e);
 int32_t mgx_num_envs(const mgx_engine* e);
 int32_t mgx_num_agents(const mgx_engine* e);   /* per env */

@@ -38,8 +38,9 @@ struct MgxDev {
                           // sec[] entries are relative to it in that kernel's copy of this table)
   int x_aoe_lds;          // 1: the extended world kernel runs the AoE phase itself and keeps its scratch in LDS
   int defer_book;         // 1: per-action bookkeeping stats are applied in one batched pass at the end of the tick
-  int shadow;             // 1: ... and into the integer record ag_cnt instead of the agents' stat rows; the float cells are
-                          // written from it (mgx_shadow_flush_kernel) before anything reads them
+  int shadow;             // bit 0: ... and into the integer record ag_cnt instead of the agents' stat rows; the float cells are
+                          // written from it (mgx_shadow_flush_kernel) before anything reads them.  bit 1: the two coverage stats
+                          // likewise (from ag_unique / ag_maxdist; lean lane-per-env dispatch).  0, 1 (lane-per-agent dispatch) or 3
   int gen_prog;           // 3 / 4: the program's handler tables equal the preset the build generated straight-line code for (0: none)
   int act_par;            // 1: the action dispatch runs in mgx_act_kernel (one lane per AGENT, conflict-ordered rounds; mgx_act.h)
   int act_tick;           // 1: ... and the per-agent on_tick handlers too (lean games), one lane per agent

@@ -1007,24 +1007,26 @@ int mgx_create(const int32_t* program, size_t program_words, const uint16_t* cla
     // ... and can be kept as integers beside the stat rows (mgx_world.h tail_shadow) when nothing on the device reads the
     // cells between two flushes: no game value at all — rewards and observation values included — reads one of them or a
     // coverage stat, and no mutation writes a coverage stat.  Lean lane-per-env dispatch only.
-    bool shadow = d.defer_book && !d.X && !getenv("MGX_NO_SHADOW");
+    bool counters = d.defer_book && !getenv("MGX_NO_SHADOW"), coverage = true;
 #ifdef MGX_CPU_EMU
-    shadow = false;   // (the sanitizer build has no flush kernel)
+    counters = false;   // (the sanitizer build has no flush kernel)
 #endif
-    auto shadowed = [&](int id) { return booked(id) || id == d.wk[MGX_S_CELL_UNIQUE] || id == d.wk[MGX_S_CELL_MAXDIST]; };
+    auto covers = [&](int id) { return id == d.wk[MGX_S_CELL_UNIQUE] || id == d.wk[MGX_S_CELL_MAXDIST]; };
     for (int i = 0; i < n_code; i++)
-      if (code[i * MGX_GV_WORDS + MGX_GV_OP] == MGX_GOP_STAT && code[i * MGX_GV_WORDS + MGX_GV_A0] != 1 && shadowed(code[i * MGX_GV_WORDS + MGX_GV_A1]))
-        shadow = false;
+      if (code[i * MGX_GV_WORDS + MGX_GV_OP] == MGX_GOP_STAT && code[i * MGX_GV_WORDS + MGX_GV_A0] != 1) {
+        if (booked(code[i * MGX_GV_WORDS + MGX_GV_A1])) counters = false;
+        if (covers(code[i * MGX_GV_WORDS + MGX_GV_A1])) coverage = false;
+      }
     for (int i = 0; i < n_mut; i++) {
       const int32_t* m = P + d.sec[MGX_SEC_MUTS] + i * MGX_MU_WORDS;
-      if (m[MGX_MU_OP] == MGX_MOP_STATS && m[MGX_MU_A0] != 0 && shadowed(m[MGX_MU_A2])) shadow = false;
+      if (m[MGX_MU_OP] == MGX_MOP_STATS && m[MGX_MU_A0] != 0 && covers(m[MGX_MU_A2])) coverage = false;
       if (m[MGX_MU_OP] == MGX_MOP_GAME_VALUE && m[MGX_MU_A1] >= 0) {
         const int32_t* V = P + d.sec[MGX_SEC_OBS_VALUES] + m[MGX_MU_A1] * MGX_OV_WORDS;
         const int32_t* c0 = P + d.sec[MGX_SEC_GV_CODE] + V[MGX_OV_GV_START] * MGX_GV_WORDS;
-        if (V[MGX_OV_GV_COUNT] > 0 && c0[MGX_GV_OP] == MGX_GOP_STAT && c0[MGX_GV_A0] != 1 && shadowed(c0[MGX_GV_A1])) shadow = false;
+        if (V[MGX_OV_GV_COUNT] > 0 && c0[MGX_GV_OP] == MGX_GOP_STAT && c0[MGX_GV_A0] != 1 && covers(c0[MGX_GV_A1])) coverage = false;
       }
     }
-    d.shadow = shadow ? 1 : 0;
+    d.shadow = !counters ? 0 : coverage ? 3 : 1;   // (settled below, once the dispatch is known)
   }
   if (d.X) {  // can the action phase's top-level handlers run on the register VM?  (mgx_world.h apply_top)
     bool flat = !getenv("MGX_NO_FLAT_TOP");
@@ -1232,7 +1234,10 @@ int mgx_create(const int32_t* program, size_t program_words, const uint16_t* cla
     par = false;   // wavefront-cooperative (ballot / readlane): not part of the sanitizer build
 #endif
     d.act_par = par ? 1 : 0;
-    if (d.act_par) d.shadow = 0;   // (the lane-per-agent dispatch flushes its bookkeeping into the stat rows: bookkeeping_flush_one)
+    // integer bookkeeping: counters and coverage stats in the lean lane-per-env kernel (all or nothing: one fused pass),
+    // counters only in the lane-per-agent dispatch kernels (bookkeeping_flush_one), none in the extended lane-per-env kernel
+    if (d.act_par) d.shadow &= 1;
+    else if (d.X || d.shadow != 3) d.shadow = 0;
     d.act_replay = getenv("MGX_ACT_SHUFFLE_REPLAY") ? 1 : 0;
     d.act_tick = (par && tick) ? 1 : 0;
     d.act_ngset = par ? (int)gset.size() : 0;
@@ -2383,7 +2388,7 @@ int32_t mgx_handler_variant(const mgx_engine* e) { return e ? e->d.gen_prog : 0;
 int32_t mgx_world_prog_in_lds(const mgx_engine* e) { return e && e->prog_in_lds ? 1 : 0; }
 int32_t mgx_is_extended(const mgx_engine* e) { return e && e->d.X ? 1 : 0; }
 int32_t mgx_dispatch_pairs(const mgx_engine* e) { return e && e->d.duo ? 1 : 0; }
-int32_t mgx_integer_bookkeeping(const mgx_engine* e) { return e && e->d.shadow ? 1 : 0; }
+int32_t mgx_integer_bookkeeping(const mgx_engine* e) { return e ? e->d.shadow : 0; }
 int32_t mgx_num_envs(const mgx_engine* e) { return e ? e->d.E : 0; }
 int32_t mgx_num_agents(const mgx_engine* e) { return e ? e->d.A : 0; }
 int32_t mgx_num_tokens(const mgx_engine* e) { return e ? e->d.T : 0; }

@@ -78,8 +78,10 @@ __global__ void __launch_bounds__(256) mgx_shadow_flush_kernel(const MgxDev* __r
 #pragma unroll
     for (int q = 0; q < 8; q++)
       if (ids[q] >= 0) row[ids[q]] = (float)(q == 7 ? c[q] : min(c[q], 1u << 24));
-    if (su >= 0) row[su] = (float)d.ag_unique[ao];
-    if (sm >= 0) row[sm] = (float)d.ag_maxdist[ao];
+    if (d.shadow & 2) {
+      if (su >= 0) row[su] = (float)d.ag_unique[ao];
+      if (sm >= 0) row[sm] = (float)d.ag_maxdist[ao];
+    }
   }
 }
 

@@ -1963,6 +1963,28 @@ struct MgxEnvT {  // per-lane view of one env
     };
     const int id0 = stat_of(res0), id1 = stat_of(res1);
     const int nfail = ((res0 & 9) == 1 ? 1 : 0) + ((res1 & 9) == 1 ? 1 : 0);
+    if (d.shadow) {   // the counters as integers in the agent's ag_cnt record (see tail_shadow)
+      uint32_t swm = d.ag_swm[ao(i)];
+      uint4 a = ((const uint4*)d.ag_cnt)[ao(i) * 2], b = ((const uint4*)d.ag_cnt)[ao(i) * 2 + 1];
+#pragma unroll
+      for (int call = 0; call < 2; call++) {
+        const uint32_t r = call ? res1 : res0;
+        if (!(r & 1)) continue;
+        if (r & 16) swm = 0;
+        else { swm += 1; b.w = max(b.w, swm); }
+        const int kind = (r >> 1) & 3;
+        const uint32_t ok = (r >> 3) & 1u, no = ok ^ 1u;
+        if (kind == MGX_AK_NOOP) { a.x += ok; a.y += no; }
+        else if (kind == MGX_AK_MOVE) { a.z += ok; a.w += no; }
+        else { b.x += ok; b.y += no; }
+        b.z += no;
+      }
+      d.ag_swm[ao(i)] = swm;
+      d.ag_prev[ao(i)] = AL().prev[li];
+      ((uint4*)d.ag_cnt)[ao(i) * 2] = a;
+      ((uint4*)d.ag_cnt)[ao(i) * 2 + 1] = b;
+      return;
+    }
     const size_t sb = ao(i) * d.NSP;
     uint32_t swm = d.ag_swm[ao(i)];
     const float v0 = d.ag_stats[sb + max(id0, 0)], v1 = d.ag_stats[sb + max(id1, 0)];
@@ -2416,7 +2438,7 @@ __device__ __forceinline__ void mgx_world_body(const MgxDev& d, PP P, uint8_t* o
     }
   }
   MGX_TICK(4);
-  if (!X && d.shadow && act) e.tail_shadow(a_lo, a_hi);   // (d.shadow implies d.defer_book)
+  if (!X && d.shadow == 3 && act) e.tail_shadow(a_lo, a_hi);   // (d.shadow implies d.defer_book)
   else {
     if (d.defer_book && act) e.bookkeeping_flush(a_lo, a_hi);
     if (phases & MGX_PH_TAIL) e.track_coverage_all(a_lo, a_hi);
