@@ -126,6 +126,7 @@ static inline int __builtin_amdgcn_update_dpp(int, int x, int, int, int, bool) {
 static inline int __builtin_amdgcn_readlane(int x, int) { return x; }
 static inline int __builtin_amdgcn_readfirstlane(int x) { return x; }
 #define __builtin_amdgcn_fence(...) ((void)0)
+#define __builtin_amdgcn_wave_barrier() ((void)0)
 static inline unsigned long long __ballot(int p) { return p ? 1ull : 0ull; }
 template <class T> static inline T __shfl(T v, int) { return v; }
 #endif
