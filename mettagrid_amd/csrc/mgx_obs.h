@@ -471,49 +471,80 @@ static __device__ __forceinline__ void mgx_obs_env(const MgxDev& d, const int en
       if (d.obsval)  // evaluated by mgx_values_kernel (one env per lane) right before this kernel
         for (int i = tid; i < A * NOV; i += NTH) s_obsval[i] = d.obsval[(size_t)env * A * NOV + i];
     }
-    if (tid == 0) { s_misc[0] = (uint32_t)pool_prefix; s_misc[1] = 0; }  // pool top, number of per-step lists
+    if (tid == 0) { s_misc[0] = (uint32_t)pool_prefix; if (S > NTH) s_misc[1] = 0; }  // pool top, number of per-step lists (S <= NTH: a count byte per wavefront, below)
   }
   const bool dyn_tags = X && d.obj_tags != nullptr;
   // ---- phase 0b: classify the object slots.  Static classes show their class tag list (pool prefix); everything
-  // else is queued for the list builder. ----
+  // else is queued for the list builder.  When every slot has a thread of its own (S <= NTH) the classification needs
+  // nothing another thread staged — its inputs are this thread's loads from the top of the kernel — so it runs IN FRONT of
+  // the staging barrier and the barrier behind it is gone: a wavefront queues its slots in its own segment of the queue
+  // (ballot rank, no shared counter) and leaves its count in a byte of s_misc[1..2]. ----
+  const bool early_cls = S <= NTH;
+  auto classify = [&](int s, uint16_t cls, uint32_t vis, uint32_t cinfo, bool& queue) -> uint32_t {
+    s_minobs[s] = 0xFFFFFFFFu;
+    uint32_t info = 0;
+    queue = false;
+    if (cls != MGX_DEAD_CLASS) {  // cinfo: start(16) | group(8) | ntags(6) | agent(1) | static(1)
+      s_visited[s] = vis;
+      if ((cinfo >> 31) != 0) info = (cinfo & 0xFFFFu) | (((cinfo >> 24) & 0x3Fu) << 16);  // static class: nothing about it changes, tags included (MGX_C_STATIC, compiler.py)
+      else { queue = true; info = cinfo; }  // parked here for the builder, which replaces it with start | count << 16
+    }
+    return info;
+  };
+  if (early_cls) {
+    bool queue = false;
+    if (tid < S) s_tokinfo[tid] = classify(tid, pre_cls, pre_vis, pre_cinfo, queue);
+    const unsigned long long qm = __ballot(queue);
+    if (queue) s_dyn[wave * MGX_WAVE + __popcll(qm & ((1ull << lane) - 1ull))] = (uint16_t)tid;
+    if (lane == 0) ((uint8_t*)&s_misc[1])[wave] = (uint8_t)__popcll(qm);
+  }
   if constexpr (BOX) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this thread's zero stores are out: no value stored
                                                                          // behind a barrier can be overtaken by one of them
   __syncthreads();
   MGX_TICK(8);
   MGX_PHASE_END(1);
-  for (int s = tid; s < S; s += NTH) {
-    const size_t o = e.so(s);
-    const bool pre = s == tid;  // first pass: loaded above
-    const uint16_t cls = pre ? pre_cls : d.obj_cls[o];
-    const uint32_t vis = pre ? pre_vis : d.obj_visited[o];
-    s_minobs[s] = 0xFFFFFFFFu;
-    uint32_t info = 0;
-    if (cls != MGX_DEAD_CLASS) {
-      const uint32_t cinfo = pre ? pre_cinfo : d.cls_tokinfo[cls];  // start(16) | group(8) | ntags(6) | agent(1) | static(1)
-      s_visited[s] = vis;
-      if ((cinfo >> 31) != 0) {  // static class: nothing about it changes, tags included (MGX_C_STATIC, compiler.py)
-        info = (cinfo & 0xFFFFu) | (((cinfo >> 24) & 0x3Fu) << 16);
-      } else {
-        const uint32_t k = atomicAdd(&s_misc[1], 1u);
-        s_dyn[k] = (uint16_t)s;
-        info = cinfo;  // parked here for the builder, which replaces it with start | count << 16
-      }
+  if (!early_cls) {
+    for (int s = tid; s < S; s += NTH) {
+      const size_t o = e.so(s);
+      const bool pre = s == tid;  // first pass: loaded above
+      const uint16_t cls = pre ? pre_cls : d.obj_cls[o];
+      const uint32_t vis = pre ? pre_vis : d.obj_visited[o];
+      const uint32_t cinfo = cls == MGX_DEAD_CLASS ? 0u : pre ? pre_cinfo : d.cls_tokinfo[cls];
+      bool queue = false;
+      const uint32_t info = classify(s, cls, vis, cinfo, queue);
+      if (queue) s_dyn[atomicAdd(&s_misc[1], 1u)] = (uint16_t)s;
+      s_tokinfo[s] = info;
     }
-    s_tokinfo[s] = info;
+    __syncthreads();
   }
-  __syncthreads();
 
   // ---- phase 0c: per-step token lists, one thread per queued object (a fraction of one wavefront in most envs).
   // The wavefronts that get no objects ("free") take the whole window-map phase and the global tokens meanwhile, so
   // the workgroup's critical path is the longer of the two jobs, not their sum. ----
-  const int ndyn = (int)s_misc[1];
+  int ndyn = (int)s_misc[1];
+  uint32_t seg_lo = 0, seg_hi = 0;   // early_cls: the wavefronts' queue lengths, one byte each
+  if (early_cls) {
+    seg_lo = s_misc[1]; seg_hi = NTH > 4 * MGX_WAVE ? s_misc[2] : 0u;
+    ndyn = 0;
+    for (int w = 0; w < NTH / MGX_WAVE; w++) ndyn += (int)(((w < 4 ? seg_lo : seg_hi) >> (8 * (w & 3))) & 0xFFu);
+  }
   const int nbw = min((ndyn + MGX_WAVE - 1) / MGX_WAVE, (NTH / MGX_WAVE));  // wavefronts with list-building work
   const int nfree = (NTH / MGX_WAVE) - nbw;
   {
     const int f_vibe = d.feat[MGX_F_VIBE], f_group = d.feat[MGX_F_GROUP], f_agent = d.feat[MGX_F_AGENT_ID], f_tag = d.feat[MGX_F_TAG];
     VP feat = vp + d.sec[MGX_SEC_INV_FEATURES];
     for (int i = tid; i < ndyn; i += NTH) {
-      const int s = s_dyn[i];
+      int qi = i;
+      if (early_cls) {   // i-th queued slot -> (wavefront segment, rank)
+        int w = 0, r = i;
+        for (; w < NTH / MGX_WAVE - 1; w++) {
+          const int c = (int)(((w < 4 ? seg_lo : seg_hi) >> (8 * (w & 3))) & 0xFFu);
+          if (r < c) break;
+          r -= c;
+        }
+        qi = w * MGX_WAVE + r;
+      }
+      const int s = s_dyn[qi];
       const uint32_t cinfo = s_tokinfo[s];
       // every field of the slot at once: independent loads, one memory round trip
       const size_t o = e.so(s);
