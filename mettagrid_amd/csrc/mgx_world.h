@@ -2679,8 +2679,9 @@ __global__ void __launch_bounds__(MGX_WAVE) mgx_init_kernel(const MgxDev* __rest
 // the entries of a device LIST whose length the host need not know: a small fixed grid walks it (`*env_list_n` entries).
 #define MGX_INIT_THREADS 256
 #define MGX_INIT_MAX_PASSES 1024   // maps up to 255 x 255 = 1 017 passes of 64 cells
+#define MGX_INIT_STAT_CELLS 256     // game stat ids below this are counted in LDS during construction (objects.<type>)
 static __device__ void mgx_init_wave_env(const MgxDev& d, const int env, const uint16_t* class_maps, const int32_t* map_index,
-                                         const uint32_t* seeds, uint16_t* s_occ, uint16_t* s_ag, int* s_tot);
+                                         const uint32_t* seeds, uint16_t* s_occ, uint16_t* s_ag, int* s_tot, uint32_t* s_cnt);
 // std::mt19937(seed) (bits/random.tcc seed()) of whole batches: one LANE per env, so that the 624 stores of a wavefront
 // are 256 contiguous bytes each (the state is env-minor: [word][env]).  Construction of all envs and masked restarts use it
 // (the in-kernel seeding of mgx_init_wave_kernel writes one 4-byte word per 64-byte line and env: 8 GB of partial-line
@@ -2705,10 +2706,11 @@ __global__ void __launch_bounds__(MGX_INIT_THREADS) mgx_init_wave_kernel(const M
   const MgxDev& d = *dp;
   __shared__ uint16_t s_occ[MGX_INIT_MAX_PASSES], s_ag[MGX_INIT_MAX_PASSES];
   __shared__ int s_tot[2];
+  __shared__ uint32_t s_cnt[MGX_INIT_STAT_CELLS];
   if (env_list) {
     const int n = (int)*env_list_n;
     for (int k = blockIdx.x; k < n; k += gridDim.x) {
-      mgx_init_wave_env(d, env_list[k], class_maps, map_index, seeds, s_occ, s_ag, s_tot);
+      mgx_init_wave_env(d, env_list[k], class_maps, map_index, seeds, s_occ, s_ag, s_tot, s_cnt);
       __syncthreads();
     }
     return;
@@ -2716,10 +2718,10 @@ __global__ void __launch_bounds__(MGX_INIT_THREADS) mgx_init_wave_kernel(const M
   const int env = blockIdx.x;
   if (env >= d.E) return;
   if (env_mask && !env_mask[env]) return;
-  mgx_init_wave_env(d, env, class_maps, map_index, seeds, s_occ, s_ag, s_tot);
+  mgx_init_wave_env(d, env, class_maps, map_index, seeds, s_occ, s_ag, s_tot, s_cnt);
 }
 static __device__ void mgx_init_wave_env(const MgxDev& d, const int env, const uint16_t* class_maps, const int32_t* map_index,
-                                         const uint32_t* seeds, uint16_t* s_occ, uint16_t* s_ag, int* s_tot) {
+                                         const uint32_t* seeds, uint16_t* s_occ, uint16_t* s_ag, int* s_tot, uint32_t* s_cnt) {
   MgxEnvX e(d, d.P, env);
   const size_t E = (size_t)d.E;
   const int tid = threadIdx.x, lane = tid & (MGX_WAVE - 1), wave = tid / MGX_WAVE, NW = (int)blockDim.x / MGX_WAVE;
@@ -2734,6 +2736,7 @@ static __device__ void mgx_init_wave_env(const MgxDev& d, const int env, const u
   const int HW = d.H * d.W, npass = (HW + MGX_WAVE - 1) / MGX_WAVE;
   const uint16_t* cm = class_maps + (size_t)(map_index ? map_index[env] : env) * HW;
   const unsigned long long lt = (1ull << lane) - 1ull;
+  for (int t = tid; t < MGX_INIT_STAT_CELLS; t += (int)blockDim.x) s_cnt[t] = 0u;   // (visible behind the barriers of (A) and (B))
   // (A) occupied / agent cells per pass
   for (int p = wave; p < npass; p += NW) {
     const int cellidx = p * MGX_WAVE + lane;
@@ -2803,8 +2806,14 @@ static __device__ void mgx_init_wave_env(const MgxDev& d, const int env, const u
     }
     const int os = C[MGX_C_OBJECTS_STAT];
     if (os >= 0) {
-      atomicAdd(&d.game_stats[(size_t)env * d.NG + os], 1.f);
-      atomicOr(&d.game_touched[(size_t)env * d.NGW + (os >> 5)], 1u << (os & 31));
+      // objects.<type> += 1 (mettagrid_c.cpp:243-245): counted in LDS and added once per stat behind the barrier.  As one
+      // float atomic + one atomicOr per object in HBM — float atomics execute at the memory side on gfx950 — the counters
+      // WERE the construction of a whole batch: 12 M atomics at rung 3 (8.6 ms), 52 M at rung 4 (102 ms).
+      if (os < MGX_INIT_STAT_CELLS) atomicAdd(&s_cnt[os], 1u);
+      else {
+        atomicAdd(&d.game_stats[(size_t)env * d.NG + os], 1.f);
+        atomicOr(&d.game_touched[(size_t)env * d.NGW + (os >> 5)], 1u << (os & 31));
+      }
     }
     if (d.X && d.obj_tags)
       for (int w = 0; w < MGX_TAG_WORDS; w++) d.obj_tags[e.so(slot) * MGX_TAG_WORDS + w] = (uint32_t)C[MGX_C_TAGS + w];
@@ -2812,6 +2821,18 @@ static __device__ void mgx_init_wave_env(const MgxDev& d, const int env, const u
   if (__ballot(overflow) && lane == 0) atomicOr(&d.err[env], 8u);
   __threadfence_block();   // the objects written by other wavefronts are read below
   __syncthreads();
+  // the object counts: whole numbers added to cells nothing else writes during construction (n additions of 1.f = + n)
+  for (int t0 = 0; t0 < min(d.NG, MGX_INIT_STAT_CELLS); t0 += (int)blockDim.x) {
+    const int t = t0 + tid;
+    const uint32_t n = t < min(d.NG, MGX_INIT_STAT_CELLS) ? s_cnt[t] : 0u;
+    if (n) d.game_stats[(size_t)env * d.NG + t] += (float)n;
+    const unsigned long long m = __ballot(n != 0);   // this wavefront's 64 stat ids = two words of the key-exists bits
+    if (m && lane == 0) {
+      const int w = (t0 + wave * MGX_WAVE) >> 5;
+      if ((uint32_t)m) d.game_touched[(size_t)env * d.NGW + w] |= (uint32_t)m;
+      if ((uint32_t)(m >> 32)) d.game_touched[(size_t)env * d.NGW + w + 1] |= (uint32_t)(m >> 32);
+    }
+  }
   const int nobj = min(s_tot[0], d.S), nag = min(s_tot[1], d.A);
   if (tid == (int)blockDim.x - 1 && seeds) {   // std::mt19937(seed): bits/random.tcc seed() — beside the registration pass below
     uint32_t x = seeds[env];   // (seeds == nullptr: mgx_seed_mt_kernel has done it)
