@@ -2833,6 +2833,7 @@ static __device__ void mgx_init_wave_env(const MgxDev& d, const int env, const u
       if ((uint32_t)(m >> 32)) d.game_touched[(size_t)env * d.NGW + w + 1] |= (uint32_t)(m >> 32);
     }
   }
+  __syncthreads();   // wavefront 0 reuses the counters for the list lengths below
   const int nobj = min(s_tot[0], d.S), nag = min(s_tot[1], d.A);
   if (tid == (int)blockDim.x - 1 && seeds) {   // std::mt19937(seed): bits/random.tcc seed() — beside the registration pass below
     uint32_t x = seeds[env];   // (seeds == nullptr: mgx_seed_mt_kernel has done it)
@@ -2843,39 +2844,93 @@ static __device__ void mgx_init_wave_env(const MgxDev& d, const int env, const u
     }
   }
   if (wave != 0) return;
-  if (lane == 0) {
-    d.num_objs[env] = (uint32_t)nobj;
-    if (d.X) {
-      int nf = 0, nm = 0, nts = 0;
-      for (int slot = 0; slot < nobj; slot++) {   // registrations in object order
-        const int32_t* C = mgx_cls(d, d.obj_cls[e.so(slot)]);
-        const uint16_t rc = d.obj_rc[e.so(slot)];
-        for (int w = 0; w < MGX_TAG_WORDS && d.NL > 0; w++) {  // TagIndex::register_object (core/tag_index.cpp:9-19)
-          for (uint32_t bits = (uint32_t)C[MGX_C_TAGS + w]; bits; bits &= bits - 1) {
-            int li = e.tag_list(w * 32 + __ffs(bits) - 1);
-            if (li >= 0) { uint16_t n = e.tl_count(li); e.tl_items(li)[n] = (uint16_t)slot; e.tl_count(li) = n + 1; }
+  if (lane == 0) d.num_objs[env] = (uint32_t)nobj;
+  // Registrations in object order (TagIndex, AOETracker, TerritoryTracker), 64 objects at a time: a list's entries of a chunk
+  // are the lanes that have it, in lane order (ballot rank / wavefront scan), behind the entries of the chunks before —
+  // what the one-lane loop over the objects gave (`slot` ascending), without its ~3 dependent HBM accesses per object and
+  // tag (a rung-4 env: ~400 objects, 3 ms of every step that restarted an env).  List lengths live in LDS (s_cnt).
+  int nf = 0, nm = 0, nts = 0;
+  if (d.X) {
+    const bool lists_in_lds = d.NL <= MGX_INIT_STAT_CELLS;
+    volatile uint32_t* s_len = s_cnt;   // list lengths: written by lane 0, read by every lane in the next round (same wavefront: LDS in program order)
+    for (int t = lane; t < min(d.NL, MGX_INIT_STAT_CELLS); t += MGX_WAVE) s_len[t] = 0u;
+    auto excl_scan = [&](int v, int& total) {
+      int inc = v;
+      for (int o = 1; o < MGX_WAVE; o <<= 1) { const int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+      total = __shfl(inc, MGX_WAVE - 1);
+      return inc - v;
+    };
+    for (int base = 0; base < nobj; base += MGX_WAVE) {
+      const int slot = base + lane;
+      const bool valid = slot < nobj;
+      const int32_t* C = mgx_cls(d, valid ? d.obj_cls[e.so(slot)] : d.obj_cls[e.so(base)]);
+      const uint16_t rc = valid ? d.obj_rc[e.so(slot)] : (uint16_t)0;
+      for (int w = 0; w < MGX_TAG_WORDS && d.NL > 0; w++) {  // TagIndex::register_object (core/tag_index.cpp:9-19)
+        const uint32_t bits = valid ? (uint32_t)C[MGX_C_TAGS + w] : 0u;
+        uint32_t any = bits;   // union over the wavefront
+        for (int o = 1; o < MGX_WAVE; o <<= 1) any |= (uint32_t)__shfl_xor((int)any, o);
+        for (; any; any &= any - 1) {
+          const int b = __ffs(any) - 1;
+          const int li = e.tag_list(w * 32 + b);
+          if (li < 0) continue;
+          const unsigned long long m = __ballot((bits >> b) & 1u);
+          if (lists_in_lds) {
+            const uint32_t n0 = s_len[li];
+            if ((bits >> b) & 1u) e.tl_items(li)[n0 + (uint32_t)__popcll(m & lt)] = (uint16_t)slot;
+            if (lane == 0) s_len[li] = n0 + (uint32_t)__popcll(m);
+          } else if (lane == 0) {   // more lists than cells: the serial form for this tag
+            for (unsigned long long mm = m; mm; mm &= mm - 1) {
+              const uint16_t n = e.tl_count(li);
+              e.tl_items(li)[n] = (uint16_t)(base + __ffsll((long long)mm) - 1);
+              e.tl_count(li) = n + 1;
+            }
           }
         }
-        for (int i = 0; i < C[MGX_C_AOE_COUNT]; i++) {  // AOETracker::register_source (mettagrid_c.cpp:249-252)
-          int a = C[MGX_C_AOE_START] + i;
-          const int32_t* AO = d.P + d.sec[MGX_SEC_AOES] + a * MGX_AO_WORDS;
-          if (AO[MGX_AO_STATIC]) {
-            if (nf < d.NF) { size_t q = (size_t)env * d.NF + nf; d.fx_obj[q] = (uint16_t)slot; d.fx_aoe[q] = (uint16_t)a; d.fx_rc[q] = rc; nf++; }
-            else e.flag(8u);
-          } else if (nm < d.NM) {
-            size_t q = (size_t)env * d.NM + nm; d.mb_obj[q] = (uint16_t)slot; d.mb_aoe[q] = (uint16_t)a; nm++;
-          } else {
-            e.flag(8u);
-          }
-        }
-        for (int i = 0; i < C[MGX_C_TERR_COUNT]; i++)  // TerritoryTracker::register_source (:254-257)
-          if (nts < d.NTS) { size_t q = (size_t)env * d.NTS + nts; d.ts_obj[q] = (uint16_t)slot; d.ts_ctrl[q] = (uint16_t)(C[MGX_C_TERR_START] + i); d.ts_rc[q] = rc; nts++; }
-          else e.flag(8u);
       }
+      {  // AOETracker::register_source (mettagrid_c.cpp:249-252): an object's sources in class order, fixed and mobile lists apart
+        const int na = valid ? C[MGX_C_AOE_COUNT] : 0;
+        int lf = 0, lm = 0;
+        for (int i = 0; i < na; i++) {
+          if (d.P[d.sec[MGX_SEC_AOES] + (C[MGX_C_AOE_START] + i) * MGX_AO_WORDS + MGX_AO_STATIC]) lf++; else lm++;
+        }
+        int tf, tm;
+        int pf = nf + excl_scan(lf, tf), pm = nm + excl_scan(lm, tm);
+        bool over = false;
+        for (int i = 0; i < na; i++) {
+          const int a = C[MGX_C_AOE_START] + i;
+          if (d.P[d.sec[MGX_SEC_AOES] + a * MGX_AO_WORDS + MGX_AO_STATIC]) {
+            if (pf < d.NF) { const size_t q = (size_t)env * d.NF + pf; d.fx_obj[q] = (uint16_t)slot; d.fx_aoe[q] = (uint16_t)a; d.fx_rc[q] = rc; }
+            else over = true;
+            pf++;
+          } else {
+            if (pm < d.NM) { const size_t q = (size_t)env * d.NM + pm; d.mb_obj[q] = (uint16_t)slot; d.mb_aoe[q] = (uint16_t)a; }
+            else over = true;
+            pm++;
+          }
+        }
+        nf = min(nf + tf, d.NF); nm = min(nm + tm, d.NM);
+        // TerritoryTracker::register_source (:254-257)
+        const int nt = valid ? C[MGX_C_TERR_COUNT] : 0;
+        int tt;
+        int pt = nts + excl_scan(nt, tt);
+        for (int i = 0; i < nt; i++, pt++) {
+          if (pt < d.NTS) { const size_t q = (size_t)env * d.NTS + pt; d.ts_obj[q] = (uint16_t)slot; d.ts_ctrl[q] = (uint16_t)(C[MGX_C_TERR_START] + i); d.ts_rc[q] = rc; }
+          else over = true;
+        }
+        nts = min(nts + tt, d.NTS);
+        if (over) atomicOr(&d.err[env], 8u);
+      }
+    }
+    if (lists_in_lds)
+      for (int t = lane; t < d.NL; t += MGX_WAVE) e.tl_count(t) = (uint16_t)s_len[t];
+    for (int i = lane; i < d.A * d.NT; i += MGX_WAVE) d.terr_prev[(size_t)env * d.A * d.NT + i] = -1;
+    __threadfence_block();   // the lists are read by lane 0 below (materialized queries)
+  }
+  if (lane == 0) {
+    if (d.X) {
       if (d.NF) d.fx_count[env] = (uint16_t)nf;
       if (d.NM) d.mb_count[env] = (uint16_t)nm;
       if (d.NTS) d.ts_count[env] = (uint16_t)nts;
-      for (int i = 0; i < d.A * d.NT; i++) d.terr_prev[(size_t)env * d.A * d.NT + i] = -1;
       d.next_event[env] = 0;
       const int32_t* mq = d.P + d.sec[MGX_SEC_MATQ];   // QuerySystem::compute_all (query_system.cpp:91-117)
       for (int i = 0; i < d.n_matq; i++, mq += MGX_MQ_WORDS) {
