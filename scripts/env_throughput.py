@@ -18,10 +18,17 @@ from mettagrid_amd.mapgen import random_class_maps  # noqa: E402
 
 E = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 1500
-spec = presets.rung3_spec()
-spec.max_steps = 1000
-prog = compile_spec(spec, 32, 32, max_objects=192)
-pool = random_class_maps(prog, 32, 32, {"wall": 40, "extractor": 8, "chest": 4}, {"red": 8, "blue": 8}, range(256))
+RUNG = int(os.environ.get("MGX_ENV_RUNG", "3"))   # 4: the rung-4 preset (64 x 64, 64 agents, area effects / territory / events / queries)
+if RUNG == 4:
+    spec = presets.rung4_spec()
+    spec.max_steps = 1000
+    prog = compile_spec(spec, 64, 64, max_objects=presets.RUNG4_MAX_OBJECTS)
+    pool = random_class_maps(prog, 64, 64, dict(presets.RUNG4_OBJECTS), dict(presets.RUNG4_AGENTS), range(256))
+else:
+    spec = presets.rung3_spec()
+    spec.max_steps = 1000
+    prog = compile_spec(spec, 32, 32, max_objects=192)
+    pool = random_class_maps(prog, 32, 32, {"wall": 40, "extractor": 8, "chest": 4}, {"red": 8, "blue": 8}, range(256))
 out = {}
 only = sys.argv[3].split(",") if len(sys.argv) > 3 else None   # e.g. "unchecked_actions" (profiling runs)
 for validate, stats in ((False, True), (False, False), (True, True)):
@@ -52,5 +59,5 @@ for validate, stats in ((False, True), (False, False), (True, True)):
     out[key] = {"agent_steps_per_s": env.num_agents * steps / dt, "ms_per_step": dt * 1e3 / steps,
                 "episodes_finished": int(ep.sum()), "env_error_bits": int(bits), "infos_returned": n_infos, "episodes_in_infos": n_eps}
     env.close()
-print(json.dumps({"workload": f"rung3 rules through MettaGridBatchedEnv, {E} envs x 16 agents, max_steps=1000, pool of 256 maps, "
+print(json.dumps({"workload": f"rung{RUNG} rules through MettaGridBatchedEnv, {E} envs x {prog.num_agents} agents, max_steps=1000, pool of 256 maps, "
                               f"desync, {steps} timed steps", **out}))
