@@ -1,3 +1,4 @@
+# The default bench.py run end to end, timed, with the fields of its line printed (GPU box).
 mkdir -p gpurun_out/r4f
 ( time python bench.py > gpurun_out/r4f/bench_default.json 2> gpurun_out/r4f/bench_default.err ) 2> gpurun_out/r4f/time.txt
 tail -3 gpurun_out/r4f/time.txt

@@ -1,3 +1,4 @@
+# Bounded small test first, then the parity files, then a rung-3 and a rung-4 bench line (GPU box).
 set -e
 mkdir -p gpurun_out/r4o
 timeout -k 10 150 python -m pytest tests/test_gpu_golden.py -x -q -k "rung3 or rung2 or torture" > gpurun_out/r4o/small.log 2>&1 || { tail -30 gpurun_out/r4o/small.log; exit 1; }

@@ -1,3 +1,4 @@
+# Agent-steps/s through MettaGridBatchedEnv at rung 3 and rung 4, and the rung-4 kernel breakdown under rocprofv3 (GPU box).
 set -e
 mkdir -p gpurun_out/r4w
 python scripts/env_throughput.py 65536 1500 unchecked_actions > gpurun_out/r4w/plain3.json 2> gpurun_out/r4w/plain3.err
